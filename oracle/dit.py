@@ -1,0 +1,198 @@
+"""Oracle: DiffusionTransformer / ContinuousTransformer forward (fp32, functional).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Every function cites the reference
+file:line it restates (paths relative to /root/reference/stable_audio_tools/).
+
+``sd`` is a state dict with the reference's key names *relative to* the
+``DiffusionTransformer`` module (i.e. ``model.model.`` stripped): ``timestep_features.weight``,
+``to_timestep_embed.{0,2}.{weight,bias}``, ``to_cond_embed.{0,2}.weight``,
+``to_global_embed.{0,2}.weight``, ``preprocess_conv.weight``, ``postprocess_conv.weight``,
+``transformer.project_in.weight``, ``transformer.project_out.weight``,
+``transformer.rotary_pos_emb.inv_freq``, ``transformer.layers.N.*``.
+
+``rnd`` is the *matched-rounding* hook: ``None`` = pure fp32 (the reference's CPU path);
+``bf16_round`` = round tensors to bf16 at exactly the points where the HIP kernels store
+bf16 (GEMM operands, q/k/v, P, attention output, FF hidden).  Accumulation stays fp32.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _r(rnd, x):
+    return x if rnd is None else rnd(x)
+
+
+# models/transformer.py:188-206 (LayerNorm: F.layer_norm with gamma, beta buffer, eps 1e-5)
+def layer_norm(x, gamma, beta):
+    return F.layer_norm(x, x.shape[-1:], weight=gamma, bias=beta)
+
+
+# models/transformer.py:130-148 (RotaryEmbedding.forward_from_seq_len / forward)
+def rotary_freqs(inv_freq, seq_len):
+    t = torch.arange(seq_len, dtype=torch.float32)
+    freqs = torch.einsum("i,j->ij", t, inv_freq.float())
+    return torch.cat((freqs, freqs), dim=-1)  # [S, rot_dim]
+
+
+# models/transformer.py:158-183 (rotate_half / apply_rotary_pos_emb, partial rotary, fp32)
+def apply_rotary(t, freqs):
+    rot_dim = freqs.shape[-1]
+    seq_len = t.shape[-2]
+    freqs = freqs[-seq_len:, :]
+    t_rot, t_pass = t[..., :rot_dim], t[..., rot_dim:]
+    half = rot_dim // 2
+    x1, x2 = t_rot[..., :half], t_rot[..., half:]
+    rotated = torch.cat((-x2, x1), dim=-1)
+    t_rot = t_rot * freqs.cos() + rotated * freqs.sin()
+    return torch.cat((t_rot, t_pass), dim=-1)
+
+
+# models/transformer.py:525-536 (the einsum/softmax(fp32) fallback branch = CPU path)
+def attention_core(q, k, v, rnd=None):
+    """q [B,H,Nq,dh]; k,v [B,KVH,Nk,dh]; GQA via repeat_interleave (transformer.py:512-515)."""
+    h, kvh = q.shape[1], k.shape[1]
+    if h != kvh:
+        k = k.repeat_interleave(h // kvh, dim=1)
+        v = v.repeat_interleave(h // kvh, dim=1)
+    scale = 1.0 / math.sqrt(q.shape[-1])
+    dots = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    if rnd is None:
+        attn = F.softmax(dots, dim=-1, dtype=torch.float32)
+        return torch.einsum("bhij,bhjd->bhid", attn, v)
+    # matched rounding: P = exp(s - max) is rounded to bf16 before P.V; the normaliser is
+    # the fp32 sum of the un-rounded P (what the flash kernel accumulates).
+    m = dots.amax(dim=-1, keepdim=True)
+    p = torch.exp(dots - m)
+    l = p.sum(dim=-1, keepdim=True)
+    return torch.einsum("bhij,bhjd->bhid", rnd(p), v) / l
+
+
+def _heads(t, h):
+    b, n, _ = t.shape
+    return t.view(b, n, h, -1).permute(0, 2, 1, 3)
+
+
+def _merge(t):
+    b, h, n, d = t.shape
+    return t.permute(0, 2, 1, 3).reshape(b, n, h * d)
+
+
+# models/transformer.py:407-554 (Attention.forward), self-attention branch (to_qkv)
+def self_attention(sd, pfx, x, freqs, num_heads, rnd=None):
+    w_qkv = _r(rnd, sd[pfx + "to_qkv.weight"])
+    q, k, v = F.linear(x, w_qkv).chunk(3, dim=-1)
+    q, k, v = (_heads(t, num_heads) for t in (q, k, v))
+    q = apply_rotary(q.float(), freqs)      # transformer.py:438-452
+    k = apply_rotary(k.float(), freqs)
+    q, k, v = _r(rnd, q), _r(rnd, k), _r(rnd, v)
+    out = _merge(attention_core(q, k, v, rnd))
+    out = _r(rnd, out)
+    return F.linear(out, _r(rnd, sd[pfx + "to_out.weight"]))
+
+
+# models/transformer.py:407-554, cross-attention branch (to_q / to_kv; no RoPE: :438)
+def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
+    q = _heads(F.linear(x, _r(rnd, sd[pfx + "to_q.weight"])), num_heads)
+    kv = F.linear(context, _r(rnd, sd[pfx + "to_kv.weight"]))
+    k, v = kv.chunk(2, dim=-1)
+    kv_heads = k.shape[-1] // dim_heads
+    k, v = _heads(k, kv_heads), _heads(v, kv_heads)
+    q, k, v = _r(rnd, q), _r(rnd, k), _r(rnd, v)
+    out = _merge(attention_core(q, k, v, rnd))
+    out = _r(rnd, out)
+    return F.linear(out, _r(rnd, sd[pfx + "to_out.weight"]))
+
+
+# models/transformer.py:211-287 (GLU + FeedForward; value = first half, gate = second half)
+def feed_forward(sd, pfx, x, rnd=None):
+    h = F.linear(x, _r(rnd, sd[pfx + "ff.0.proj.weight"]), sd[pfx + "ff.0.proj.bias"])
+    val, gate = h.chunk(2, dim=-1)
+    h = _r(rnd, val * F.silu(gate))
+    return F.linear(h, _r(rnd, sd[pfx + "ff.2.weight"]), sd[pfx + "ff.2.bias"])
+
+
+# models/transformer.py:656-702 (TransformerBlock.forward, non-adaLN branch :691-700)
+def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None):
+    h = _r(rnd, layer_norm(x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"]))
+    x = x + self_attention(sd, pfx + "self_attn.", h, freqs, num_heads, rnd)
+    if context is not None:
+        h = _r(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]))
+        x = x + cross_attention(sd, pfx + "cross_attn.", h, context, num_heads, dim_heads, rnd)
+    h = _r(rnd, layer_norm(x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"]))
+    x = x + feed_forward(sd, pfx + "ff.", h, rnd)
+    return x
+
+
+# models/transformer.py:764-809 (ContinuousTransformer.forward)
+def continuous_transformer(sd, x, prepend_embeds, context, depth, num_heads, rnd=None, return_hidden=False):
+    pfx = "transformer."
+    x = F.linear(x, sd[pfx + "project_in.weight"])
+    x = torch.cat((prepend_embeds, x), dim=-2)
+    dim_heads = x.shape[-1] // num_heads
+    freqs = rotary_freqs(sd[pfx + "rotary_pos_emb.inv_freq"], x.shape[1])
+    hidden = []
+    for i in range(depth):
+        x = transformer_block(sd, f"{pfx}layers.{i}.", x, context, freqs, num_heads, dim_heads, rnd)
+        if return_hidden:
+            hidden.append(x)
+    out = F.linear(x, sd[pfx + "project_out.weight"])
+    return (out, hidden) if return_hidden else out
+
+
+# models/blocks.py:88-97 (FourierFeatures)
+def fourier_features(weight, inp):
+    f = 2 * math.pi * inp @ weight.T
+    return torch.cat([f.cos(), f.sin()], dim=-1)
+
+
+def _mlp(sd, pfx, x, bias):
+    x = F.linear(x, sd[pfx + "0.weight"], sd[pfx + "0.bias"] if bias else None)
+    x = F.silu(x)
+    return F.linear(x, sd[pfx + "2.weight"], sd[pfx + "2.bias"] if bias else None)
+
+
+# models/dit.py:135-226 (DiffusionTransformer._forward; global_cond_type == "prepend")
+def dit_inner_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, rnd=None, return_hidden=False):
+    """x [B,C,T] fp32, t [B], cross_attn_cond [B,Lc,Dc] or None, global_embed [B,Dg] or None."""
+    context = None
+    if cross_attn_cond is not None:
+        context = _r(rnd, _mlp(sd, "to_cond_embed.", cross_attn_cond, bias=False))   # dit.py:150
+    if global_embed is not None:
+        global_embed = _mlp(sd, "to_global_embed.", global_embed, bias=False)          # dit.py:154
+    timestep_embed = _mlp(sd, "to_timestep_embed.", fourier_features(sd["timestep_features.weight"], t[:, None]), bias=True)
+    global_embed = timestep_embed if global_embed is None else global_embed + timestep_embed  # dit.py:179-182
+    prepend = global_embed.unsqueeze(1)                                                  # dit.py:185-195
+    x = F.conv1d(x, sd["preprocess_conv.weight"]) + x                                    # dit.py:197
+    x = x.transpose(1, 2)                                                                # dit.py:199
+    out = continuous_transformer(sd, x, prepend, context, depth, num_heads, rnd, return_hidden)
+    if return_hidden:
+        out, hidden = out
+    out = out.transpose(1, 2)[:, :, 1:]                                                  # dit.py:219
+    out = F.conv1d(out, sd["postprocess_conv.weight"]) + out                             # dit.py:224
+    return (out, hidden) if return_hidden else out
+
+
+# models/dit.py:228-364 (DiffusionTransformer.forward: batched CFG :270-349)
+def dit_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, cfg_scale=1.0, scale_phi=0.0,
+                negative_cross_attn_cond=None, rnd=None):
+    if cfg_scale != 1.0 and cross_attn_cond is not None:
+        bx = torch.cat([x, x], dim=0)
+        bt = torch.cat([t, t], dim=0)
+        bg = None if global_embed is None else torch.cat([global_embed, global_embed], dim=0)
+        null = torch.zeros_like(cross_attn_cond) if negative_cross_attn_cond is None else negative_cross_attn_cond
+        bc = torch.cat([cross_attn_cond, null], dim=0)
+        out = dit_inner_forward(sd, bx, bt, bc, bg, depth, num_heads, rnd)
+        cond, uncond = torch.chunk(out, 2, dim=0)
+        cfg = uncond + (cond - uncond) * cfg_scale                                       # dit.py:338-339
+        if scale_phi != 0.0:                                                             # dit.py:342-345
+            cond_std = cond.std(dim=1, keepdim=True)
+            cfg_std = cfg.std(dim=1, keepdim=True)
+            return scale_phi * (cfg * (cond_std / cfg_std)) + (1 - scale_phi) * cfg
+        return cfg
+    return dit_inner_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, rnd)
