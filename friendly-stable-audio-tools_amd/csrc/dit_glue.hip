@@ -1,0 +1,364 @@
+// Small fp32 kernels around the DiT blocks: conditioning / timestep MLPs,
+// the folded 1x1-conv + project_in / project_out, CFG combine + VDenoiser scalings, the
+// DPM-Solver++(3M) SDE state update, VAE sampling and int16 quantisation.  All of them are
+// HBM/L2-bound elementwise or skinny-GEMV work kept in fp32 (the reference computes them
+// in fp32 on CPU); none is reshaped into a GEMM to reach MFMA.
+#include "dit_glue.h"
+
+namespace {
+
+// y[r][n] = act( sum_k x[r][k] * W[n][k] + bias[n] ) (+ add[r][n]) ; one wave per n, RB rows
+// per wave.  x row stride ldx, y row stride ldy (lets the caller write straight into the
+// prepend-token rows of the residual stream).  OUT_BF16: y is bf16 (GEMM A operand).
+template <int RB, bool OUT_BF16>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, const float* __restrict__ add,
+                                                           int ldadd, void* __restrict__ yv, int ldy, int R, int N, int K,
+                                                           int act) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = blockIdx.y * RB;
+    if (n >= N) return;
+    float acc[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) acc[i] = 0.f;
+    const float* wr = W + (size_t)n * K;
+    for (int k = lane * 4; k < K; k += 256) {
+        float4 w = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            int r = r0 + i;
+            r = r < R ? r : R - 1;
+            float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + k);
+            acc[i] += (w.x * v.x + w.y * v.y) + (w.z * v.z + w.w * v.w);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            int r = r0 + i;
+            if (r < R) {
+                float v = acc[i] + bv;
+                if (act == 1) v = silu_f(v);
+                if (add) v += add[(size_t)r * ldadd + n];
+                if (OUT_BF16)
+                    reinterpret_cast<bf16_t*>(yv)[(size_t)r * ldy + n] = f32_to_bf16(v);
+                else
+                    reinterpret_cast<float*>(yv)[(size_t)r * ldy + n] = v;
+            }
+        }
+    }
+}
+
+// models/blocks.py:95-97: f = 2*pi*t*w ; cat(cos f, sin f)
+__global__ void fourier_kernel(const float* __restrict__ t, float t_const, const float* __restrict__ w, float* __restrict__ out,
+                               int B, int half_feat) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half_feat) return;
+    int b = i / half_feat, j = i - b * half_feat;
+    float tv = t ? t[b] : t_const;
+    float f = (6.283185307179586f * tv) * w[j];
+    out[(size_t)b * 2 * half_feat + j] = cosf(f);
+    out[(size_t)b * 2 * half_feat + half_feat + j] = sinf(f);
+}
+
+// Weff[n][c] = Win[n][c] + sum_j Win[n][j] * Wpre[j][c]   (project_in o (I + preprocess_conv))
+__global__ void fold_in_kernel(const float* __restrict__ Win, const float* __restrict__ Wpre, float* __restrict__ Weff, int D, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * C) return;
+    int n = i / C, c = i - n * C;
+    float acc = Win[i];
+    for (int j = 0; j < C; ++j) acc += Win[n * C + j] * Wpre[j * C + c];
+    Weff[i] = acc;
+}
+// Weff[c][n] = Wout[c][n] + sum_j Wpost[c][j] * Wout[j][n]   ((I + postprocess_conv) o project_out)
+__global__ void fold_out_kernel(const float* __restrict__ Wout, const float* __restrict__ Wpost, float* __restrict__ Weff, int D, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * D) return;
+    int c = i / D, n = i - c * D;
+    float acc = Wout[i];
+    for (int j = 0; j < C; ++j) acc += Wpost[c * C + j] * Wout[j * D + n];
+    Weff[i] = acc;
+}
+
+// X[b, 1+t, n] = xscale * sum_c Weff[n][c] * x[b % xB][c][t]       (C <= 64)
+constexpr int IP_TT = 8;
+__global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ Weff,
+                                                         float* __restrict__ X, int xB, int C, int T, int S, int D, float xscale) {
+    __shared__ float xs[64][IP_TT];
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * IP_TT;
+    const float* xb = x + (size_t)(b % xB) * C * T;
+    for (int i = threadIdx.x; i < C * IP_TT; i += 256) {
+        int c = i / IP_TT, tt = i - c * IP_TT;
+        int t = t0 + tt;
+        xs[c][tt] = (t < T) ? xb[(size_t)c * T + t] * xscale : 0.f;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < D; n += 256) {
+        float acc[IP_TT];
+#pragma unroll
+        for (int tt = 0; tt < IP_TT; ++tt) acc[tt] = 0.f;
+        const float* wr = Weff + (size_t)n * C;
+        for (int c = 0; c < C; ++c) {
+            float w = wr[c];
+#pragma unroll
+            for (int tt = 0; tt < IP_TT; ++tt) acc[tt] += w * xs[c][tt];
+        }
+#pragma unroll
+        for (int tt = 0; tt < IP_TT; ++tt) {
+            int t = t0 + tt;
+            if (t < T) X[((size_t)b * S + 1 + t) * D + n] = acc[tt];
+        }
+    }
+}
+
+// out[b][c][t] = sum_n Weff[c][n] * X[b, 1+t, n] ; one wave per (b,t) row, D % 256 == 0
+template <int NV>
+__global__ __launch_bounds__(256) void output_proj_kernel(const float* __restrict__ X, const float* __restrict__ Weff,
+                                                          float* __restrict__ out, int Bf, int C, int T, int S, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Bf * T) return;
+    const int b = row / T, t = row - b * T;
+    const float4* xr = reinterpret_cast<const float4*>(X + ((size_t)b * S + 1 + t) * D);
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
+    float mine = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float4* wr = reinterpret_cast<const float4*>(Weff + (size_t)c * D);
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float4 w = wr[i * 64 + lane];
+            acc += (w.x * v[i].x + w.y * v[i].y) + (w.z * v[i].z + w.w * v[i].w);
+        }
+        acc = wave_sum(acc);
+        if (lane == c) mine = acc;
+    }
+    if (lane < C) out[((size_t)b * C + lane) * T + t] = mine;
+}
+
+// models/dit.py:336-345 (CFG combine + optional std rescale) then VDenoiser:
+// den = cfg * c_out + x * c_skip.  One thread per (b,t) column, loops the channels.
+__global__ __launch_bounds__(256) void cfg_denoise_kernel(const float* __restrict__ mo, const float* __restrict__ x,
+                                                          float* __restrict__ den, int B, int C, int T, int use_cfg,
+                                                          float cfg_scale, float scale_phi, float c_out, float c_skip) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * T) return;
+    int b = i / T, t = i - b * T;
+    const float* pc = mo + (size_t)b * C * T + t;
+    const float* pu = mo + (size_t)(b + B) * C * T + t;
+    const float* px = x + (size_t)b * C * T + t;
+    float* pd = den + (size_t)b * C * T + t;
+    float ratio_mix = 1.0f;
+    if (use_cfg && scale_phi != 0.0f) {
+        // unbiased std over channels of cond and of the cfg output (torch.std, dim=1)
+        float sc = 0.f, sg = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float vc = pc[(size_t)c * T], vu = pu[(size_t)c * T];
+            sc += vc;
+            sg += vu + (vc - vu) * cfg_scale;
+        }
+        float mc = sc / C, mg = sg / C, qc = 0.f, qg = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float vc = pc[(size_t)c * T], vu = pu[(size_t)c * T];
+            float g = vu + (vc - vu) * cfg_scale;
+            qc += (vc - mc) * (vc - mc);
+            qg += (g - mg) * (g - mg);
+        }
+        float stdc = sqrtf(qc / (C - 1)), stdg = sqrtf(qg / (C - 1));
+        ratio_mix = scale_phi * (stdc / stdg) + (1.0f - scale_phi);
+    }
+    for (int c = 0; c < C; ++c) {
+        float vc = pc[(size_t)c * T];
+        float g = vc;
+        if (use_cfg) {
+            float vu = pu[(size_t)c * T];
+            g = (vu + (vc - vu) * cfg_scale) * ratio_mix;
+        }
+        pd[(size_t)c * T] = g * c_out + px[(size_t)c * T] * c_skip;
+    }
+}
+
+__global__ __launch_bounds__(256) void dpmpp3m_update_kernel(float* __restrict__ x, const float* __restrict__ d,
+                                                             const float* __restrict__ d1, const float* __restrict__ d2,
+                                                             const float* __restrict__ noise, float a, float b, float c1,
+                                                             float c2, float cn, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        float dv = d[i];
+        float v = a * x[i] + b * dv;
+        if (d1) {
+            float d1v = d1[i];
+            v += c1 * (dv - d1v);
+            if (d2) v += c2 * (d1v - d2[i]);
+        }
+        if (noise) v += cn * noise[i];
+        x[i] = v;
+    }
+}
+
+// models/bottleneck.py:46-52
+__global__ __launch_bounds__(256) void vae_sample_kernel(const float* __restrict__ ms, const float* __restrict__ noise,
+                                                         float* __restrict__ z, int B, int C, int T) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * T) return;
+    int64_t ct = (int64_t)C * T;
+    int b = (int)(i / ct);
+    int64_t r = i - (int64_t)b * ct;
+    float mean = ms[(int64_t)b * 2 * ct + r];
+    float scale = ms[(int64_t)b * 2 * ct + ct + r];
+    float sp = scale > 20.f ? scale : log1pf(expf(scale));   // F.softplus (beta 1, threshold 20)
+    z[i] = noise[i] * (sp + 1e-4f) + mean;
+}
+
+// utils/audio_utils.py:21-26
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float m = 0.f;
+    for (; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));   // non-negative floats order like uints
+}
+__global__ __launch_bounds__(256) void to_int16_kernel(const float* __restrict__ x, int16_t* __restrict__ y, int64_t n,
+                                                       const unsigned* __restrict__ peak_bits, int maximize) {
+    float div = __uint_as_float(*peak_bits);
+    if (!maximize) div = fmaxf(div, 1.0f);
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) y[i] = (int16_t)((x[i] / div) * 32767.0f);   // truncation toward zero
+}
+
+// models/blocks.py:318-319 -- standalone SnakeBeta (the VAE kernels fuse it on load)
+__global__ __launch_bounds__(256) void snake_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                    const float* __restrict__ beta, float* __restrict__ y, int C, int T,
+                                                    int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)((i / T) % C);
+    float a = expf(alpha[c]), ib = 1.0f / (expf(beta[c]) + 0.000000001f);
+    float v = x[i];
+    float s = sinf(v * a);
+    y[i] = v + ib * (s * s);
+}
+
+}  // namespace
+
+int glue_small_linear(const float* x, int ldx, const float* W, const float* bias, const float* add, int ldadd, void* y,
+                      int ldy, int R, int N, int K, int act, bool out_bf16, hipStream_t s) {
+    SAT_CHECK_ARG(x && W && y && R > 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0, SAT_E_INVALID,
+                  "small_linear: bad args R=%d N=%d K=%d", R, N, K);
+    constexpr int RB = 8;
+    dim3 grid(cdiv(N, 4), cdiv(R, RB));
+    if (out_bf16)
+        hipLaunchKernelGGL((small_linear_kernel<RB, true>), grid, dim3(256), 0, s, x, ldx, W, bias, add, ldadd, y, ldy, R, N, K, act);
+    else
+        hipLaunchKernelGGL((small_linear_kernel<RB, false>), grid, dim3(256), 0, s, x, ldx, W, bias, add, ldadd, y, ldy, R, N, K, act);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int glue_fourier(const float* t, float t_const, const float* w, float* out, int B, int half_feat, hipStream_t s) {
+    hipLaunchKernelGGL(fourier_kernel, dim3(cdiv(B * half_feat, 256)), dim3(256), 0, s, t, t_const, w, out, B, half_feat);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int glue_fold_in(const float* Win, const float* Wpre, float* Weff, int D, int C, hipStream_t s) {
+    hipLaunchKernelGGL(fold_in_kernel, dim3(cdiv(D * C, 256)), dim3(256), 0, s, Win, Wpre, Weff, D, C);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+int glue_fold_out(const float* Wout, const float* Wpost, float* Weff, int D, int C, hipStream_t s) {
+    hipLaunchKernelGGL(fold_out_kernel, dim3(cdiv(D * C, 256)), dim3(256), 0, s, Wout, Wpost, Weff, D, C);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int glue_input_proj(const float* x, const float* Weff, float* X, int Bf, int xB, int C, int T, int S, int D, float xscale,
+                    hipStream_t s) {
+    SAT_CHECK_ARG(C <= 64, SAT_E_UNSUPPORTED, "input_proj: io_channels %d > 64", C);
+    hipLaunchKernelGGL(input_proj_kernel, dim3(cdiv(T, IP_TT), Bf), dim3(256), 0, s, x, Weff, X, xB, C, T, S, D, xscale);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int glue_output_proj(const float* X, const float* Weff, float* out, int Bf, int C, int T, int S, int D, hipStream_t s) {
+    SAT_CHECK_ARG(C <= 64 && D % 256 == 0 && D / 256 <= 8, SAT_E_UNSUPPORTED, "output_proj: C=%d D=%d unsupported", C, D);
+    dim3 grid(cdiv((int64_t)Bf * T, 4)), block(256);
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(output_proj_kernel<1>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+        case 2: hipLaunchKernelGGL(output_proj_kernel<2>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+        case 3: hipLaunchKernelGGL(output_proj_kernel<3>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+        case 4: hipLaunchKernelGGL(output_proj_kernel<4>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+        case 5: hipLaunchKernelGGL(output_proj_kernel<5>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+        case 6: hipLaunchKernelGGL(output_proj_kernel<6>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+        case 7: hipLaunchKernelGGL(output_proj_kernel<7>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+        default: hipLaunchKernelGGL(output_proj_kernel<8>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+    }
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int glue_cfg_denoise(const float* mo, const float* x, float* den, int B, int C, int T, int use_cfg, float cfg_scale,
+                     float scale_phi, float c_out, float c_skip, hipStream_t s) {
+    hipLaunchKernelGGL(cfg_denoise_kernel, dim3(cdiv((int64_t)B * T, 256)), dim3(256), 0, s, mo, x, den, B, C, T, use_cfg,
+                       cfg_scale, scale_phi, c_out, c_skip);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sat_dpmpp3m_update(float* x_dev, const float* d_dev, const float* d1_dev, const float* d2_dev,
+                                  const float* noise_dev, float a, float b, float c1, float c2, float cn, int64_t n,
+                                  sat_stream_t stream) {
+    SAT_CHECK_ARG(x_dev && d_dev && n > 0, SAT_E_INVALID, "dpmpp3m_update: null state or n <= 0");
+    SAT_CHECK_ARG(!(c1 != 0.f && !d1_dev) && !(c2 != 0.f && !d2_dev) && !(cn != 0.f && !noise_dev), SAT_E_INVALID,
+                  "dpmpp3m_update: non-zero coefficient with a NULL tensor");
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dpmpp3m_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_dev, d_dev,
+                       c1 != 0.f || c2 != 0.f ? d1_dev : nullptr, c2 != 0.f ? d2_dev : nullptr, cn != 0.f ? noise_dev : nullptr, a,
+                       b, c1, c2, cn, n);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sat_vae_sample(const float* mean_scale_dev, const float* noise_dev, float* z_dev, int32_t b, int32_t c,
+                              int32_t t, sat_stream_t stream) {
+    SAT_CHECK_ARG(mean_scale_dev && noise_dev && z_dev && b > 0 && c > 0 && t > 0, SAT_E_INVALID, "vae_sample: bad args");
+    int64_t n = (int64_t)b * c * t;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean_scale_dev,
+                       noise_dev, z_dev, b, c, t);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sat_float_to_int16(const float* x_dev, int16_t* out_dev, int64_t n, int32_t maximize, void* scratch_dev,
+                                  sat_stream_t stream) {
+    SAT_CHECK_ARG(x_dev && out_dev && scratch_dev && n > 0, SAT_E_INVALID, "float_to_int16: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    SAT_HIP(hipMemsetAsync(scratch_dev, 0, 4, s));
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x_dev, n, (unsigned*)scratch_dev);
+    hipLaunchKernelGGL(to_int16_kernel, dim3(blocks), dim3(256), 0, s, x_dev, out_dev, n, (const unsigned*)scratch_dev, maximize);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sat_snake_beta(const float* x_dev, const float* alpha_dev, const float* beta_dev, float* y_dev, int32_t b,
+                              int32_t c, int32_t t, sat_stream_t stream) {
+    SAT_CHECK_ARG(x_dev && alpha_dev && beta_dev && y_dev && b > 0 && c > 0 && t > 0, SAT_E_INVALID, "snake: bad args");
+    int64_t n = (int64_t)b * c * t;
+    hipLaunchKernelGGL(snake_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev, alpha_dev,
+                       beta_dev, y_dev, c, t, n);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}

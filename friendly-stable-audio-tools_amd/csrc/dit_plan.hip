@@ -1,0 +1,504 @@
+// DiT plan: owns the re-packed weights and drives one DiffusionTransformer forward
+// (models/dit.py:135-226 + models/transformer.py:764-809, 656-702 of the reference) as a
+// fixed sequence of HIP kernel launches on the caller's stream.  Host-side C++ only; the
+// arithmetic lives in gemm_bf16.hip / attention.hip / layernorm.hip / dit_glue.hip.
+#include <math.h>
+#include <stdarg.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "dit_glue.h"
+#include "sat_common.h"
+
+// ------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+void sat_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+extern "C" const char* sat_last_error(void) { return g_last_error.c_str(); }
+extern "C" int sat_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------ plan
+namespace {
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    bool dry = true;
+    void* take(size_t bytes) {
+        size_t o = off;
+        off += (size_t)round_up((int64_t)bytes, 256);
+        return dry ? nullptr : base + o;
+    }
+};
+
+struct LayerW {
+    float *pre_g, *pre_b, *cross_g, *cross_b, *ff_g, *ff_b;
+    bf16_t *w_qkv, *w_o, *w_cq, *w_ckv, *w_co, *w_ff1, *w_ff2;
+    float *b_ff1, *b_ff2;
+};
+
+}  // namespace
+
+struct sat_dit_plan {
+    sat_dit_cfg cfg;
+    std::map<std::string, std::pair<const float*, int64_t>> tensors;
+    bool finalized = false;
+    int inner = 0;          // FF inner dim
+    int kvh_cross = 0;
+    char* arena = nullptr;
+    std::vector<LayerW> layers;
+    float *ts_w, *te0_w, *te0_b, *te2_w, *te2_b;
+    float *ce0_w, *ce2_w, *ge0_w, *ge2_w;
+    float *win_eff, *wout_eff;
+    float *rope_cos, *rope_sin, *inv_freq;
+    // per-generation context (sat_dit_prepare_context)
+    char* ctx_buf = nullptr;
+    size_t ctx_cap = 0;
+    int ctx_bf = 0, ctx_lc = 0, ctx_lcpad = 0;
+    bool has_global = false;
+    float* ge = nullptr;            // [bf, D] projected global embedding
+    bf16_t* kc = nullptr;           // [depth][bf, kvh, lcpad, 64]
+    bf16_t* vct = nullptr;          // [depth][bf, kvh, 64, lcpad]
+};
+
+namespace {
+
+int get_tensor(sat_dit_plan* p, const std::string& name, int64_t numel, const float** out) {
+    auto it = p->tensors.find(name);
+    SAT_CHECK_ARG(it != p->tensors.end(), SAT_E_MISSING, "dit plan: tensor '%s' was never set", name.c_str());
+    SAT_CHECK_ARG(numel < 0 || it->second.second == numel, SAT_E_INVALID, "dit plan: tensor '%s' has %lld elements, expected %lld",
+                  name.c_str(), (long long)it->second.second, (long long)numel);
+    *out = it->second.first;
+    return 0;
+}
+
+int copy_f32(sat_dit_plan* p, Arena& ar, const std::string& name, int64_t numel, float** dst, hipStream_t s) {
+    *dst = (float*)ar.take(numel * 4);
+    if (ar.dry) return 0;
+    const float* src;
+    SAT_TRY(get_tensor(p, name, numel, &src));
+    SAT_HIP(hipMemcpyAsync(*dst, src, numel * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int pack_w(sat_dit_plan* p, Arena& ar, const std::string& name, int n, int k, int interleave, bf16_t** dst, hipStream_t s) {
+    *dst = (bf16_t*)ar.take((size_t)n * k * 2);
+    if (ar.dry) return 0;
+    const float* src;
+    SAT_TRY(get_tensor(p, name, (int64_t)n * k, &src));
+    return sat_launch_pack_rows_bf16(src, *dst, n, k, interleave, s);
+}
+
+int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
+    const sat_dit_cfg& c = p->cfg;
+    const int D = c.embed_dim, C = c.io_channels, Dc = c.cond_embed_dim, Dct = c.cond_token_dim, Dg = c.global_cond_dim;
+    const int inner = p->inner;
+    SAT_TRY(copy_f32(p, ar, "timestep_features.weight", 128, &p->ts_w, s));
+    SAT_TRY(copy_f32(p, ar, "to_timestep_embed.0.weight", (int64_t)D * 256, &p->te0_w, s));
+    SAT_TRY(copy_f32(p, ar, "to_timestep_embed.0.bias", D, &p->te0_b, s));
+    SAT_TRY(copy_f32(p, ar, "to_timestep_embed.2.weight", (int64_t)D * D, &p->te2_w, s));
+    SAT_TRY(copy_f32(p, ar, "to_timestep_embed.2.bias", D, &p->te2_b, s));
+    if (Dct > 0) {
+        SAT_TRY(copy_f32(p, ar, "to_cond_embed.0.weight", (int64_t)Dc * Dct, &p->ce0_w, s));
+        SAT_TRY(copy_f32(p, ar, "to_cond_embed.2.weight", (int64_t)Dc * Dc, &p->ce2_w, s));
+    }
+    if (Dg > 0) {
+        SAT_TRY(copy_f32(p, ar, "to_global_embed.0.weight", (int64_t)D * Dg, &p->ge0_w, s));
+        SAT_TRY(copy_f32(p, ar, "to_global_embed.2.weight", (int64_t)D * D, &p->ge2_w, s));
+    }
+    SAT_TRY(copy_f32(p, ar, "transformer.rotary_pos_emb.inv_freq", 16, &p->inv_freq, s));
+    p->win_eff = (float*)ar.take((size_t)D * C * 4);
+    p->wout_eff = (float*)ar.take((size_t)D * C * 4);
+    const int smax = c.max_seq_len + 1;
+    p->rope_cos = (float*)ar.take((size_t)smax * 16 * 4);
+    p->rope_sin = (float*)ar.take((size_t)smax * 16 * 4);
+    if (!ar.dry) {
+        const float *win, *wpre, *wout, *wpost;
+        SAT_TRY(get_tensor(p, "transformer.project_in.weight", (int64_t)D * C, &win));
+        SAT_TRY(get_tensor(p, "preprocess_conv.weight", (int64_t)C * C, &wpre));
+        SAT_TRY(get_tensor(p, "transformer.project_out.weight", (int64_t)D * C, &wout));
+        SAT_TRY(get_tensor(p, "postprocess_conv.weight", (int64_t)C * C, &wpost));
+        SAT_TRY(glue_fold_in(win, wpre, p->win_eff, D, C, s));
+        SAT_TRY(glue_fold_out(wout, wpost, p->wout_eff, D, C, s));
+        SAT_TRY(sat_launch_rope_table(p->inv_freq, p->rope_cos, p->rope_sin, smax, s));
+    }
+    p->layers.resize(c.depth);
+    for (int l = 0; l < c.depth; ++l) {
+        LayerW& L = p->layers[l];
+        const std::string pf = "transformer.layers." + std::to_string(l) + ".";
+        SAT_TRY(copy_f32(p, ar, pf + "pre_norm.gamma", D, &L.pre_g, s));
+        SAT_TRY(copy_f32(p, ar, pf + "pre_norm.beta", D, &L.pre_b, s));
+        SAT_TRY(copy_f32(p, ar, pf + "ff_norm.gamma", D, &L.ff_g, s));
+        SAT_TRY(copy_f32(p, ar, pf + "ff_norm.beta", D, &L.ff_b, s));
+        SAT_TRY(pack_w(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, s));
+        SAT_TRY(pack_w(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, s));
+        if (Dct > 0) {
+            SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.gamma", D, &L.cross_g, s));
+            SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.beta", D, &L.cross_b, s));
+            SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, s));
+            SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_kv.weight", 2 * Dc, Dc, 0, &L.w_ckv, s));
+            SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, s));
+        }
+        SAT_TRY(pack_w(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, s));
+        L.b_ff1 = (float*)ar.take((size_t)2 * inner * 4);
+        if (!ar.dry) {
+            const float* b1;
+            SAT_TRY(get_tensor(p, pf + "ff.ff.0.proj.bias", 2 * inner, &b1));
+            SAT_TRY(sat_launch_pack_bias(b1, L.b_ff1, 2 * inner, 1, s));
+        }
+        SAT_TRY(pack_w(p, ar, pf + "ff.ff.2.weight", D, inner, 0, &L.w_ff2, s));
+        SAT_TRY(copy_f32(p, ar, pf + "ff.ff.2.bias", D, &L.b_ff2, s));
+    }
+    return 0;
+}
+
+struct Workspace {
+    float* X;
+    bf16_t *A, *AO, *Q, *K, *Vt, *Hh;
+    float *ff, *h1, *mo;
+    size_t qkv_bytes;
+    size_t total;
+};
+
+Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
+    const sat_dit_cfg& c = p->cfg;
+    const int D = c.embed_dim, H = c.num_heads;
+    const int S = T + 1;
+    const size_t M = (size_t)bf * S;
+    const int Spad = (int)round_up(S, 128);
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* ptr = base ? base + off : nullptr;
+        off += (size_t)round_up((int64_t)bytes, 256);
+        return ptr;
+    };
+    w.X = (float*)take(M * D * 4);
+    w.A = (bf16_t*)take(M * D * 2);
+    w.AO = (bf16_t*)take(M * D * 2);
+    w.qkv_bytes = (size_t)bf * H * Spad * 64 * 2;
+    // Q, K, Vt contiguous so that one memset clears all pads
+    w.Q = (bf16_t*)take(w.qkv_bytes);
+    w.K = (bf16_t*)take(w.qkv_bytes);
+    w.Vt = (bf16_t*)take(w.qkv_bytes);
+    w.Hh = (bf16_t*)take(M * (size_t)p->inner * 2);
+    w.ff = (float*)take((size_t)bf * 256 * 4);
+    w.h1 = (float*)take((size_t)bf * D * 4);
+    w.mo = (float*)take((size_t)bf * c.io_channels * T * 4);
+    w.total = off;
+    return w;
+}
+
+int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const float* t_dev, float t_const, float* out, int bf,
+                int T, void* ws, size_t ws_bytes, hipStream_t s) {
+    SAT_CHECK_ARG(p && p->finalized, SAT_E_STATE, "dit forward: plan not finalized");
+    const sat_dit_cfg& c = p->cfg;
+    SAT_CHECK_ARG(x && out && ws && bf > 0 && T > 0, SAT_E_INVALID, "dit forward: bad arguments");
+    SAT_CHECK_ARG(T <= c.max_seq_len, SAT_E_INVALID, "dit forward: t_len %d exceeds plan max_seq_len %d", T, c.max_seq_len);
+    SAT_CHECK_ARG(((uintptr_t)ws & 255) == 0, SAT_E_INVALID, "dit forward: workspace must be 256-byte aligned");
+    const bool cross = c.cond_token_dim > 0;
+    SAT_CHECK_ARG(p->ctx_bf == bf, SAT_E_STATE, "dit forward: context prepared for %d sequences, forward called with %d",
+                  p->ctx_bf, bf);
+    Workspace w = carve(p, bf, T, (char*)ws);
+    SAT_CHECK_ARG(ws_bytes >= w.total, SAT_E_WORKSPACE, "dit forward: workspace %zu < required %zu", ws_bytes, w.total);
+    const int D = c.embed_dim, H = c.num_heads, C = c.io_channels;
+    const int S = T + 1, M = bf * S, Spad = (int)round_up(S, 128);
+
+    // pads of q/k/vt must be finite (zero): one memset per forward
+    SAT_HIP(hipMemsetAsync(w.Q, 0, 3 * (size_t)round_up((int64_t)w.qkv_bytes, 256), s));
+
+    // timestep embedding (dit.py:176) + global embed (dit.py:179-182) -> prepend token rows X[b,0,:]
+    SAT_TRY(glue_fourier(t_dev, t_const, p->ts_w, w.ff, bf, 128, s));
+    SAT_TRY(glue_small_linear(w.ff, 256, p->te0_w, p->te0_b, nullptr, 0, w.h1, D, bf, D, 256, 1, false, s));
+    SAT_TRY(glue_small_linear(w.h1, D, p->te2_w, p->te2_b, p->has_global ? p->ge : nullptr, D, w.X, S * D, bf, D, D, 0, false, s));
+    // preprocess_conv + residual + project_in (dit.py:197-199, transformer.py:778)
+    SAT_TRY(glue_input_proj(x, p->win_eff, w.X, bf, xB, C, T, S, D, xscale, s));
+
+    GemmArgs g{};
+    for (int l = 0; l < c.depth; ++l) {
+        const LayerW& L = p->layers[l];
+        // ---- self-attention branch (transformer.py:692)
+        SAT_TRY(sat_launch_layernorm(w.X, L.pre_g, L.pre_b, w.A, M, D, s));
+        g = GemmArgs{};
+        g.A = w.A; g.W = L.w_qkv; g.M = M; g.N = 3 * D; g.K = D;
+        g.heads.out[0] = w.Q; g.heads.out[1] = w.K; g.heads.out[2] = w.Vt;
+        g.heads.kind[0] = 2; g.heads.kind[1] = 2; g.heads.kind[2] = 1;
+        g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
+        g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
+        SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
+        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s));
+        g = GemmArgs{};
+        g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
+        SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
+        // ---- cross-attention branch (transformer.py:694-695)
+        if (cross) {
+            SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, M, D, s));
+            g = GemmArgs{};
+            g.A = w.A; g.W = L.w_cq; g.M = M; g.N = D; g.K = D;
+            g.heads.out[0] = w.Q; g.heads.kind[0] = 0; g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
+            SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
+            const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lcpad * 64;
+            SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bf, H, p->kvh_cross, S,
+                                         p->ctx_lc, Spad, p->ctx_lcpad, s));
+            g = GemmArgs{};
+            g.A = w.AO; g.W = L.w_co; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
+            SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
+        }
+        // ---- feed-forward branch (transformer.py:700)
+        SAT_TRY(sat_launch_layernorm(w.X, L.ff_g, L.ff_b, w.A, M, D, s));
+        g = GemmArgs{};
+        g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
+        SAT_TRY(sat_launch_gemm(EPI_SWIGLU, g, s));
+        g = GemmArgs{};
+        g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
+        SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
+    }
+    // project_out + drop prepend + postprocess_conv + residual (transformer.py:807, dit.py:219-224)
+    SAT_TRY(glue_output_proj(w.X, p->wout_eff, out, bf, C, T, S, D, s));
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C ABI
+extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan) {
+    SAT_CHECK_ARG(cfg && out_plan, SAT_E_INVALID, "dit_plan_create: null argument");
+    SAT_CHECK_ARG(cfg->embed_dim > 0 && cfg->num_heads > 0 && cfg->embed_dim == cfg->num_heads * 64, SAT_E_UNSUPPORTED,
+                  "dit_plan_create: dim_heads must be 64 (embed_dim %d, heads %d)", cfg->embed_dim, cfg->num_heads);
+    SAT_CHECK_ARG(cfg->embed_dim % 128 == 0 && cfg->embed_dim <= 2048, SAT_E_UNSUPPORTED,
+                  "dit_plan_create: embed_dim %d must be a multiple of 128 and <= 2048", cfg->embed_dim);
+    SAT_CHECK_ARG(cfg->io_channels > 0 && cfg->io_channels <= 64, SAT_E_UNSUPPORTED, "dit_plan_create: io_channels %d not in 1..64",
+                  cfg->io_channels);
+    SAT_CHECK_ARG(cfg->depth > 0 && cfg->max_seq_len > 0, SAT_E_INVALID, "dit_plan_create: depth/max_seq_len must be positive");
+    if (cfg->cond_token_dim > 0) {
+        SAT_CHECK_ARG(cfg->cond_embed_dim % 64 == 0 && cfg->cond_embed_dim > 0 && cfg->cond_token_dim % 4 == 0, SAT_E_UNSUPPORTED,
+                      "dit_plan_create: cond_embed_dim %d must be a multiple of 64", cfg->cond_embed_dim);
+        int kvh = cfg->cond_embed_dim / 64;
+        SAT_CHECK_ARG(cfg->num_heads % kvh == 0, SAT_E_UNSUPPORTED, "dit_plan_create: %d query heads not divisible by %d kv heads",
+                      cfg->num_heads, kvh);
+    }
+    SAT_CHECK_ARG(cfg->global_cond_dim % 4 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: global_cond_dim must be a multiple of 4");
+    sat_dit_plan* p = new (std::nothrow) sat_dit_plan();
+    SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_plan_create: out of host memory");
+    p->cfg = *cfg;
+    p->kvh_cross = cfg->cond_token_dim > 0 ? cfg->cond_embed_dim / 64 : 0;
+    *out_plan = p;
+    return 0;
+}
+
+extern "C" void sat_dit_plan_destroy(sat_dit_plan* p) {
+    if (!p) return;
+    if (p->arena) (void)hipFree(p->arena);
+    if (p->ctx_buf) (void)hipFree(p->ctx_buf);
+    delete p;
+}
+
+extern "C" int sat_dit_plan_set_tensor(sat_dit_plan* p, const char* name, const float* data_dev, int64_t numel) {
+    SAT_CHECK_ARG(p && name && data_dev && numel > 0, SAT_E_INVALID, "dit_plan_set_tensor: bad argument");
+    p->tensors[name] = {data_dev, numel};
+    return 0;
+}
+
+extern "C" int sat_dit_plan_finalize(sat_dit_plan* p, sat_stream_t stream) {
+    SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_plan_finalize: null plan");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = p->cfg.embed_dim;
+    auto it = p->tensors.find("transformer.layers.0.ff.ff.0.proj.weight");
+    SAT_CHECK_ARG(it != p->tensors.end(), SAT_E_MISSING, "dit plan: tensor 'transformer.layers.0.ff.ff.0.proj.weight' was never set");
+    SAT_CHECK_ARG(it->second.second % (2 * (int64_t)D) == 0, SAT_E_INVALID, "dit plan: FF weight size not divisible by 2*embed_dim");
+    p->inner = (int)(it->second.second / (2 * (int64_t)D));
+    SAT_CHECK_ARG(p->inner % 64 == 0, SAT_E_UNSUPPORTED, "dit plan: FF inner dim %d must be a multiple of 64", p->inner);
+    if (p->arena) {
+        (void)hipFree(p->arena);
+        p->arena = nullptr;
+    }
+    p->finalized = false;
+    Arena dry;
+    SAT_TRY(build(p, dry, s));
+    SAT_HIP(hipMalloc((void**)&p->arena, dry.off));
+    Arena real;
+    real.base = p->arena;
+    real.dry = false;
+    SAT_TRY(build(p, real, s));
+    SAT_HIP(hipStreamSynchronize(s));   // the caller may free its fp32 tensors once this returns
+    p->tensors.clear();
+    p->finalized = true;
+    return 0;
+}
+
+extern "C" int sat_dit_workspace_bytes(const sat_dit_plan* p, int32_t bf, int32_t t_len, size_t* out_bytes) {
+    SAT_CHECK_ARG(p && out_bytes && bf > 0 && t_len > 0, SAT_E_INVALID, "dit_workspace_bytes: bad argument");
+    SAT_CHECK_ARG(p->finalized, SAT_E_STATE, "dit_workspace_bytes: plan not finalized");
+    *out_bytes = carve(p, bf, t_len, nullptr).total;
+    return 0;
+}
+
+extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32_t bf, int32_t lc, const float* global_cond,
+                                       sat_stream_t stream) {
+    SAT_CHECK_ARG(p && p->finalized, SAT_E_STATE, "dit_prepare_context: plan not finalized");
+    hipStream_t s = (hipStream_t)stream;
+    const sat_dit_cfg& c = p->cfg;
+    const int D = c.embed_dim, Dc = c.cond_embed_dim, Dct = c.cond_token_dim, Dg = c.global_cond_dim;
+    const bool cross = Dct > 0;
+    SAT_CHECK_ARG(bf > 0, SAT_E_INVALID, "dit_prepare_context: bf must be positive");
+    SAT_CHECK_ARG(!cross || (cond && lc > 0), SAT_E_INVALID, "dit_prepare_context: model has cross-attention but no cond given");
+    SAT_CHECK_ARG(!(global_cond && Dg == 0), SAT_E_INVALID, "dit_prepare_context: model has no global conditioning");
+    const int lcpad = cross ? (int)round_up(lc, 64) : 0;
+    const int R = bf * lc;
+    // layout of the context buffer
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (size_t)round_up((int64_t)bytes, 256);
+        return o;
+    };
+    const size_t o_ge = take((size_t)bf * D * 4);
+    const size_t o_gh = take((size_t)bf * D * 4);
+    const size_t o_ch = cross ? take((size_t)R * Dc * 4) : 0;
+    const size_t o_ce = cross ? take((size_t)R * Dc * 2) : 0;
+    const size_t kv_elems = cross ? (size_t)c.depth * bf * p->kvh_cross * lcpad * 64 : 0;
+    const size_t o_kc = take(kv_elems * 2);
+    const size_t o_vc = take(kv_elems * 2);
+    if (off > p->ctx_cap) {
+        SAT_HIP(hipStreamSynchronize(s));
+        if (p->ctx_buf) SAT_HIP(hipFree(p->ctx_buf));
+        p->ctx_buf = nullptr;
+        p->ctx_cap = 0;
+        SAT_HIP(hipMalloc((void**)&p->ctx_buf, off));
+        p->ctx_cap = off;
+    }
+    p->ge = (float*)(p->ctx_buf + o_ge);
+    float* gh = (float*)(p->ctx_buf + o_gh);
+    p->kc = (bf16_t*)(p->ctx_buf + o_kc);
+    p->vct = (bf16_t*)(p->ctx_buf + o_vc);
+    p->has_global = global_cond != nullptr;
+    if (global_cond) {   // dit.py:154
+        SAT_TRY(glue_small_linear(global_cond, Dg, p->ge0_w, nullptr, nullptr, 0, gh, D, bf, D, Dg, 1, false, s));
+        SAT_TRY(glue_small_linear(gh, D, p->ge2_w, nullptr, nullptr, 0, p->ge, D, bf, D, D, 0, false, s));
+    }
+    if (cross) {   // dit.py:150 then per-layer to_kv (transformer.py:420-427)
+        float* ch = (float*)(p->ctx_buf + o_ch);
+        bf16_t* ce = (bf16_t*)(p->ctx_buf + o_ce);
+        SAT_TRY(glue_small_linear(cond, Dct, p->ce0_w, nullptr, nullptr, 0, ch, Dc, R, Dc, Dct, 1, false, s));
+        SAT_TRY(glue_small_linear(ch, Dc, p->ce2_w, nullptr, nullptr, 0, ce, Dc, R, Dc, Dc, 0, true, s));
+        SAT_HIP(hipMemsetAsync(p->kc, 0, kv_elems * 2, s));
+        SAT_HIP(hipMemsetAsync(p->vct, 0, kv_elems * 2, s));
+        const size_t per_layer = (size_t)bf * p->kvh_cross * lcpad * 64;
+        for (int l = 0; l < c.depth; ++l) {
+            GemmArgs g{};
+            g.A = ce; g.W = p->layers[l].w_ckv; g.M = R; g.N = 2 * Dc; g.K = Dc;
+            g.heads.out[0] = p->kc + l * per_layer; g.heads.out[1] = p->vct + l * per_layer;
+            g.heads.kind[0] = 0; g.heads.kind[1] = 1; g.heads.parts = 2; g.heads.heads = p->kvh_cross;
+            g.heads.S = lc; g.heads.Spad = lcpad;
+            g.variant = 1;
+            SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
+        }
+    }
+    p->ctx_bf = bf;
+    p->ctx_lc = cross ? lc : 0;
+    p->ctx_lcpad = lcpad;
+    return 0;
+}
+
+extern "C" int sat_dit_forward(sat_dit_plan* p, const float* x_dev, const float* t_dev, float* out_dev, int32_t bf, int32_t t_len,
+                               void* ws, size_t ws_bytes, sat_stream_t stream) {
+    SAT_CHECK_ARG(t_dev, SAT_E_INVALID, "dit_forward: t_dev is null");
+    return run_forward(p, x_dev, bf, 1.0f, t_dev, 0.f, out_dev, bf, t_len, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int sat_dit_denoise_cfg(sat_dit_plan* p, const float* x_dev, float sigma, float cfg_scale, float scale_phi,
+                                   float* denoised_dev, int32_t b, int32_t t_len, void* ws, size_t ws_bytes, sat_stream_t stream) {
+    SAT_CHECK_ARG(p && p->finalized, SAT_E_STATE, "dit_denoise_cfg: plan not finalized");
+    SAT_CHECK_ARG(x_dev && denoised_dev && b > 0 && t_len > 0 && ws, SAT_E_INVALID, "dit_denoise_cfg: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    // models/dit.py:270: CFG only when cfg_scale != 1 and there is cross-attention conditioning
+    const int use_cfg = (cfg_scale != 1.0f && p->cfg.cond_token_dim > 0) ? 1 : 0;
+    const int bf = use_cfg ? 2 * b : b;
+    // k_diffusion.external.VDenoiser, sigma_data = 1
+    const double sg = (double)sigma;
+    const float c_skip = (float)(1.0 / (sg * sg + 1.0));
+    const float c_out = (float)(-sg / sqrt(sg * sg + 1.0));
+    const float c_in = (float)(1.0 / sqrt(sg * sg + 1.0));
+    const float t = (float)(atan(sg) / M_PI * 2.0);
+    size_t need = 0;
+    SAT_TRY(sat_dit_workspace_bytes(p, bf, t_len, &need));
+    SAT_CHECK_ARG(ws_bytes >= need, SAT_E_WORKSPACE, "dit_denoise_cfg: workspace %zu < required %zu", ws_bytes, need);
+    Workspace w = carve(p, bf, t_len, (char*)ws);
+    SAT_TRY(run_forward(p, x_dev, b, c_in, nullptr, t, w.mo, bf, t_len, ws, ws_bytes, s));
+    return glue_cfg_denoise(w.mo, x_dev, denoised_dev, b, p->cfg.io_channels, t_len, use_cfg, cfg_scale, scale_phi, c_out, c_skip, s);
+}
+
+extern "C" int sat_cfg_combine(const float* model_out_dev, float* out_dev, int32_t b, int32_t c, int32_t t, float cfg_scale,
+                               float scale_phi, sat_stream_t stream) {
+    SAT_CHECK_ARG(model_out_dev && out_dev && b > 0 && c > 1 && t > 0, SAT_E_INVALID, "cfg_combine: bad arguments");
+    // denoise form with c_out = 1, c_skip = 0 (x is not read when c_skip == 0, but must be a valid pointer)
+    return glue_cfg_denoise(model_out_dev, model_out_dev, out_dev, b, c, t, 1, cfg_scale, scale_phi, 1.0f, 0.0f, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------ unit-level entry points
+extern "C" int sat_layernorm_bf16(const float* x, const float* gamma, const float* beta, void* y, int32_t m, int32_t d,
+                                  sat_stream_t stream) {
+    return sat_launch_layernorm(x, gamma, beta, (bf16_t*)y, m, d, (hipStream_t)stream);
+}
+
+extern "C" int sat_cast_bf16(const float* x, void* y, int64_t n, sat_stream_t stream) {
+    return sat_launch_cast_bf16(x, (bf16_t*)y, n, (hipStream_t)stream);
+}
+
+extern "C" int sat_gemm_bf16_f32(const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
+                                 int32_t accumulate, int32_t variant, sat_stream_t stream) {
+    SAT_CHECK_ARG(c, SAT_E_INVALID, "gemm: null output");
+    GemmArgs g{};
+    g.A = (const bf16_t*)a; g.W = (const bf16_t*)w; g.bias = bias; g.M = m; g.N = n; g.K = k;
+    g.C = c; g.ldc = n; g.accumulate = accumulate; g.variant = variant;
+    return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);
+}
+
+extern "C" int sat_gemm_swiglu_bf16(const void* a, const float* w_f32, const float* bias_f32, void* wpack, float* bpack,
+                                    void* h, int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
+    SAT_CHECK_ARG(w_f32 && wpack && bpack && h, SAT_E_INVALID, "gemm_swiglu: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    SAT_TRY(sat_launch_pack_rows_bf16(w_f32, (bf16_t*)wpack, n, k, 1, s));
+    if (bias_f32) SAT_TRY(sat_launch_pack_bias(bias_f32, bpack, n, 1, s));
+    GemmArgs g{};
+    g.A = (const bf16_t*)a; g.W = (const bf16_t*)wpack; g.bias = bias_f32 ? bpack : nullptr; g.M = m; g.N = n; g.K = k;
+    g.H = (bf16_t*)h; g.variant = variant;
+    return sat_launch_gemm(EPI_SWIGLU, g, s);
+}
+
+extern "C" int sat_attention_bf16(const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
+                                  int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
+    return sat_launch_attention((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, b, h, kvh, sq, sk, sq_pad,
+                                sk_pad, (hipStream_t)stream);
+}
+
+extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_freq, void* q, void* k, void* vt,
+                                 float* rope_scratch, int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant,
+                                 sat_stream_t stream) {
+    SAT_CHECK_ARG(a && w && inv_freq && q && k && vt && rope_scratch, SAT_E_INVALID, "qkv_rope: null pointer");
+    SAT_CHECK_ARG(d % 64 == 0 && s_pad >= s_len && s_pad % 128 == 0, SAT_E_INVALID, "qkv_rope: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = d / 64;
+    const size_t bytes = (size_t)b * H * s_pad * 64 * 2;
+    SAT_HIP(hipMemsetAsync(q, 0, bytes, s));
+    SAT_HIP(hipMemsetAsync(k, 0, bytes, s));
+    SAT_HIP(hipMemsetAsync(vt, 0, bytes, s));
+    float* cs = rope_scratch;
+    float* sn = rope_scratch + (size_t)s_len * 16;
+    SAT_TRY(sat_launch_rope_table(inv_freq, cs, sn, s_len, s));
+    GemmArgs g{};
+    g.A = (const bf16_t*)a; g.W = (const bf16_t*)w; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant;
+    g.heads.out[0] = (bf16_t*)q; g.heads.out[1] = (bf16_t*)k; g.heads.out[2] = (bf16_t*)vt;
+    g.heads.kind[0] = 2; g.heads.kind[1] = 2; g.heads.kind[2] = 1;
+    g.heads.parts = 3; g.heads.heads = H; g.heads.S = s_len; g.heads.Spad = s_pad;
+    g.heads.rope_cos = cs; g.heads.rope_sin = sn;
+    return sat_launch_gemm(EPI_HEADS, g, s);
+}

@@ -1,0 +1,264 @@
+// bf16 MFMA GEMM for the DiT projections and the SwiGLU FFN (SURVEY.md K2,K5,K6,K7,K8):
+//     C[M,N] = A[M,K] . W[N,K]^T      A, W bf16 (K contiguous), fp32 accumulate
+// replacing the nn.Linear calls at models/transformer.py:222,270,314,311-312,319 of the
+// reference.  gfx950 only: v_mfma_f32_32x32x16_bf16, 64-wide wavefronts, LDS-staged tiles
+// (XOR-swizzled, conflict-free ds_read_b128), register-staged double buffering with one
+// barrier per K-tile, XCD-aware tile rasterisation.
+//
+// Fused epilogues
+//   EPI_F32    C (fp32) = acc (+bias) (+C)           -> to_out / FF-out + residual add
+//   EPI_SWIGLU H (bf16) = (acc_v+b_v) * silu(acc_g+b_g)   (W rows interleaved 32 value /
+//              32 gate so both land in one wave tile; models/transformer.py:232-235)
+//   EPI_HEADS  split into heads, partial RoPE (models/transformer.py:158-183,438-452) on
+//              q/k, store q/k as [B,H,Spad,64] and v transposed as [B,H,64,Spad]
+#include "sat_common.h"
+
+namespace {
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM;
+    constexpr int TN = BN / WN;
+    static_assert(TN == 64, "wave tile is TM x 64");
+    constexpr int MI = TM / 32;
+    constexpr int NI = 2;
+    constexpr int A_CH = BM * 8 / NT;
+    constexpr int B_CH = BN * 8 / NT;
+    static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for the block");
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_n = N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    if (tiles_m <= tiles_n) {   // M is the short dimension: m fastest, W panels stay in one XCD's L2
+        tn = bid / tiles_m;
+        tm = bid - tn * tiles_m;
+    } else {
+        tm = bid / tiles_n;
+        tn = bid - tm * tiles_n;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    const bf16_t* __restrict__ A = g.A;
+    const bf16_t* __restrict__ W = g.W;
+
+    // per-thread staging coordinates
+    int a_row[A_CH], a_chk[A_CH];
+    const bf16_t* a_ptr[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        int id = i * NT + tid;
+        a_row[i] = id >> 3;
+        a_chk[i] = id & 7;
+        int gm = m0 + a_row[i];
+        gm = gm < M ? gm : M - 1;
+        a_ptr[i] = A + (size_t)gm * K + a_chk[i] * 8;
+    }
+    int b_row[B_CH], b_chk[B_CH];
+    const bf16_t* b_ptr[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        int id = i * NT + tid;
+        b_row[i] = id >> 3;
+        b_chk[i] = id & 7;
+        b_ptr[i] = W + (size_t)(n0 + b_row[i]) * K + b_chk[i] * 8;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[A_CH], rb[B_CH];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + kt * 64);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + kt * 64);
+    };
+    auto lstore = [&](int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(sa + lds_tile_off(a_row[i], a_chk[i])) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(sb + lds_tile_off(b_row[i], b_chk[i])) = rb[i];
+    };
+
+    const int nk = K / 64;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* sa = smem + cur * STAGE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31   (guide section 3)
+    const int mw = m0 + wm * TM;
+    const int nw = n0 + wn * TN;
+
+    if constexpr (EPI == EPI_F32) {
+        float* __restrict__ C = g.C;
+        const int ldc = g.ldc;
+        float bia[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bia[j] = g.bias ? g.bias[nw + j * 32 + l31] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        size_t o = (size_t)m * ldc + nw + j * 32 + l31;
+                        float v = acc[i][j][r] + bia[j];
+                        if (g.accumulate) v += C[o];
+                        C[o] = v;
+                    }
+                }
+            }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        bf16_t* __restrict__ H = g.H;
+        const int ldh = N >> 1;
+        const float bv = g.bias ? g.bias[nw + l31] : 0.f;
+        const float bg = g.bias ? g.bias[nw + 32 + l31] : 0.f;
+        const int hc = (nw >> 1) + l31;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M) {
+                    float v = acc[i][0][r] + bv;
+                    float gt = acc[i][1][r] + bg;
+                    H[(size_t)m * ldh + hc] = f32_to_bf16(v * silu_f(gt));
+                }
+            }
+    } else {   // EPI_HEADS
+        const HeadsEpi& he = g.heads;
+        const int hp = he.heads * 64;
+        const int part = nw / hp;
+        const int head = (nw - part * hp) >> 6;
+        const int kind = he.kind[part];
+        bf16_t* __restrict__ dst = he.out[part];
+        const int S = he.S, Spad = he.Spad;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool valid = m < M;
+                int mm = valid ? m : M - 1;
+                int b = mm / S;
+                int s = mm - b * S;
+                float v0 = acc[i][0][r], v1 = acc[i][1][r];
+                if (kind & 2) {   // wave-uniform
+                    float p = __shfl_xor(v0, 16, 64);
+                    int jf = l31 & 15;
+                    float cs = he.rope_cos[s * 16 + jf], sn = he.rope_sin[s * 16 + jf];
+                    v0 = (l31 < 16) ? (v0 * cs - p * sn) : (v0 * cs + p * sn);
+                }
+                if (valid) {
+                    if (kind & 1) {
+                        size_t base = ((size_t)(b * he.heads + head) * 64) * Spad + s;
+                        dst[base + (size_t)l31 * Spad] = f32_to_bf16(v0);
+                        dst[base + (size_t)(32 + l31) * Spad] = f32_to_bf16(v1);
+                    } else {
+                        size_t base = ((size_t)(b * he.heads + head) * Spad + s) * 64;
+                        dst[base + l31] = f32_to_bf16(v0);
+                        dst[base + 32 + l31] = f32_to_bf16(v1);
+                    }
+                }
+            }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
+int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    auto kern = gemm_kernel<BM, BN, WM, WN, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
+    int tiles = cdiv(a.M, BM) * (a.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, a);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI>
+int launch_epi(const GemmArgs& a, hipStream_t stream) {
+    int v = a.variant;
+    if (v == 0) {   // default heuristic: big tiles only when they still fill the chip
+        long t256 = (long)cdiv(a.M, 256) * (a.N / 256 > 0 ? a.N / 256 : 1);
+        v = (a.N % 256 == 0 && t256 >= 512) ? 3 : 1;
+    }
+    switch (v) {
+        case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
+        case 2: return launch_cfg<256, 128, 4, 2, EPI>(a, stream);
+        case 3: return launch_cfg<256, 256, 2, 4, EPI>(a, stream);
+        case 4: return launch_cfg<128, 256, 1, 4, EPI>(a, stream);
+        default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
+    }
+}
+
+}  // namespace
+
+int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
+    SAT_CHECK_ARG(a.A && a.W, SAT_E_INVALID, "gemm: null operand");
+    SAT_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, SAT_E_INVALID, "gemm: bad shape %d %d %d", a.M, a.N, a.K);
+    SAT_CHECK_ARG(a.K % 64 == 0, SAT_E_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", a.K);
+    SAT_CHECK_ARG(a.N % 128 == 0, SAT_E_UNSUPPORTED, "gemm: N=%d must be a multiple of 128", a.N);
+    switch (epi) {
+        case EPI_F32:
+        case EPI_RESID: return launch_epi<EPI_F32>(a, stream);
+        case EPI_SWIGLU: return launch_epi<EPI_SWIGLU>(a, stream);
+        case EPI_HEADS: return launch_epi<EPI_HEADS>(a, stream);
+    }
+    sat_set_error("gemm: unknown epilogue %d", epi);
+    return SAT_E_INVALID;
+}

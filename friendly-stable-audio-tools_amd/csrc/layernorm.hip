@@ -1,0 +1,182 @@
+// LayerNorm (bias-less gamma + persisted beta buffer, eps 1e-5) -> bf16, one wave per row.
+// Replaces F.layer_norm at models/transformer.py:205-206 (pre_norm / cross_attend_norm /
+// ff_norm, :671/678/685 resp. :692/695/700).  HBM-bound: reads the fp32 residual stream
+// once (float4 per lane), two-pass statistics in registers, writes the bf16 GEMM operand.
+#include "sat_common.h"
+
+namespace {
+
+// D = 64 * 4 * NV  (NV float4 per lane)
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        int m, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * d);
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[i * 64 + lane];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + e * e);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    const float4* gr = reinterpret_cast<const float4*>(gamma);
+    const float4* br = reinterpret_cast<const float4*>(beta);
+    bf16x4* yr = reinterpret_cast<bf16x4*>(y + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float4 g = gr[i * 64 + lane];
+        float4 b = beta ? br[i * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bf16x4 o;
+        o[0] = f32_to_bf16((v[i].x - mean) * rstd * g.x + b.x);
+        o[1] = f32_to_bf16((v[i].y - mean) * rstd * g.y + b.y);
+        o[2] = f32_to_bf16((v[i].z - mean) * rstd * g.z + b.z);
+        o[3] = f32_to_bf16((v[i].w - mean) * rstd * g.w + b.w);
+        yr[i * 64 + lane] = o;
+    }
+}
+
+// generic fallback: any d % 4 == 0 (strided loop, row re-read from L2)
+__global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                int m, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const float* xr = x + (size_t)row * d;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        float a = xr[i] - mean;
+        q += a * a;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    for (int i = lane; i < d; i += 64)
+        y[(size_t)row * d + i] = f32_to_bf16((xr[i] - mean) * rstd * gamma[i] + (beta ? beta[i] : 0.f));
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) {
+        float4 v = *reinterpret_cast<const float4*>(x + i);
+        bf16x4 o;
+        o[0] = f32_to_bf16(v.x);
+        o[1] = f32_to_bf16(v.y);
+        o[2] = f32_to_bf16(v.z);
+        o[3] = f32_to_bf16(v.w);
+        *reinterpret_cast<bf16x4*>(y + i) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t j = n & ~(int64_t)3; j < n; ++j) y[j] = f32_to_bf16(x[j]);
+}
+
+// out[n'][k] = bf16(w[src(n')][k]); swiglu_interleave: groups of 64 output rows = 32 value
+// rows g*32.. followed by the 32 matching gate rows n/2 + g*32..  (see gemm_bf16.hip)
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int n, int k,
+                                                        int interleave) {
+    const int row = blockIdx.x;
+    int src = row;
+    if (interleave) {
+        int g = row >> 6, c = row & 63;
+        src = (c < 32) ? (g * 32 + c) : (n / 2 + g * 32 + (c - 32));
+    }
+    const float* wr = w + (size_t)src * k;
+    bf16_t* o = out + (size_t)row * k;
+    for (int i = threadIdx.x * 4; i < k; i += 256 * 4) {
+        float4 v = *reinterpret_cast<const float4*>(wr + i);
+        bf16x4 p;
+        p[0] = f32_to_bf16(v.x);
+        p[1] = f32_to_bf16(v.y);
+        p[2] = f32_to_bf16(v.z);
+        p[3] = f32_to_bf16(v.w);
+        *reinterpret_cast<bf16x4*>(o + i) = p;
+    }
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int n, int interleave) {
+    int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    int src = row;
+    if (interleave) {
+        int g = row >> 6, c = row & 63;
+        src = (c < 32) ? (g * 32 + c) : (n / 2 + g * 32 + (c - 32));
+    }
+    out[row] = b[src];
+}
+
+// models/transformer.py:130-148: freqs[s][j] = s * inv_freq[j] (fp32), cos/sin in fp32
+__global__ void rope_table_kernel(const float* __restrict__ inv_freq, float* __restrict__ cos_t, float* __restrict__ sin_t,
+                                  int s_len) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s_len * 16) return;
+    int s = i >> 4, j = i & 15;
+    float f = (float)s * inv_freq[j];
+    cos_t[i] = cosf(f);
+    sin_t[i] = sinf(f);
+}
+
+}  // namespace
+
+int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s) {
+    SAT_CHECK_ARG(x && gamma && y && m > 0 && d > 0 && d % 4 == 0, SAT_E_INVALID, "layernorm: bad args m=%d d=%d", m, d);
+    dim3 grid(cdiv(m, 4)), block(256);
+    if (d % 256 == 0 && d / 256 <= 8) {
+        switch (d / 256) {
+            case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
+            case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
+            case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
+            case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
+            case 6: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
+            case 8: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
+            default: hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, gamma, beta, y, m, d); break;
+        }
+    } else {
+        hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, gamma, beta, y, m, d);
+    }
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s) {
+    SAT_CHECK_ARG(x && y && n > 0, SAT_E_INVALID, "cast: bad args");
+    SAT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0), SAT_E_INVALID, "cast: unaligned pointers");
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, s, x, y, n);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swiglu_interleave, hipStream_t s) {
+    SAT_CHECK_ARG(w && out && n > 0 && k > 0 && k % 4 == 0, SAT_E_INVALID, "pack_rows: bad args");
+    SAT_CHECK_ARG(!swiglu_interleave || n % 128 == 0, SAT_E_UNSUPPORTED, "pack_rows: swiglu needs n %% 128 == 0");
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(n), dim3(256), 0, s, w, out, n, k, swiglu_interleave);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int sat_launch_pack_bias(const float* b, float* out, int n, int swiglu_interleave, hipStream_t s) {
+    hipLaunchKernelGGL(pack_bias_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, b, out, n, swiglu_interleave);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int sat_launch_rope_table(const float* inv_freq, float* cos_t, float* sin_t, int s_len, hipStream_t s) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv((int64_t)s_len * 16, 256)), dim3(256), 0, s, inv_freq, cos_t, sin_t, s_len);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}

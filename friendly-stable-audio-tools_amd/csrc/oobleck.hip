@@ -1,0 +1,713 @@
+// Oobleck 1-D conv VAE on MI355X: every Conv1d / ConvTranspose1d of
+// models/autoencoders.py:45-194 (reference) runs as ONE implicit-GEMM MFMA kernel over
+// channels-last bf16 activations act[b][t][c]:
+//     out[m][n] = sum_j sum_ci  in[m*stride + off0 + j*doff][ci] * W[j][n][ci]
+//   * dilated k=7 conv      : stride 1, off0 = -3*dil, doff = dil          (autoencoders.py:56)
+//   * k=1 / k=3 conv        : stride 1, off0 = 0 / -1, doff = 1            (:58, :147)
+//   * strided encoder conv  : stride s, off0 = -ceil(s/2), doff = 1, 2s taps (:80-81)
+//   * transposed conv k=2s  : polyphase -- N = s*Cout (phase-major), 2 taps at rows m, m-1;
+//                             row m of the GEMM is the contiguous output span
+//                             [(m*s - pad)*Cout, +s*Cout)                     (:102-105)
+// Contiguous sample windows are loaded with coalesced 16-byte accesses ([t][c] rows are
+// 128..4096 B) into XOR-swizzled LDS tiles; taps re-read the window through L2.
+// SnakeBeta (models/blocks.py:318-319) is never a standalone pass: the PRODUCER's epilogue
+// applies the consumer's Snake to the fp32 accumulator and stores the activated tensor
+// (and the raw tensor only where a residual needs it).  Weight norm (dac WNConv1d) is
+// folded once at plan finalize.
+#include <math.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "sat_common.h"
+
+namespace {
+
+struct ConvArgs {
+    const bf16_t* in;        // [B][Tin][Cin]
+    int Tin, Cin;
+    const bf16_t* W;         // [taps][N][Cin]
+    int taps, N, M;          // M GEMM rows per batch item
+    int stride, off0, doff;
+    const float* bias;       // [Cout] or null ; n -> bias[n % Cout]
+    int Cout;
+    const bf16_t* res;       // residual (raw), same indexing as out ; or null
+    bf16_t* out_raw;         // or null
+    bf16_t* out_snk;         // or null
+    const float* sn_a;       // exp(alpha)[Cout]
+    const float* sn_ib;      // 1/(exp(beta)+1e-9)[Cout]
+    long long out_bstride;   // elements per batch item
+    long long out_shift;     // flat = m*N + out_shift + n ; valid if 0 <= flat < out_limit
+    long long out_limit;
+    float* out_cf;           // channel-first fp32 output [B][cf_channels][M] (final convs) or null
+    int cf_channels;
+};
+
+__device__ __forceinline__ float snake_f(float v, float a, float ib) {
+    float s = __sinf(v * a);
+    return v + ib * (s * s);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_kernel(ConvArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM;
+    constexpr int TN = BN / WN;
+    static_assert(TN == 64, "wave tile is TM x 64");
+    constexpr int MI = TM / 32;
+    constexpr int NI = 2;
+    constexpr int A_CH = BM * 8 / NT;
+    constexpr int B_CH = BN * 8 / NT;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int tiles_n = g.N / BN;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    // n fastest: the (few) column tiles of one time window run back-to-back and share the
+    // input window in L2; weights are small and stay cached.
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n;
+    const int tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    (void)tiles_m;
+
+    const int Cin = g.Cin, Tin = g.Tin;
+    const int cpt = Cin >> 6;                 // 64-channel chunks per tap
+    const int nk = g.taps * cpt;
+    const bf16_t* __restrict__ inb = g.in + (size_t)b * Tin * Cin;
+
+    int a_row[A_CH], a_chk[A_CH], a_m[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        int id = i * NT + tid;
+        a_row[i] = id >> 3;
+        a_chk[i] = id & 7;
+        a_m[i] = (m0 + a_row[i]) * g.stride;
+    }
+    int b_row[B_CH], b_chk[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        int id = i * NT + tid;
+        b_row[i] = id >> 3;
+        b_chk[i] = id & 7;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[A_CH], rb[B_CH];
+    auto gload = [&](int kt) {
+        const int tap = kt / cpt;
+        const int ci0 = (kt - tap * cpt) << 6;
+        const int off = g.off0 + tap * g.doff;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            int r = a_m[i] + off;
+            if (r >= 0 && r < Tin)
+                ra[i] = *reinterpret_cast<const uint4*>(inb + (size_t)r * Cin + ci0 + a_chk[i] * 8);
+            else
+                ra[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const bf16_t* wt = g.W + ((size_t)tap * g.N + n0) * Cin + ci0;
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const uint4*>(wt + (size_t)b_row[i] * Cin + b_chk[i] * 8);
+    };
+    auto lstore = [&](int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(sa + lds_tile_off(a_row[i], a_chk[i])) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(sb + lds_tile_off(b_row[i], b_chk[i])) = rb[i];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* sa = smem + cur * STAGE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31
+    const int mw = m0 + wm * TM;
+    const int nw = n0 + wn * TN;
+    float bia[NI], sa_[NI], sib[NI];
+    int nn[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        nn[j] = nw + j * 32 + l31;
+        int co = nn[j] % g.Cout;
+        bia[j] = g.bias ? g.bias[co] : 0.f;
+        sa_[j] = g.out_snk ? g.sn_a[co] : 0.f;
+        sib[j] = g.out_snk ? g.sn_ib[co] : 0.f;
+    }
+    if (g.out_cf) {
+        float* __restrict__ o = g.out_cf + (size_t)b * g.cf_channels * g.M;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < g.M) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        if (nn[j] < g.cf_channels) o[(size_t)nn[j] * g.M + m] = acc[i][j][r] + bia[j];
+                }
+            }
+        return;
+    }
+    const bf16_t* res = g.res ? g.res + (size_t)b * g.out_bstride : nullptr;
+    bf16_t* oraw = g.out_raw ? g.out_raw + (size_t)b * g.out_bstride : nullptr;
+    bf16_t* __restrict__ osnk = g.out_snk ? g.out_snk + (size_t)b * g.out_bstride : nullptr;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < g.M) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    long long flat = (long long)m * g.N + g.out_shift + nn[j];
+                    if (flat >= 0 && flat < g.out_limit) {
+                        float v = acc[i][j][r] + bia[j];
+                        if (res) v += bf16_to_f32(res[flat]);
+                        if (oraw) oraw[flat] = f32_to_bf16(v);
+                        if (osnk) osnk[flat] = f32_to_bf16(snake_f(v, sa_[j], sib[j]));
+                    }
+                }
+            }
+        }
+}
+
+// z [B][C][T] fp32 (channel-first) -> [B][T][C] bf16
+__global__ __launch_bounds__(256) void cf_to_cl_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int C, int T) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int c = i >> 6, t = i & 63;
+        tile[c][t] = (c0 + c < C && t0 + t < T) ? x[((size_t)b * C + c0 + c) * T + t0 + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int t = i >> 6, c = i & 63;
+        if (c0 + c < C && t0 + t < T) y[((size_t)b * T + t0 + t) * C + c0 + c] = f32_to_bf16(tile[c][t]);
+    }
+}
+
+// OobleckEncoder first conv (autoencoders.py:136): audio [B][Cin<=2][L] fp32 channel-first,
+// k=7 pad 3 -> Cout channels; writes raw + snaked channels-last bf16.  VALU (K = 14).
+__global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict__ x, const float* __restrict__ w /*[Cout][Cin][7]*/,
+                                                         const float* __restrict__ bias, const float* __restrict__ sn_a,
+                                                         const float* __restrict__ sn_ib, bf16_t* __restrict__ out_raw,
+                                                         bf16_t* __restrict__ out_snk, int Cin, int Cout, int L) {
+    __shared__ float xs[2][64 + 6];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 2 * 70; i += 256) {
+        int c = i / 70, k = i - c * 70;
+        int t = t0 + k - 3;
+        xs[c][k] = (c < Cin && t >= 0 && t < L) ? x[((size_t)b * Cin + c) * L + t] : 0.f;
+    }
+    __syncthreads();
+    for (int co = threadIdx.x; co < Cout; co += 256) {
+        float wr[2][7];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int k = 0; k < 7; ++k) wr[c][k] = (c < Cin) ? w[((size_t)co * Cin + c) * 7 + k] : 0.f;
+        const float bv = bias[co], a = sn_a[co], ib = sn_ib[co];
+        for (int tt = 0; tt < 64; ++tt) {
+            if (t0 + tt >= L) break;
+            float acc = bv;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int k = 0; k < 7; ++k) acc += wr[c][k] * xs[c][tt + k];
+            size_t o = ((size_t)b * L + t0 + tt) * Cout + co;
+            out_raw[o] = f32_to_bf16(acc);
+            out_snk[o] = f32_to_bf16(snake_f(acc, a, ib));
+        }
+    }
+}
+
+// ---- weight-norm folding (dac WNConv1d == torch weight_norm dim 0): w = g * v / ||v||
+__global__ __launch_bounds__(256) void wn_invnorm_kernel(const float* __restrict__ v, const float* __restrict__ gsc,
+                                                         float* __restrict__ scale, int slice) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < slice; k += 256) {
+        float x = v[(size_t)i * slice + k];
+        s += x * x;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) scale[i] = gsc[i] / sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+// Conv1d v[co][ci][k] -> W[j][co_pad][ci] bf16 (rows co >= Cout are zero)
+__global__ void wn_pack_conv_kernel(const float* __restrict__ v, const float* __restrict__ scale, bf16_t* __restrict__ W,
+                                    int Cout, int Cin, int k, int Npad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)k * Npad * Cin) return;
+    int ci = (int)(i % Cin);
+    int n = (int)((i / Cin) % Npad);
+    int j = (int)(i / ((size_t)Cin * Npad));
+    W[i] = f32_to_bf16(n < Cout ? v[((size_t)n * Cin + ci) * k + j] * scale[n] : 0.f);
+}
+// same, fp32, original layout (for the VALU first conv)
+__global__ void wn_fold_f32_kernel(const float* __restrict__ v, const float* __restrict__ scale, float* __restrict__ w, int slice,
+                                   size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = v[i] * scale[i / slice];
+}
+// ConvTranspose1d v[ci][co][k=2s] -> W[j][phi*Cout+co][ci] = w[ci][co][phi + j*s]
+__global__ void wn_pack_convT_kernel(const float* __restrict__ v, const float* __restrict__ scale, bf16_t* __restrict__ W,
+                                     int Cin, int Cout, int s) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = s * Cout;
+    if (i >= (size_t)2 * N * Cin) return;
+    int ci = (int)(i % Cin);
+    int n = (int)((i / Cin) % N);
+    int j = (int)(i / ((size_t)Cin * N));
+    int phi = n / Cout, co = n - phi * Cout;
+    W[i] = f32_to_bf16(v[((size_t)ci * Cout + co) * (2 * s) + phi + j * s] * scale[ci]);
+}
+__global__ void snake_params_kernel(const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ a,
+                                    float* __restrict__ ib, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    a[i] = expf(alpha[i]);
+    ib[i] = 1.0f / (expf(beta[i]) + 0.000000001f);
+}
+
+int launch_conv(const ConvArgs& a, int B, hipStream_t s) {
+    SAT_CHECK_ARG(a.Cin % 64 == 0, SAT_E_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", a.Cin);
+    SAT_CHECK_ARG(a.N % 64 == 0, SAT_E_UNSUPPORTED, "conv: N=%d must be a multiple of 64", a.N);
+    if (a.N % 128 == 0) {
+        constexpr int BM = 128, BN = 128, LDS = 2 * (BM + BN) * 128;
+        auto kern = conv_kernel<BM, BN, 2, 2>;
+        static bool set = false;
+        if (!set) {
+            SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(cdiv(a.M, BM) * (a.N / BN), B), dim3(256), LDS, s, a);
+    } else {
+        constexpr int BM = 256, BN = 64, LDS = 2 * (BM + BN) * 128;
+        auto kern = conv_kernel<BM, BN, 4, 1>;
+        static bool set = false;
+        if (!set) {
+            SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(cdiv(a.M, BM) * (a.N / BN), B), dim3(256), LDS, s, a);
+    }
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+struct Snake {
+    float *a = nullptr, *ib = nullptr;
+};
+struct ConvW {
+    bf16_t* W = nullptr;
+    float* bias = nullptr;
+    int Cin = 0, Cout = 0, taps = 0, N = 0;
+};
+
+}  // namespace
+
+struct sat_oobleck_plan {
+    sat_oobleck_cfg cfg;
+    std::map<std::string, std::pair<const float*, int64_t>> tensors;
+    bool finalized = false;
+    char* arena = nullptr;
+    int ratio = 1;
+    std::vector<int> chans;   // channels after each stage, decoder order or encoder order
+    // decoder / encoder share the block structure
+    ConvW first, last;
+    float* first_w_f32 = nullptr;   // encoder first conv (VALU)
+    struct Block {
+        Snake sn_in;             // decoder: block snake before convT ; encoder: snake before strided conv
+        ConvW resample;          // convT (decoder) / strided conv (encoder)
+        Snake ru_sn1[3], ru_sn2[3];
+        ConvW ru_c7[3], ru_c1[3];
+        int stride, cin, cout;
+    };
+    std::vector<Block> blocks;
+    Snake final_snake;
+};
+
+namespace {
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    bool dry = true;
+    void* take(size_t bytes) {
+        size_t o = off;
+        off += (size_t)round_up((int64_t)bytes, 256);
+        return dry ? nullptr : base + o;
+    }
+};
+
+int get_tensor(sat_oobleck_plan* p, const std::string& name, int64_t numel, const float** out) {
+    auto it = p->tensors.find(name);
+    SAT_CHECK_ARG(it != p->tensors.end(), SAT_E_MISSING, "oobleck plan: tensor '%s' was never set", name.c_str());
+    SAT_CHECK_ARG(it->second.second == numel, SAT_E_INVALID, "oobleck plan: tensor '%s' has %lld elements, expected %lld", name.c_str(),
+                  (long long)it->second.second, (long long)numel);
+    *out = it->second.first;
+    return 0;
+}
+
+int make_snake(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int C, Snake* sn, hipStream_t s) {
+    sn->a = (float*)ar.take((size_t)C * 4);
+    sn->ib = (float*)ar.take((size_t)C * 4);
+    if (ar.dry) return 0;
+    const float *al, *be;
+    SAT_TRY(get_tensor(p, pfx + "alpha", C, &al));
+    SAT_TRY(get_tensor(p, pfx + "beta", C, &be));
+    hipLaunchKernelGGL(snake_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, al, be, sn->a, sn->ib, C);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+// Conv1d weight [Cout][Cin][k]
+int make_conv(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, int Cout, int k, bool has_bias, ConvW* cw,
+              hipStream_t s, float** w_f32 = nullptr) {
+    const int Npad = (int)round_up(Cout, 64);
+    cw->Cin = Cin; cw->Cout = Cout; cw->taps = k; cw->N = Npad;
+    float* scale = (float*)ar.take((size_t)Cout * 4);
+    if (w_f32) *w_f32 = (float*)ar.take((size_t)Cout * Cin * k * 4);
+    else cw->W = (bf16_t*)ar.take((size_t)k * Npad * Cin * 2);
+    cw->bias = has_bias ? (float*)ar.take((size_t)Cout * 4) : nullptr;
+    if (ar.dry) return 0;
+    const float *g, *v, *bsrc;
+    SAT_TRY(get_tensor(p, pfx + "weight_g", Cout, &g));
+    SAT_TRY(get_tensor(p, pfx + "weight_v", (int64_t)Cout * Cin * k, &v));
+    hipLaunchKernelGGL(wn_invnorm_kernel, dim3(Cout), dim3(256), 0, s, v, g, scale, Cin * k);
+    if (w_f32) {
+        size_t n = (size_t)Cout * Cin * k;
+        hipLaunchKernelGGL(wn_fold_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, scale, *w_f32, Cin * k, n);
+    } else {
+        size_t n = (size_t)k * Npad * Cin;
+        hipLaunchKernelGGL(wn_pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, scale, cw->W, Cout, Cin, k, Npad);
+    }
+    if (has_bias) {
+        SAT_TRY(get_tensor(p, pfx + "bias", Cout, &bsrc));
+        SAT_HIP(hipMemcpyAsync(cw->bias, bsrc, (size_t)Cout * 4, hipMemcpyDeviceToDevice, s));
+    }
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ConvTranspose1d weight [Cin][Cout][2s]
+int make_convT(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, int Cout, int stride, ConvW* cw, hipStream_t s) {
+    cw->Cin = Cin; cw->Cout = Cout; cw->taps = 2; cw->N = stride * Cout;
+    float* scale = (float*)ar.take((size_t)Cin * 4);
+    cw->W = (bf16_t*)ar.take((size_t)2 * cw->N * Cin * 2);
+    cw->bias = (float*)ar.take((size_t)Cout * 4);
+    if (ar.dry) return 0;
+    const float *g, *v, *bsrc;
+    SAT_TRY(get_tensor(p, pfx + "weight_g", Cin, &g));
+    SAT_TRY(get_tensor(p, pfx + "weight_v", (int64_t)Cin * Cout * 2 * stride, &v));
+    SAT_TRY(get_tensor(p, pfx + "bias", Cout, &bsrc));
+    hipLaunchKernelGGL(wn_invnorm_kernel, dim3(Cin), dim3(256), 0, s, v, g, scale, Cout * 2 * stride);
+    size_t n = (size_t)2 * cw->N * Cin;
+    hipLaunchKernelGGL(wn_pack_convT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, scale, cw->W, Cin, Cout, stride);
+    SAT_HIP(hipMemcpyAsync(cw->bias, bsrc, (size_t)Cout * 4, hipMemcpyDeviceToDevice, s));
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int make_ru(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int C, sat_oobleck_plan::Block& blk, int r, hipStream_t s) {
+    SAT_TRY(make_snake(p, ar, pfx + "layers.0.", C, &blk.ru_sn1[r], s));
+    SAT_TRY(make_conv(p, ar, pfx + "layers.1.", C, C, 7, true, &blk.ru_c7[r], s));
+    SAT_TRY(make_snake(p, ar, pfx + "layers.2.", C, &blk.ru_sn2[r], s));
+    SAT_TRY(make_conv(p, ar, pfx + "layers.3.", C, C, 1, true, &blk.ru_c1[r], s));
+    return 0;
+}
+
+int build(sat_oobleck_plan* p, Arena& ar, hipStream_t s) {
+    const sat_oobleck_cfg& c = p->cfg;
+    const int nb = c.n_blocks;
+    p->blocks.resize(nb);
+    if (c.is_decoder) {
+        // autoencoders.py:174-191: channel list c_mults=[1]+c_mults ; blocks from deepest to shallowest
+        const int ctop = c.c_mults[nb - 1] * c.channels;
+        SAT_TRY(make_conv(p, ar, "layers.0.", c.latent_dim, ctop, 7, true, &p->first, s));
+        for (int bi = 0; bi < nb; ++bi) {
+            const int i = nb - bi;   // reference loop index: range(depth-1, 0, -1)
+            auto& blk = p->blocks[bi];
+            blk.cin = c.c_mults[i - 1] * c.channels;
+            blk.cout = (i - 2 >= 0 ? c.c_mults[i - 2] : 1) * c.channels;
+            blk.stride = c.strides[i - 1];
+            const std::string pf = "layers." + std::to_string(bi + 1) + ".";
+            SAT_TRY(make_snake(p, ar, pf + "layers.0.", blk.cin, &blk.sn_in, s));
+            SAT_TRY(make_convT(p, ar, pf + "layers.1.", blk.cin, blk.cout, blk.stride, &blk.resample, s));
+            for (int r = 0; r < 3; ++r) SAT_TRY(make_ru(p, ar, pf + "layers." + std::to_string(2 + r) + ".", blk.cout, blk, r, s));
+        }
+        SAT_TRY(make_snake(p, ar, "layers." + std::to_string(nb + 1) + ".", c.channels, &p->final_snake, s));
+        SAT_TRY(make_conv(p, ar, "layers." + std::to_string(nb + 2) + ".", c.channels, c.io_channels, 7, false, &p->last, s));
+    } else {
+        // autoencoders.py:131-151
+        SAT_TRY(make_conv(p, ar, "layers.0.", c.io_channels, c.channels, 7, true, &p->first, s, &p->first_w_f32));
+        for (int bi = 0; bi < nb; ++bi) {
+            auto& blk = p->blocks[bi];
+            blk.cin = (bi == 0 ? 1 : c.c_mults[bi - 1]) * c.channels;
+            blk.cout = c.c_mults[bi] * c.channels;
+            blk.stride = c.strides[bi];
+            const std::string pf = "layers." + std::to_string(bi + 1) + ".";
+            for (int r = 0; r < 3; ++r) SAT_TRY(make_ru(p, ar, pf + "layers." + std::to_string(r) + ".", blk.cin, blk, r, s));
+            SAT_TRY(make_snake(p, ar, pf + "layers.3.", blk.cin, &blk.sn_in, s));
+            SAT_TRY(make_conv(p, ar, pf + "layers.4.", blk.cin, blk.cout, 2 * blk.stride, true, &blk.resample, s));
+        }
+        const int ctop = c.c_mults[nb - 1] * c.channels;
+        SAT_TRY(make_snake(p, ar, "layers." + std::to_string(nb + 1) + ".", ctop, &p->final_snake, s));
+        SAT_TRY(make_conv(p, ar, "layers." + std::to_string(nb + 2) + ".", ctop, c.latent_dim, 3, true, &p->last, s));
+    }
+    return 0;
+}
+
+struct Bufs {
+    bf16_t *R, *S0, *S1, *Y;
+    size_t total;
+};
+Bufs carve(const sat_oobleck_plan* p, int B, int T, char* base) {
+    // largest channels-last tensor of the network, in elements per batch item
+    const sat_oobleck_cfg& c = p->cfg;
+    size_t len = (size_t)T, mx = 0;
+    if (c.is_decoder) {
+        mx = (size_t)T * p->blocks[0].cin;
+        for (auto& b : p->blocks) {
+            len *= b.stride;
+            mx = std::max(mx, len * b.cout);
+        }
+    } else {
+        len = (size_t)T * p->ratio;
+        mx = len * c.channels;
+        for (auto& b : p->blocks) {
+            mx = std::max(mx, len * b.cin);
+            len /= b.stride;
+            mx = std::max(mx, len * b.cout);
+        }
+    }
+    size_t per = (size_t)round_up((int64_t)(mx * B * 2), 256);
+    Bufs o;
+    o.R = (bf16_t*)(base ? base : nullptr);
+    o.S0 = (bf16_t*)(base ? base + per : nullptr);
+    o.S1 = (bf16_t*)(base ? base + 2 * per : nullptr);
+    o.Y = (bf16_t*)(base ? base + 3 * per : nullptr);
+    o.total = 4 * per;
+    return o;
+}
+
+ConvArgs base_args(const ConvW& w, const bf16_t* in, int Tin, int M) {
+    ConvArgs a{};
+    a.in = in; a.Tin = Tin; a.Cin = w.Cin; a.W = w.W; a.taps = w.taps; a.N = w.N; a.M = M;
+    a.stride = 1; a.off0 = 0; a.doff = 1; a.bias = w.bias; a.Cout = w.Cout;
+    a.out_bstride = (long long)M * w.N; a.out_shift = 0; a.out_limit = (long long)M * w.N;
+    return a;
+}
+
+// one ResidualUnit (autoencoders.py:45-68): in S (snaked x) + R (raw x) -> R (raw x') and/or Sout (snake_next(x'))
+int run_ru(const sat_oobleck_plan::Block& blk, int r, int C, int L, int B, bf16_t* R, const bf16_t* S, bf16_t* Y, bf16_t* Sout,
+           const Snake& next, bool need_raw, hipStream_t s) {
+    static const int dil[3] = {1, 3, 9};
+    ConvArgs a = base_args(blk.ru_c7[r], S, L, L);
+    a.off0 = -3 * dil[r]; a.doff = dil[r];
+    a.out_snk = Y; a.sn_a = blk.ru_sn2[r].a; a.sn_ib = blk.ru_sn2[r].ib;
+    SAT_TRY(launch_conv(a, B, s));
+    ConvArgs c = base_args(blk.ru_c1[r], Y, L, L);
+    c.res = R;
+    c.out_raw = need_raw ? R : nullptr;   // in place: each thread reads then writes its own elements
+    c.out_snk = Sout; c.sn_a = next.a; c.sn_ib = next.ib;
+    SAT_TRY(launch_conv(c, B, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sat_oobleck_plan_create(const sat_oobleck_cfg* cfg, sat_oobleck_plan** out_plan) {
+    SAT_CHECK_ARG(cfg && out_plan, SAT_E_INVALID, "oobleck_plan_create: null argument");
+    SAT_CHECK_ARG(cfg->n_blocks >= 1 && cfg->n_blocks <= 8, SAT_E_UNSUPPORTED, "oobleck_plan_create: n_blocks %d not in 1..8", cfg->n_blocks);
+    SAT_CHECK_ARG(cfg->channels % 64 == 0 && cfg->channels > 0, SAT_E_UNSUPPORTED, "oobleck_plan_create: channels %d must be a multiple of 64", cfg->channels);
+    SAT_CHECK_ARG(cfg->io_channels >= 1 && cfg->io_channels <= 2, SAT_E_UNSUPPORTED, "oobleck_plan_create: io_channels must be 1 or 2");
+    if (cfg->is_decoder)
+        SAT_CHECK_ARG(cfg->latent_dim % 64 == 0, SAT_E_UNSUPPORTED, "oobleck_plan_create: decoder latent_dim %d must be a multiple of 64", cfg->latent_dim);
+    sat_oobleck_plan* p = new (std::nothrow) sat_oobleck_plan();
+    SAT_CHECK_ARG(p, SAT_E_INVALID, "oobleck_plan_create: out of host memory");
+    p->cfg = *cfg;
+    p->ratio = 1;
+    for (int i = 0; i < cfg->n_blocks; ++i) {
+        SAT_CHECK_ARG(cfg->strides[i] >= 1 && cfg->strides[i] <= 16 && cfg->c_mults[i] >= 1, SAT_E_UNSUPPORTED, "oobleck_plan_create: bad stride/c_mult");
+        p->ratio *= cfg->strides[i];
+    }
+    *out_plan = p;
+    return 0;
+}
+
+extern "C" void sat_oobleck_plan_destroy(sat_oobleck_plan* p) {
+    if (!p) return;
+    if (p->arena) (void)hipFree(p->arena);
+    delete p;
+}
+
+extern "C" int sat_oobleck_plan_set_tensor(sat_oobleck_plan* p, const char* name, const float* data_dev, int64_t numel) {
+    SAT_CHECK_ARG(p && name && data_dev && numel > 0, SAT_E_INVALID, "oobleck_plan_set_tensor: bad argument");
+    p->tensors[name] = {data_dev, numel};
+    return 0;
+}
+
+extern "C" int sat_oobleck_plan_finalize(sat_oobleck_plan* p, sat_stream_t stream) {
+    SAT_CHECK_ARG(p, SAT_E_INVALID, "oobleck_plan_finalize: null plan");
+    hipStream_t s = (hipStream_t)stream;
+    if (p->arena) {
+        (void)hipFree(p->arena);
+        p->arena = nullptr;
+    }
+    p->finalized = false;
+    Arena dry;
+    SAT_TRY(build(p, dry, s));
+    SAT_HIP(hipMalloc((void**)&p->arena, dry.off));
+    Arena real;
+    real.base = p->arena;
+    real.dry = false;
+    SAT_TRY(build(p, real, s));
+    SAT_HIP(hipStreamSynchronize(s));
+    p->tensors.clear();
+    p->finalized = true;
+    return 0;
+}
+
+extern "C" int sat_oobleck_workspace_bytes(const sat_oobleck_plan* p, int32_t b, int32_t t_len, size_t* out_bytes) {
+    SAT_CHECK_ARG(p && out_bytes && b > 0 && t_len > 0, SAT_E_INVALID, "oobleck_workspace_bytes: bad argument");
+    SAT_CHECK_ARG(p->finalized, SAT_E_STATE, "oobleck_workspace_bytes: plan not finalized");
+    *out_bytes = carve(p, b, t_len, nullptr).total;
+    return 0;
+}
+
+extern "C" int sat_oobleck_decode(sat_oobleck_plan* p, const float* z, float* audio, int32_t B, int32_t T, void* ws, size_t ws_bytes,
+                                  sat_stream_t stream) {
+    SAT_CHECK_ARG(p && p->finalized && p->cfg.is_decoder, SAT_E_STATE, "oobleck_decode: not a finalized decoder plan");
+    SAT_CHECK_ARG(z && audio && ws && B > 0 && T > 0, SAT_E_INVALID, "oobleck_decode: bad arguments");
+    SAT_CHECK_ARG(((uintptr_t)ws & 255) == 0, SAT_E_INVALID, "oobleck_decode: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    Bufs bf = carve(p, B, T, (char*)ws);
+    SAT_CHECK_ARG(ws_bytes >= bf.total, SAT_E_WORKSPACE, "oobleck_decode: workspace %zu < required %zu", ws_bytes, bf.total);
+    const sat_oobleck_cfg& c = p->cfg;
+    const int nb = c.n_blocks;
+    // latents -> channels-last bf16 (in Y), first conv (autoencoders.py:175) -> S0 = snake_block1(x)
+    hipLaunchKernelGGL(cf_to_cl_kernel, dim3(cdiv(T, 64), cdiv(c.latent_dim, 64), B), dim3(256), 0, s, z, bf.Y, c.latent_dim, T);
+    SAT_LAUNCH_CHECK();
+    bf16_t* S = bf.S0;
+    bf16_t* Sn = bf.S1;
+    {
+        ConvArgs a = base_args(p->first, bf.Y, T, T);
+        a.off0 = -3;
+        a.out_snk = S; a.sn_a = p->blocks[0].sn_in.a; a.sn_ib = p->blocks[0].sn_in.ib;
+        SAT_TRY(launch_conv(a, B, s));
+    }
+    int L = T;
+    for (int bi = 0; bi < nb; ++bi) {
+        const auto& blk = p->blocks[bi];
+        const int st = blk.stride, pad = (st + 1) / 2;
+        // transposed conv (autoencoders.py:102-105): rows m = 0..L, output row span (m*st - pad)*Cout
+        ConvArgs a = base_args(blk.resample, S, L, L + 1);
+        a.off0 = 0; a.doff = -1;
+        a.out_bstride = (long long)L * st * blk.cout;
+        a.out_shift = -(long long)pad * blk.cout;
+        a.out_limit = (long long)L * st * blk.cout;
+        a.out_raw = bf.R;
+        a.out_snk = Sn; a.sn_a = blk.ru_sn1[0].a; a.sn_ib = blk.ru_sn1[0].ib;
+        SAT_TRY(launch_conv(a, B, s));
+        std::swap(S, Sn);
+        L *= st;
+        for (int r = 0; r < 3; ++r) {
+            const Snake& next = r < 2 ? blk.ru_sn1[r + 1] : (bi + 1 < nb ? p->blocks[bi + 1].sn_in : p->final_snake);
+            SAT_TRY(run_ru(blk, r, blk.cout, L, B, bf.R, S, bf.Y, Sn, next, r < 2, s));
+            std::swap(S, Sn);
+        }
+    }
+    // final conv (autoencoders.py:187): no bias, no tanh -> fp32 channel-first audio
+    ConvArgs a = base_args(p->last, S, L, L);
+    a.off0 = -3;
+    a.out_cf = audio; a.cf_channels = c.io_channels;
+    SAT_TRY(launch_conv(a, B, s));
+    return 0;
+}
+
+extern "C" int sat_oobleck_encode(sat_oobleck_plan* p, const float* audio, float* out, int32_t B, int32_t T, void* ws,
+                                  size_t ws_bytes, sat_stream_t stream) {
+    SAT_CHECK_ARG(p && p->finalized && !p->cfg.is_decoder, SAT_E_STATE, "oobleck_encode: not a finalized encoder plan");
+    SAT_CHECK_ARG(audio && out && ws && B > 0 && T > 0, SAT_E_INVALID, "oobleck_encode: bad arguments");
+    SAT_CHECK_ARG(((uintptr_t)ws & 255) == 0, SAT_E_INVALID, "oobleck_encode: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    Bufs bf = carve(p, B, T, (char*)ws);
+    SAT_CHECK_ARG(ws_bytes >= bf.total, SAT_E_WORKSPACE, "oobleck_encode: workspace %zu < required %zu", ws_bytes, bf.total);
+    const sat_oobleck_cfg& c = p->cfg;
+    const int nb = c.n_blocks;
+    int L = T * p->ratio;
+    bf16_t* S = bf.S0;
+    bf16_t* Sn = bf.S1;
+    hipLaunchKernelGGL(first_conv_kernel, dim3(cdiv(L, 64), B), dim3(256), 0, s, audio, p->first_w_f32, p->first.bias,
+                       p->blocks[0].ru_sn1[0].a, p->blocks[0].ru_sn1[0].ib, bf.R, S, c.io_channels, c.channels, L);
+    SAT_LAUNCH_CHECK();
+    for (int bi = 0; bi < nb; ++bi) {
+        const auto& blk = p->blocks[bi];
+        for (int r = 0; r < 3; ++r) {
+            const Snake& next = r < 2 ? blk.ru_sn1[r + 1] : blk.sn_in;
+            SAT_TRY(run_ru(blk, r, blk.cin, L, B, bf.R, S, bf.Y, Sn, next, r < 2, s));
+            std::swap(S, Sn);
+        }
+        const int st = blk.stride, pad = (st + 1) / 2;
+        const int Lo = L / st;
+        ConvArgs a = base_args(blk.resample, S, L, Lo);
+        a.stride = st; a.off0 = -pad; a.doff = 1;
+        const bool lastb = bi + 1 == nb;
+        a.out_raw = lastb ? nullptr : bf.R;
+        const Snake& nx = lastb ? p->final_snake : p->blocks[bi + 1].ru_sn1[0];
+        a.out_snk = Sn; a.sn_a = nx.a; a.sn_ib = nx.ib;
+        SAT_TRY(launch_conv(a, B, s));
+        std::swap(S, Sn);
+        L = Lo;
+    }
+    ConvArgs a = base_args(p->last, S, L, L);
+    a.off0 = -1;
+    a.out_cf = out; a.cf_channels = c.latent_dim;
+    SAT_TRY(launch_conv(a, B, s));
+    return 0;
+}

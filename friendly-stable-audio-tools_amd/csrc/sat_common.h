@@ -1,0 +1,132 @@
+// Shared device/host helpers for libsat_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/sat_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void sat_set_error(const char* fmt, ...);
+
+#define SAT_CHECK_ARG(cond, code, ...)            \
+    do {                                          \
+        if (!(cond)) {                            \
+            sat_set_error(__VA_ARGS__);           \
+            return (code);                        \
+        }                                         \
+    } while (0)
+
+#define SAT_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            sat_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (int)e__;                                                                \
+        }                                                                                   \
+    } while (0)
+
+#define SAT_LAUNCH_CHECK()                                                                  \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess) {                                                            \
+            sat_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (int)e__;                                                                \
+        }                                                                                   \
+    } while (0)
+
+#define SAT_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }   // RNE
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids
+// land on the same XCD (hardware places block b on XCD b % 8), so neighbouring tiles share
+// one L2.  Speed only -- never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    int xcd = bid % NX, idx = bid / NX;
+    int q = nwg / NX, r = nwg % NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// LDS tile layout used by the MFMA kernels: rows of 64 bf16 (128 B = eight 16-B chunks);
+// chunk c of row r lives at chunk (c ^ ((r >> 1) & 7)).  With this XOR every 16-lane group
+// of a ds_read_b128 fragment read (16 distinct rows, same logical chunk) covers all 16
+// 16-B slots of the 256-B bank row: conflict-free; an 8-lane ds_write_b128 group (one row,
+// 8 chunks) is conflict-free as well.
+__device__ __forceinline__ int lds_tile_off(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// ---------------------------------------------------------------------------------------
+// internal launchers shared between translation units
+// ---------------------------------------------------------------------------------------
+enum { EPI_F32 = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_HEADS = 3 };
+
+struct HeadsEpi {
+    bf16_t* out[3];      // per part destination
+    int kind[3];         // bit0: transposed ([B,Hh,64,Spad]) else [B,Hh,Spad,64]; bit1: apply RoPE
+    int parts;           // N == parts * heads * 64
+    int heads;           // heads per part
+    int S;               // valid rows per sequence (row m -> b = m / S, s = m % S)
+    int Spad;            // padded sequence length of the destination
+    const float* rope_cos;   // [>=S][16]
+    const float* rope_sin;
+};
+
+struct GemmArgs {
+    const bf16_t* A;     // [M,K]
+    const bf16_t* W;     // [N,K]
+    const float* bias;   // [N] or nullptr
+    int M, N, K;
+    int variant;
+    // EPI_F32 / EPI_RESID
+    float* C;            // [M,ldc]
+    int ldc;
+    int accumulate;
+    // EPI_SWIGLU
+    bf16_t* H;           // [M, N/2]
+    // EPI_HEADS
+    HeadsEpi heads;
+};
+
+int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream);
+int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s);
+int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
+                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s);
+int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
+int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swiglu_interleave, hipStream_t s);
+int sat_launch_pack_bias(const float* b, float* out, int n, int swiglu_interleave, hipStream_t s);
+int sat_launch_rope_table(const float* inv_freq, float* cos_t, float* sin_t, int s_len, hipStream_t s);

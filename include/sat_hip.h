@@ -1,0 +1,207 @@
+/*
+ * sat_hip.h -- C ABI of libsat_hip.so: the MI355X (gfx950) implementation of the
+ * diffusion-sampling hot path of stable-audio-tools (DiT denoiser + DPM-Solver++ update +
+ * Oobleck VAE encode/decode).
+ *
+ * The reference (yukara-ikemiya/friendly-stable-audio-tools) is pure Python on stock
+ * PyTorch ops and has NO FFI / plugin boundary of its own: the
+ * boundary it exposes is its Python API.  This header is what a Python (ctypes), C++ or
+ * any-other-language host binds *underneath* that API.  Each entry point names the
+ * reference interface it replaces (paths relative to stable_audio_tools/ in the reference).
+ *
+ * Conventions
+ *   - return 0 on success; negative SAT_E_* on invalid argument / unsupported config;
+ *     positive = hipError_t of a failed HIP call.  Never throws, never exits.
+ *     sat_last_error() gives a thread-local message for the last non-zero return.
+ *   - all pointers named *_dev are DEVICE pointers owned by the caller (e.g. PyTorch
+ *     storage); tensors are dense, row-major ("PyTorch contiguous"), fp32 unless noted.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All compute
+ *     calls are asynchronous on that stream; no call synchronises the device.
+ *   - no allocation on the hot calls (forward / denoise / step / decode / encode): the
+ *     caller supplies the workspace; plans own only re-packed (bf16) weights and the
+ *     per-generation cross-attention K/V cache (allocated in *_prepare_context).
+ *   - a plan is not thread-safe; distinct plans are independent.  One process per GPU.
+ */
+#ifndef SAT_HIP_H
+#define SAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAT_OK 0
+#define SAT_E_INVALID (-1)      /* bad argument (NULL, shape, size) */
+#define SAT_E_UNSUPPORTED (-2)  /* configuration outside the kernels' supported set */
+#define SAT_E_MISSING (-3)      /* a required tensor was never set */
+#define SAT_E_WORKSPACE (-4)    /* workspace too small */
+#define SAT_E_STATE (-5)        /* call order violated (e.g. forward before finalize) */
+
+typedef void* sat_stream_t;     /* hipStream_t */
+
+int sat_version(void);
+const char* sat_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * DiT denoiser.  Replaces models/dit.py:135-364 (DiffusionTransformer._forward/.forward),
+ * models/transformer.py:99-809 (ContinuousTransformer, TransformerBlock, Attention,
+ * FeedForward, LayerNorm, RotaryEmbedding), models/diffusion.py:482-529 (DiTWrapper).
+ * Supported set: transformer_type "continuous_transformer", global_cond_type "prepend",
+ * dim_heads 64, patch_size 1, no input_concat / prepend_cond, non-causal, no masks
+ * (the reference discards them at inference: models/dit.py:250-252).
+ * ---------------------------------------------------------------------------------- */
+typedef struct sat_dit_plan sat_dit_plan;
+
+typedef struct sat_dit_cfg {
+    int32_t io_channels;       /* config "io_channels" (64) */
+    int32_t embed_dim;         /* "embed_dim" (1536); multiple of 128 */
+    int32_t depth;             /* "depth" (24) */
+    int32_t num_heads;         /* "num_heads" (24); embed_dim / num_heads must be 64 */
+    int32_t cond_token_dim;    /* "cond_token_dim" (768); 0 = no cross-attention */
+    int32_t cond_embed_dim;    /* cond_token_dim if project_cond_tokens=false else embed_dim */
+    int32_t global_cond_dim;   /* "global_cond_dim" (1536); 0 = timestep embedding only */
+    int32_t max_seq_len;       /* largest latent length T the plan will see (+1 prepend) */
+} sat_dit_cfg;
+
+int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
+void sat_dit_plan_destroy(sat_dit_plan* plan);
+
+/* Hand one fp32 tensor of the reference state dict to the plan.  `name` is the key
+ * RELATIVE to the DiffusionTransformer module ("model.model." stripped), e.g.
+ * "transformer.layers.3.ff.ff.0.proj.weight" (models/dit.py, models/transformer.py module
+ * tree).  The pointer is only read inside sat_dit_plan_finalize. */
+int sat_dit_plan_set_tensor(sat_dit_plan* plan, const char* name, const float* data_dev, int64_t numel);
+
+/* Checks that every required tensor was set, converts GEMM weights to bf16 (SwiGLU rows
+ * interleaved), folds the 1x1 pre/post convs into the in/out projections, builds the RoPE
+ * table.  Replaces nn.Module.load_state_dict for the DiT. */
+int sat_dit_plan_finalize(sat_dit_plan* plan, sat_stream_t stream);
+
+/* Bytes of caller workspace needed by sat_dit_forward / sat_dit_denoise_cfg for `bf`
+ * sequences (bf = 2*B with CFG) of latent length `t_len`. */
+int sat_dit_workspace_bytes(const sat_dit_plan* plan, int32_t bf, int32_t t_len, size_t* out_bytes);
+
+/* Per-generation constants (models/dit.py:150,154 to_cond_embed / to_global_embed and the
+ * per-layer cross-attention to_kv projection, models/transformer.py:420-427): computed
+ * once, reused by all sampler steps.  cross_attn_cond_dev [bf, lc, cond_token_dim] (NULL
+ * if the model has no cross-attention), global_cond_dev [bf, global_cond_dim] or NULL. */
+int sat_dit_prepare_context(sat_dit_plan* plan, const float* cross_attn_cond_dev, int32_t bf, int32_t lc,
+                            const float* global_cond_dev, sat_stream_t stream);
+
+/* DiffusionTransformer._forward (models/dit.py:135-226) on bf sequences:
+ * x_dev [bf, io_channels, t_len], t_dev [bf] (timestep in [0,1]) -> out_dev [bf, io_channels, t_len]. */
+int sat_dit_forward(sat_dit_plan* plan, const float* x_dev, const float* t_dev, float* out_dev,
+                    int32_t bf, int32_t t_len, void* workspace_dev, size_t workspace_bytes, sat_stream_t stream);
+
+/* One k-diffusion VDenoiser evaluation with batched CFG (k_diffusion.external.VDenoiser
+ * called at inference/sampling.py:159 around DiTWrapper.forward; CFG models/dit.py:270-349):
+ *   denoised = cfg(DiT(x*c_in, t(sigma))) * c_out + x * c_skip
+ * x_dev, denoised_dev [b, io_channels, t_len]; the context prepared must hold bf = 2*b
+ * sequences (cond half first, uncond half second) when cfg_scale != 1, else bf = b.
+ * scale_phi: CFG rescale (models/dit.py:342-345); 0 = off. */
+int sat_dit_denoise_cfg(sat_dit_plan* plan, const float* x_dev, float sigma, float cfg_scale, float scale_phi,
+                        float* denoised_dev, int32_t b, int32_t t_len,
+                        void* workspace_dev, size_t workspace_bytes, sat_stream_t stream);
+
+/* Batched-CFG combine alone (models/dit.py:336-345): model_out_dev [2*b, c, t] (cond half, then
+ * uncond half) -> out_dev [b, c, t] = uncond + (cond - uncond) * cfg_scale, with the optional
+ * std rescale when scale_phi != 0. */
+int sat_cfg_combine(const float* model_out_dev, float* out_dev, int32_t b, int32_t c, int32_t t,
+                    float cfg_scale, float scale_phi, sat_stream_t stream);
+
+/* One DPM-Solver++(3M) SDE update (k_diffusion.sampling.sample_dpmpp_3m_sde, called at
+ * inference/sampling.py:228), fused elementwise over n elements:
+ *   x <- a*x + b*d + c1*(d - d1) + c2*(d1 - d2) + cn*noise     (in place on x_dev)
+ * The host computes the scalars from the sigma schedule (see the Python host code);
+ * d1_dev / d2_dev / noise_dev may be NULL when their coefficient is 0. */
+int sat_dpmpp3m_update(float* x_dev, const float* d_dev, const float* d1_dev, const float* d2_dev,
+                       const float* noise_dev, float a, float b, float c1, float c2, float cn,
+                       int64_t n, sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Oobleck VAE.  Replaces models/autoencoders.py:45-194 (ResidualUnit, EncoderBlock,
+ * DecoderBlock, OobleckEncoder, OobleckDecoder), models/blocks.py:318-358 (SnakeBeta),
+ * dac.nn.layers.WNConv1d/WNConvTranspose1d (weight norm folded at finalize).
+ * ---------------------------------------------------------------------------------- */
+typedef struct sat_oobleck_plan sat_oobleck_plan;
+
+typedef struct sat_oobleck_cfg {
+    int32_t is_decoder;        /* 1 = OobleckDecoder, 0 = OobleckEncoder */
+    int32_t io_channels;       /* decoder out_channels / encoder in_channels (2) */
+    int32_t channels;          /* "channels" (128) */
+    int32_t latent_dim;        /* decoder input (64) / encoder output (128) channels */
+    int32_t n_blocks;          /* len(strides) (5) */
+    int32_t c_mults[8];        /* WITHOUT the implicit leading 1: e.g. {1,2,4,8,16} */
+    int32_t strides[8];        /* e.g. {2,4,4,8,8} */
+} sat_oobleck_cfg;
+
+int sat_oobleck_plan_create(const sat_oobleck_cfg* cfg, sat_oobleck_plan** out_plan);
+void sat_oobleck_plan_destroy(sat_oobleck_plan* plan);
+/* `name` relative to the OobleckEncoder/OobleckDecoder module, e.g.
+ * "layers.1.layers.2.layers.1.weight_v". */
+int sat_oobleck_plan_set_tensor(sat_oobleck_plan* plan, const char* name, const float* data_dev, int64_t numel);
+int sat_oobleck_plan_finalize(sat_oobleck_plan* plan, sat_stream_t stream);
+/* latent length `t_len` for both directions (audio length = t_len * prod(strides)). */
+int sat_oobleck_workspace_bytes(const sat_oobleck_plan* plan, int32_t b, int32_t t_len, size_t* out_bytes);
+
+/* OobleckDecoder.forward (models/autoencoders.py:193-194): z_dev [b, latent_dim, t_len]
+ * -> audio_dev [b, io_channels, t_len * prod(strides)] fp32. */
+int sat_oobleck_decode(sat_oobleck_plan* plan, const float* z_dev, float* audio_dev, int32_t b, int32_t t_len,
+                       void* workspace_dev, size_t workspace_bytes, sat_stream_t stream);
+/* OobleckEncoder.forward (models/autoencoders.py:152-153): audio_dev [b, io_channels, t_len*ratio]
+ * -> out_dev [b, latent_dim, t_len] fp32 (for the VAE: mean | scale halves). */
+int sat_oobleck_encode(sat_oobleck_plan* plan, const float* audio_dev, float* out_dev, int32_t b, int32_t t_len,
+                       void* workspace_dev, size_t workspace_bytes, sat_stream_t stream);
+
+/* VAEBottleneck.encode / vae_sample (models/bottleneck.py:46-62) with the Gaussian noise
+ * supplied by the caller: z = noise * (softplus(scale) + 1e-4) + mean.
+ * mean_scale_dev [b, 2*c, t], noise_dev/z_dev [b, c, t]. */
+int sat_vae_sample(const float* mean_scale_dev, const float* noise_dev, float* z_dev,
+                   int32_t b, int32_t c, int32_t t, sat_stream_t stream);
+
+/* float_to_int16_audio (utils/audio_utils.py:21-26) for one item of n samples:
+ * peak = max|x| (device reduction), div = maximize ? peak : max(peak, 1),
+ * out = (int16) trunc(x / div * 32767).  scratch_dev: >= 4 bytes. */
+int sat_float_to_int16(const float* x_dev, int16_t* out_dev, int64_t n, int32_t maximize,
+                       void* scratch_dev, sat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Unit-level entry points (used by the parity tests and micro-benchmarks; the plans above
+ * are built from exactly these kernels).
+ * ---------------------------------------------------------------------------------- */
+/* LayerNorm (models/transformer.py:205-206): x [m,d] fp32 -> y [m,d] bf16 (eps 1e-5). */
+int sat_layernorm_bf16(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_bf16_dev,
+                       int32_t m, int32_t d, sat_stream_t stream);
+/* fp32 -> bf16 (round to nearest even) */
+int sat_cast_bf16(const float* x_dev, void* y_bf16_dev, int64_t n, sat_stream_t stream);
+/* C[m,n] (fp32) = A[m,k] (bf16) * W[n,k]^T (bf16)  (+ bias[n]) ; accumulate != 0 adds into C.
+ * n % 128 == 0, k % 64 == 0.  variant selects a tile configuration (0 = default). */
+int sat_gemm_bf16_f32(const void* a_bf16_dev, const void* w_bf16_dev, const float* bias_dev, float* c_dev,
+                      int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream);
+/* SwiGLU GEMM (models/transformer.py:211-235): h[m,n/2] (bf16) = (A W_v^T + b_v) * silu(A W_g^T + b_g)
+ * with W [n,k] in the REFERENCE row order (value rows then gate rows); re-packed internally
+ * into wpack_dev [n,k] bf16 and bpack_dev [n] fp32 scratch. */
+int sat_gemm_swiglu_bf16(const void* a_bf16_dev, const float* w_f32_dev, const float* bias_f32_dev,
+                         void* wpack_dev, float* bpack_dev, void* h_bf16_dev,
+                         int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream);
+/* Attention core (models/transformer.py:496-536): q [b,h,sq_pad,64], k [b,kvh,sk_pad,64],
+ * vt [b,kvh,64,sk_pad] bf16 -> out [b*sq, h*64] bf16; softmax(q k^T / 8) v, GQA h/kvh. */
+int sat_attention_bf16(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
+                       int32_t b, int32_t h, int32_t kvh, int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad,
+                       sat_stream_t stream);
+/* Fused QKV projection + partial RoPE + head split (models/transformer.py:430-452):
+ * a [b*s, d] bf16, w_qkv [3d, d] bf16 -> q,k [b,h,s_pad,64], vt [b,h,64,s_pad] bf16.
+ * inv_freq_dev [16] fp32 (RotaryEmbedding.inv_freq, models/transformer.py:114-115). */
+int sat_qkv_rope_bf16(const void* a_bf16_dev, const void* w_bf16_dev, const float* inv_freq_dev,
+                      void* q_dev, void* k_dev, void* vt_dev, float* rope_scratch_dev,
+                      int32_t b, int32_t s, int32_t s_pad, int32_t d, int32_t variant, sat_stream_t stream);
+/* SnakeBeta (models/blocks.py:318-319): y = x + sin^2(x*exp(alpha_c)) / (exp(beta_c)+1e-9); x,y [b,c,t] fp32 */
+int sat_snake_beta(const float* x_dev, const float* alpha_dev, const float* beta_dev, float* y_dev,
+                   int32_t b, int32_t c, int32_t t, sat_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAT_HIP_H */

@@ -36,58 +36,56 @@ def _wconv(sd, pfx, rnd):
     return _r(rnd, fold_weight_norm(sd[pfx + "weight_g"], sd[pfx + "weight_v"]))
 
 
-# models/autoencoders.py:45-68 (ResidualUnit)
-def residual_unit(sd, pfx, x, dilation, rnd=None):
-    h = _r(rnd, snake_beta(x, sd[pfx + "layers.0.alpha"], sd[pfx + "layers.0.beta"]))
-    h = F.conv1d(h, _wconv(sd, pfx + "layers.1.", rnd), sd[pfx + "layers.1.bias"],
+# models/autoencoders.py:45-68 (ResidualUnit).  Matched-rounding convention (rnd != None): tensors
+# travel as their fp32 PRE-ROUND value v; a consumer sees rnd(snake(v)) as conv input and rnd(v)
+# as residual -- exactly what the HIP epilogues store (Snake is applied to the fp32 accumulator).
+def residual_unit(sd, pfx, v, dilation, rnd=None):
+    h = _r(rnd, snake_beta(v, sd[pfx + "layers.0.alpha"], sd[pfx + "layers.0.beta"]))
+    y = F.conv1d(h, _wconv(sd, pfx + "layers.1.", rnd), sd[pfx + "layers.1.bias"],
                  dilation=dilation, padding=(dilation * 6) // 2)
-    h = _r(rnd, h)
-    h = _r(rnd, snake_beta(h, sd[pfx + "layers.2.alpha"], sd[pfx + "layers.2.beta"]))
+    h = _r(rnd, snake_beta(y, sd[pfx + "layers.2.alpha"], sd[pfx + "layers.2.beta"]))
     h = F.conv1d(h, _wconv(sd, pfx + "layers.3.", rnd), sd[pfx + "layers.3.bias"])
-    return _r(rnd, h + x)
+    return h + _r(rnd, v)
 
 
 # models/autoencoders.py:88-116 (DecoderBlock) + :156-194 (OobleckDecoder)
 def oobleck_decoder(sd, z, strides=(2, 4, 4, 8, 8), rnd=None, return_stages=False):
     """z [B,latent,T] -> [B,out_channels,T*prod(strides)]."""
     stages = []
-    x = _r(rnd, z)
-    x = _r(rnd, F.conv1d(x, _wconv(sd, "layers.0.", rnd), sd["layers.0.bias"], padding=3))
-    stages.append(x)
+    v = F.conv1d(_r(rnd, z), _wconv(sd, "layers.0.", rnd), sd["layers.0.bias"], padding=3)
+    stages.append(v)
     depth = len(strides)
     for bi in range(depth):
         stride = strides[depth - 1 - bi]
         pfx = f"layers.{bi + 1}."
-        h = _r(rnd, snake_beta(x, sd[pfx + "layers.0.alpha"], sd[pfx + "layers.0.beta"]))
-        x = F.conv_transpose1d(h, _wconv(sd, pfx + "layers.1.", rnd), sd[pfx + "layers.1.bias"],
+        h = _r(rnd, snake_beta(v, sd[pfx + "layers.0.alpha"], sd[pfx + "layers.0.beta"]))
+        v = F.conv_transpose1d(h, _wconv(sd, pfx + "layers.1.", rnd), sd[pfx + "layers.1.bias"],
                                stride=stride, padding=math.ceil(stride / 2))
-        x = _r(rnd, x)
         for ri, dil in enumerate((1, 3, 9)):
-            x = residual_unit(sd, f"{pfx}layers.{2 + ri}.", x, dil, rnd)
-        stages.append(x)
+            v = residual_unit(sd, f"{pfx}layers.{2 + ri}.", v, dil, rnd)
+        stages.append(v)
     k = depth + 1
-    h = _r(rnd, snake_beta(x, sd[f"layers.{k}.alpha"], sd[f"layers.{k}.beta"]))
+    h = _r(rnd, snake_beta(v, sd[f"layers.{k}.alpha"], sd[f"layers.{k}.beta"]))
     out = F.conv1d(h, _wconv(sd, f"layers.{k + 1}.", rnd), None, padding=3)   # bias=False, final_tanh=False
     return (out, stages) if return_stages else out
 
 
 # models/autoencoders.py:71-85 (EncoderBlock) + :119-153 (OobleckEncoder)
 def oobleck_encoder(sd, audio, strides=(2, 4, 4, 8, 8), rnd=None):
-    """audio [B,in_ch,L] -> [B,latent_dim(=2*latent for VAE),L/prod(strides)]."""
-    x = _r(rnd, audio)
-    x = _r(rnd, F.conv1d(x, _wconv(sd, "layers.0.", rnd), sd["layers.0.bias"], padding=3))
+    """audio [B,in_ch,L] -> [B,latent_dim(=2*latent for VAE),L/prod(strides)].  The first conv reads
+    the fp32 audio with fp32 (folded) weights in the HIP path as well, hence no rounding there."""
+    v = F.conv1d(audio, fold_weight_norm(sd["layers.0.weight_g"], sd["layers.0.weight_v"]), sd["layers.0.bias"], padding=3)
     depth = len(strides)
     for bi in range(depth):
         stride = strides[bi]
         pfx = f"layers.{bi + 1}."
         for ri, dil in enumerate((1, 3, 9)):
-            x = residual_unit(sd, f"{pfx}layers.{ri}.", x, dil, rnd)
-        h = _r(rnd, snake_beta(x, sd[pfx + "layers.3.alpha"], sd[pfx + "layers.3.beta"]))
-        x = F.conv1d(h, _wconv(sd, pfx + "layers.4.", rnd), sd[pfx + "layers.4.bias"],
+            v = residual_unit(sd, f"{pfx}layers.{ri}.", v, dil, rnd)
+        h = _r(rnd, snake_beta(v, sd[pfx + "layers.3.alpha"], sd[pfx + "layers.3.beta"]))
+        v = F.conv1d(h, _wconv(sd, pfx + "layers.4.", rnd), sd[pfx + "layers.4.bias"],
                      stride=stride, padding=math.ceil(stride / 2))
-        x = _r(rnd, x)
     k = depth + 1
-    h = _r(rnd, snake_beta(x, sd[f"layers.{k}.alpha"], sd[f"layers.{k}.beta"]))
+    h = _r(rnd, snake_beta(v, sd[f"layers.{k}.alpha"], sd[f"layers.{k}.beta"]))
     return F.conv1d(h, _wconv(sd, f"layers.{k + 1}.", rnd), sd[f"layers.{k + 1}.bias"], padding=1)
 
 

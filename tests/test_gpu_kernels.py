@@ -1,0 +1,216 @@
+"""Per-kernel parity: HIP kernels (through the C ABI) vs plain fp32 torch statements of the same
+op / the oracle, on seeded inputs.  Tolerances: bf16-operand kernels are compared with a reference
+fed the SAME bf16-rounded operands and fp32 accumulation, so only accumulation order and the final
+bf16 store differ: rel-L2 <= 1e-3 for fp32 outputs, <= 4e-3 for bf16 outputs (one rounding, 2^-9)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, bf16_round, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from stable_audio_tools import _hip
+    return _hip, _hip.lib()
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("m,d", [(2050, 1536), (37, 256), (5, 768)])
+def test_layernorm(dev, m, d):
+    _hip, lib = _lib()
+    x = _rand((m, d), 1, 2.0) + 0.3
+    g = 0.5 + 0.1 * _rand((d,), 2)
+    b = 0.05 * _rand((d,), 3)
+    want = F.layer_norm(x, (d,), g, b, eps=1e-5)
+    xd, gd, bd = x.to(dev), g.to(dev), b.to(dev)
+    y = torch.empty((m, d), dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_layernorm_bf16(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(y), m, d, _hip.stream()))
+    assert_close("layernorm", y, want, 4e-3)
+    assert_close("layernorm-vs-rounded", y, bf16_round(want), 1e-3)
+
+
+def test_cast_bf16(dev):
+    _hip, lib = _lib()
+    x = _rand((1000003,), 4)
+    xd = x.to(dev)
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_cast_bf16(_hip.ptr(xd), _hip.ptr(y), x.numel(), _hip.stream()))
+    assert torch.equal(y.cpu(), x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("m,n,k", [(2050, 1536, 1536), (130, 256, 128), (1, 512, 64), (257, 768, 6144)])
+def test_gemm_f32(dev, variant, m, n, k):
+    if variant in (3, 4) and n % 256:
+        pytest.skip("256-column tile needs n % 256 == 0")
+    _hip, lib = _lib()
+    a = _rand((m, k), 5).to(torch.bfloat16)
+    # asymmetric weights so that a transposed / mis-indexed tile cannot pass
+    w = (_rand((n, k), 6) * 0.05 + torch.linspace(-0.02, 0.03, n)[:, None]).to(torch.bfloat16)
+    bias = _rand((n,), 7)
+    c0 = _rand((m, n), 8)
+    want = a.float() @ w.float().T + bias + c0
+    ad, wd, bd, cd = a.to(dev), w.to(dev), bias.to(dev), c0.to(dev)
+    _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1, variant, _hip.stream()))
+    assert_close(f"gemm v{variant} {m}x{n}x{k}", cd, want, 1e-3)
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_gemm_swiglu(dev, variant):
+    _hip, lib = _lib()
+    m, k, inner = 300, 256, 512
+    a = _rand((m, k), 9).to(torch.bfloat16)
+    w = _rand((2 * inner, k), 10) * 0.08
+    bias = _rand((2 * inner,), 11) * 0.1
+    h = F.linear(a.float(), bf16_round(w), bias)
+    val, gate = h.chunk(2, dim=-1)
+    want = val * F.silu(gate)
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    wp = torch.empty((2 * inner, k), dtype=torch.bfloat16, device=dev)
+    bp = torch.empty((2 * inner,), dtype=torch.float32, device=dev)
+    out = torch.empty((m, inner), dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m,
+                                        2 * inner, k, variant, _hip.stream()))
+    assert_close("swiglu", out, want, 4e-3)
+
+
+def _pad_heads(x, s_pad):
+    # [B,H,S,64] -> zero-padded [B,H,s_pad,64]
+    b, h, s, d = x.shape
+    out = torch.zeros((b, h, s_pad, d), dtype=x.dtype)
+    out[:, :, :s] = x
+    return out
+
+
+@pytest.mark.parametrize("b,h,kvh,sq,sk", [(2, 4, 4, 1025, 1025), (1, 4, 2, 300, 130), (2, 2, 2, 64, 64), (1, 2, 1, 129, 7)])
+def test_attention(dev, b, h, kvh, sq, sk):
+    from oracle import dit as odit
+    _hip, lib = _lib()
+    q = (_rand((b, h, sq, 64), 12) * 1.5).to(torch.bfloat16)
+    k = (_rand((b, kvh, sk, 64), 13) * 1.5).to(torch.bfloat16)
+    v = _rand((b, kvh, sk, 64), 14).to(torch.bfloat16)
+    # spike one key against one query so that the running max jumps late in the sequence (rescale branch)
+    k[0, 0, sk - 1] = q[0, 0, min(5, sq - 1)] * 3
+    want = odit._merge(odit.attention_core(q.float(), k.float(), v.float(), rnd=bf16_round))
+    sq_pad = (sq + 127) // 128 * 128
+    sk_pad = (sk + 63) // 64 * 64
+    qd = _pad_heads(q, sq_pad).to(dev)
+    kd = _pad_heads(k, sk_pad).to(dev)
+    vtd = _pad_heads(v, sk_pad).transpose(2, 3).contiguous().to(dev)
+    out = torch.empty((b * sq, h * 64), dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_attention_bf16(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, h, kvh, sq, sk, sq_pad, sk_pad,
+                                      _hip.stream()))
+    assert_close(f"attention {b}x{h}x{sq}x{sk}", out.view(b, sq, h * 64), want, 5e-3)
+    exact = odit._merge(odit.attention_core(q.float(), k.float(), v.float()))
+    assert rel_l2(out.view(b, sq, h * 64), exact) < 1e-2
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_qkv_rope(dev, variant):
+    from oracle import dit as odit
+    _hip, lib = _lib()
+    b, s, d = 2, 197, 256
+    h = d // 64
+    s_pad = 256
+    a = _rand((b * s, d), 15).to(torch.bfloat16)
+    w = (_rand((3 * d, d), 16) * 0.1).to(torch.bfloat16)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    qkv = (a.float() @ w.float().T).view(b, s, 3 * d)
+    q, k, v = (odit._heads(t, h) for t in qkv.chunk(3, dim=-1))
+    freqs = odit.rotary_freqs(inv_freq, s)
+    q, k = odit.apply_rotary(q, freqs), odit.apply_rotary(k, freqs)
+    ad, wd, fd = a.to(dev), w.to(dev), inv_freq.to(dev)
+    qd = torch.full((b, h, s_pad, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    kd = torch.full_like(qd, float("nan"))
+    vtd = torch.full((b, h, 64, s_pad), float("nan"), dtype=torch.bfloat16, device=dev)
+    scratch = torch.empty((2 * s * 16,), dtype=torch.float32, device=dev)
+    _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd),
+                                     _hip.ptr(scratch), b, s, s_pad, d, variant, _hip.stream()))
+    assert_close("rope q", qd[:, :, :s], q, 4e-3)
+    assert_close("rope k", kd[:, :, :s], k, 4e-3)
+    assert_close("v^T", vtd[:, :, :, :s], v.transpose(2, 3), 4e-3)
+    assert (qd[:, :, s:] == 0).all() and (vtd[:, :, :, s:] == 0).all(), "pads must be zero"
+
+
+def test_snake_vae_int16(dev):
+    from oracle import oobleck as oob
+    _hip, lib = _lib()
+    x = _rand((2, 5, 333), 17, 2.0)
+    al, be = _rand((5,), 18, 0.3), _rand((5,), 19, 0.3)
+    want = oob.snake_beta(x, al, be)
+    xd, ad, bd = x.to(dev), al.to(dev), be.to(dev)
+    y = torch.empty_like(xd)
+    _hip.check(lib.sat_snake_beta(_hip.ptr(xd), _hip.ptr(ad), _hip.ptr(bd), _hip.ptr(y), 2, 5, 333, _hip.stream()))
+    assert_close("snake", y, want, 1e-5)
+
+    ms = _rand((2, 8, 50), 20)
+    nz = _rand((2, 4, 50), 21)
+    want = oob.vae_sample(ms, nz)
+    z = torch.empty((2, 4, 50), device=dev)
+    _hip.check(lib.sat_vae_sample(_hip.ptr(ms.to(dev)), _hip.ptr(nz.to(dev)), _hip.ptr(z), 2, 4, 50, _hip.stream()))
+    assert_close("vae_sample", z, want, 1e-6)
+
+    from stable_audio_tools.utils.audio_utils import float_to_int16_audio
+    for scale in (0.3, 2.5):
+        a = _rand((2, 4099), 22, scale)
+        for maximize in (False, True):
+            div = a.abs().max().item()
+            if not maximize:
+                div = max(div, 1.0)
+            want = a.div(div).mul(32767).to(torch.int16)
+            got = float_to_int16_audio(a.to(dev), maximize=maximize)
+            assert got.dtype == torch.int16 and got.device.type == "cpu"
+            assert (got.int() - want.int()).abs().max().item() <= 1, "int16 quantisation differs by more than 1 LSB"
+            assert (got != want).float().mean().item() < 1e-3
+
+
+def test_cfg_combine_and_sampler_update(dev):
+    from oracle import sampler as osamp
+    _hip, lib = _lib()
+    b, c, t = 2, 8, 77
+    mo = _rand((2 * b, c, t), 23)
+    cond, uncond = mo[:b], mo[b:]
+    for scale_phi in (0.0, 0.6):
+        cfg = uncond + (cond - uncond) * 7.0
+        if scale_phi:
+            cfg = scale_phi * (cfg * (cond.std(dim=1, keepdim=True) / cfg.std(dim=1, keepdim=True))) + (1 - scale_phi) * cfg
+        out = torch.empty((b, c, t), device=dev)
+        _hip.check(lib.sat_cfg_combine(_hip.ptr(mo.to(dev)), _hip.ptr(out), b, c, t, 7.0, scale_phi, _hip.stream()))
+        assert_close(f"cfg combine phi={scale_phi}", out, cfg, 1e-5)
+
+    # the fused (a,b,c1,c2,cn) update must reproduce the multistep form of the oracle sampler on a linear denoiser
+    from stable_audio_tools.inference.sampling import dpmpp3m_coefficients, get_sigmas_polyexponential
+    steps = 12
+    sig = get_sigmas_polyexponential(steps, 0.3, 500.0, 1.0)
+    assert torch.allclose(torch.tensor(sig), osamp.get_sigmas_polyexponential(steps, 0.3, 500.0, 1.0))
+    coeffs = dpmpp3m_coefficients(sig)
+    x0 = _rand((b, c, t), 24) * sig[0]
+    target = _rand((b, c, t), 25)
+    noises = [_rand((b, c, t), 100 + i) for i in range(steps)]
+
+    def den(x, sigma):   # a smooth, sigma-dependent "denoiser"
+        s = sigma.view(-1, 1, 1)
+        return target + (x - target) / (1 + s * s) + 0.1 * torch.tanh(x / (1 + s))
+
+    want = osamp.sample_dpmpp_3m_sde(den, x0.clone(), torch.tensor(sig), lambda i, s, sn: noises[i])
+    x = x0.clone().to(dev)
+    d, d1, d2 = (torch.empty_like(x) for _ in range(3))
+    have = 0
+    for i in range(steps):
+        d.copy_(den(x.cpu(), torch.full((b,), sig[i])).to(dev))
+        a_, b_, c1, c2, cn = coeffs[i]
+        nz = noises[i].to(dev) if cn != 0 else None
+        _hip.check(lib.sat_dpmpp3m_update(_hip.ptr(x), _hip.ptr(d), _hip.ptr(d1) if have >= 1 else None,
+                                          _hip.ptr(d2) if have >= 2 else None, _hip.ptr(nz), a_, b_, c1, c2, cn, x.numel(),
+                                          _hip.stream()))
+        d, d1, d2 = d2, d, d1
+        have = min(have + 1, 2)
+    assert_close("dpmpp3m trajectory", x, want, 2e-5)

@@ -1,0 +1,124 @@
+"""Developer probe for a GPU box: micro-benchmarks of the hot kernels at SA-Open shapes (all variants in ONE
+process, interleaved), one full-size DiT step and a full-size decode.  Not part of the product or the tests."""
+import ctypes
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "friendly-stable-audio-tools_amd"))
+import torch
+
+from stable_audio_tools import _hip
+
+dev = torch.device("cuda:0")
+lib = _hip.lib()
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters   # ms
+
+
+def section(name, fn):
+    print(f"==== {name}", flush=True)
+    try:
+        fn()
+    except Exception:
+        traceback.print_exc()
+    sys.stdout.flush()
+
+
+def gemm_bench():
+    shapes = [("ff_in(swiglu)", 2050, 12288, 1536), ("ff_out", 2050, 1536, 6144), ("qkv", 2050, 4608, 1536), ("proj", 2050, 1536, 1536),
+              ("ff_in B8", 16400, 12288, 1536), ("ff_out B8", 16400, 1536, 6144)]
+    for name, m, n, k in shapes:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        c = torch.zeros(m, n, device=dev)
+        for v in (1, 2, 3, 4):
+            if v in (3, 4) and n % 256:
+                continue
+            f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
+            ms = timeit(f)
+            print(f"gemm {name:14s} v{v} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
+        del a, w, c
+
+
+def attn_bench():
+    for name, b, h, kvh, sq, sk in [("self B1", 2, 24, 24, 1025, 1025), ("cross B1", 2, 24, 12, 1025, 130), ("self B8", 16, 24, 24, 1025, 1025),
+                                    ("self SA2", 2, 24, 24, 6145, 6145)]:
+        sqp, skp = (sq + 127) // 128 * 128, (sk + 63) // 64 * 64
+        q = torch.randn(b, h, sqp, 64, device=dev).to(torch.bfloat16)
+        k = torch.randn(b, kvh, skp, 64, device=dev).to(torch.bfloat16)
+        vt = torch.randn(b, kvh, 64, skp, device=dev).to(torch.bfloat16)
+        o = torch.empty(b * sq, h * 64, device=dev, dtype=torch.bfloat16)
+        f = lambda: _hip.check(lib.sat_attention_bf16(_hip.ptr(q), _hip.ptr(k), _hip.ptr(vt), _hip.ptr(o), b, h, kvh, sq, sk, sqp, skp, _hip.stream()))
+        ms = timeit(f)
+        print(f"attention {name:9s}: {ms*1e3:8.1f} us  {4.0*b*h*sq*sk*64/ms/1e9:8.1f} TFLOP/s", flush=True)
+
+
+def ln_bench():
+    m, d = 2050, 1536
+    x = torch.randn(m, d, device=dev)
+    g = torch.ones(d, device=dev)
+    bb = torch.zeros(d, device=dev)
+    y = torch.empty(m, d, device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: _hip.check(lib.sat_layernorm_bf16(_hip.ptr(x), _hip.ptr(g), _hip.ptr(bb), _hip.ptr(y), m, d, _hip.stream())), iters=50)
+    print(f"layernorm {m}x{d}: {ms*1e3:.1f} us  {(m*d*6)/ms/1e6:.1f} GB/s")
+
+
+def full_model():
+    import stable_audio_tools as S
+    from stable_audio_tools import model_configs as MC, synthetic
+    from stable_audio_tools.models import _init
+    t0 = time.time()
+    with _init.skip_init():
+        model = S.create_model_from_config(MC.stable_audio_open_1_0())
+    sd = synthetic.synth_state_dict(model.state_dict(), 0)
+    model.load_state_dict(sd)
+    del sd
+    model = model.to(dev).eval()
+    print(f"model built + synthetic weights in {time.time()-t0:.1f}s", flush=True)
+    dit = model.model.model
+    b = int(os.environ.get("PROBE_B", "1"))
+    c = torch.randn(b, 130, 768, device=dev)
+    g = torch.randn(b, 1536, device=dev)
+    x = torch.randn(b, 64, 1024, device=dev)
+    t0 = time.time()
+    dit.prepare_generation(c, g, 7.0)
+    torch.cuda.synchronize()
+    print(f"plan finalize + context: {time.time()-t0:.2f}s", flush=True)
+    out = torch.empty_like(x)
+    ms = timeit(lambda: dit.denoise(x, 3.0, cfg_scale=7.0, out=out), iters=10, warm=2)
+    print(f"DiT CFG step B={b}: {ms:.3f} ms  -> {4.544*b/ms:.1f} TFLOP/s effective; 100 steps = {ms/10:.2f} s", flush=True)
+    print("denoise finite:", torch.isfinite(out).all().item(), "std", out.std().item())
+    z = torch.randn(b, 64, 1024, device=dev)
+    dec = model.pretransform.model
+    ms = timeit(lambda: dec.decode(z[:1]), iters=3, warm=1)
+    print(f"Oobleck decode 1x1024 frames: {ms:.2f} ms -> {5.16/ms*1e3:.1f} TFLOP/s", flush=True)
+    a = dec.decode(z[:1])
+    print("decode finite:", torch.isfinite(a).all().item(), "std", a.std().item(), "mem GB", torch.cuda.max_memory_allocated() / 1e9)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "attn", "ln", "full"]
+    print(torch.cuda.get_device_name(0), flush=True)
+    if "gemm" in which:
+        section("gemm", gemm_bench)
+    if "attn" in which:
+        section("attention", attn_bench)
+    if "ln" in which:
+        section("layernorm", ln_bench)
+    if "full" in which:
+        section("full model", full_model)
