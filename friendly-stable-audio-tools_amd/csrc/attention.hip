@@ -58,13 +58,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         srow[i] = id >> 3;
         schk[i] = id & 7;
     }
-    uint4 rk[2], rv[2];
+    u32x4 rk[2], rv[2];
     auto gload = [&](int tile) {
         const int key0 = tile * KV_TILE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)(key0 + srow[i]) * 64 + schk[i] * 8);
-            rv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)srow[i] * Sk_pad + key0 + schk[i] * 8);
+            rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)(key0 + srow[i]) * 64 + schk[i] * 8);
+            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)srow[i] * Sk_pad + key0 + schk[i] * 8);
         }
     };
     auto lstore = [&](int stage) {
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         char* sv = sk + KV_TILE * 128;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<uint4*>(sk + lds_tile_off(srow[i], schk[i])) = rk[i];
+            *reinterpret_cast<u32x4*>(sk + lds_tile_off(srow[i], schk[i])) = rk[i];
             // keys 8c..8c+3 -> chunk 2*(c>>1), keys 8c+4..8c+7 -> chunk 2*(c>>1)+1, byte 8*(c&1)
             const int c = schk[i];
             const int c0 = (c >> 1) * 2;
-            *reinterpret_cast<uint2*>(sv + lds_tile_off(srow[i], c0) + 8 * (c & 1)) = make_uint2(rv[i].x, rv[i].y);
-            *reinterpret_cast<uint2*>(sv + lds_tile_off(srow[i], c0 + 1) + 8 * (c & 1)) = make_uint2(rv[i].z, rv[i].w);
+            *reinterpret_cast<u32x2*>(sv + lds_tile_off(srow[i], c0) + 8 * (c & 1)) = u32x2{rv[i][0], rv[i][1]};
+            *reinterpret_cast<u32x2*>(sv + lds_tile_off(srow[i], c0 + 1) + 8 * (c & 1)) = u32x2{rv[i][2], rv[i][3]};
         }
     };
 
@@ -94,9 +94,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     lstore(0);
     __syncthreads();
 
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    auto process = [&](int tile) {
         const int cur = tile & 1;
-        if (tile + 1 < n_tiles) gload(tile + 1);
         const char* sk = smem + cur * (2 * KV_TILE * 128);
         const char* sv = sk + KV_TILE * 128;
 
@@ -161,9 +160,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[kb][u], oacc[db], 0, 0, 0);
                 }
 
-        if (tile + 1 < n_tiles) lstore(cur ^ 1);
+    };
+    for (int tile = 0; tile < n_tiles - 1; ++tile) {
+        gload(tile + 1);
+        process(tile);
+        lstore((tile + 1) & 1);
         __syncthreads();
     }
+    process(n_tiles - 1);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;

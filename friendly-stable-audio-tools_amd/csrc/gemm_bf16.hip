@@ -86,31 +86,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[A_CH], rb[B_CH];
+    u32x4 ra[A_CH], rb[B_CH];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + kt * 64);
+        for (int i = 0; i < A_CH; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + kt * 64);
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + kt * 64);
+        for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + kt * 64);
     };
     auto lstore = [&](int stage) {
         char* sa = smem + stage * STAGE_BYTES;
         char* sb = sa + BM * 128;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(sa + lds_tile_off(a_row[i], a_chk[i])) = ra[i];
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(sa + lds_tile_off(a_row[i], a_chk[i])) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(sb + lds_tile_off(b_row[i], b_chk[i])) = rb[i];
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(sb + lds_tile_off(b_row[i], b_chk[i])) = rb[i];
     };
 
-    const int nk = K / 64;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const char* sa = smem + cur * STAGE_BYTES;
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE_BYTES;
         const char* sb = sa + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -127,9 +120,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+    };
+
+    // register-staged double buffer, one barrier per K-tile; the last tile is peeled so that the
+    // staging registers are written/read unconditionally (keeps them out of scratch)
+    const int nk = K / 64;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        gload(kt + 1);
+        compute(kt & 1);
+        lstore((kt + 1) & 1);
         __syncthreads();
     }
+    compute((nk - 1) & 1);
 
     // ------------------------------------------------------------------ epilogue
     // acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31   (guide section 3)
@@ -142,21 +147,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
         float bia[NI];
 #pragma unroll
         for (int j = 0; j < NI; ++j) bia[j] = g.bias ? g.bias[nw + j * 32 + l31] : 0.f;
+        const bool accum = g.accumulate != 0;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+            // residual reads are issued as one batch per 32-row block (32 loads in flight), then added
+            float old[16][NI];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    old[r][j] = (accum && m < M) ? C[(size_t)m * ldc + nw + j * 32 + l31] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m < M) {
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        size_t o = (size_t)m * ldc + nw + j * 32 + l31;
-                        float v = acc[i][j][r] + bia[j];
-                        if (g.accumulate) v += C[o];
-                        C[o] = v;
-                    }
+                    for (int j = 0; j < NI; ++j) C[(size_t)m * ldc + nw + j * 32 + l31] = acc[i][j][r] + bia[j] + old[r][j];
                 }
             }
+        }
     } else if constexpr (EPI == EPI_SWIGLU) {
         bf16_t* __restrict__ H = g.H;
         const int ldh = N >> 1;

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_kernel(ConvArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[A_CH], rb[B_CH];
+    u32x4 ra[A_CH], rb[B_CH];
     auto gload = [&](int kt) {
         const int tap = kt / cpt;
         const int ci0 = (kt - tap * cpt) << 6;
@@ -116,30 +116,25 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_kernel(ConvArgs g) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             int r = a_m[i] + off;
-            if (r >= 0 && r < Tin)
-                ra[i] = *reinterpret_cast<const uint4*>(inb + (size_t)r * Cin + ci0 + a_chk[i] * 8);
-            else
-                ra[i] = make_uint4(0u, 0u, 0u, 0u);
+            const bool ok = r >= 0 && r < Tin;
+            r = ok ? r : 0;
+            u32x4 v = *reinterpret_cast<const u32x4*>(inb + (size_t)r * Cin + ci0 + a_chk[i] * 8);
+            ra[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
         const bf16_t* wt = g.W + ((size_t)tap * g.N + n0) * Cin + ci0;
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const uint4*>(wt + (size_t)b_row[i] * Cin + b_chk[i] * 8);
+        for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(wt + (size_t)b_row[i] * Cin + b_chk[i] * 8);
     };
     auto lstore = [&](int stage) {
         char* sa = smem + stage * STAGE_BYTES;
         char* sb = sa + BM * 128;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(sa + lds_tile_off(a_row[i], a_chk[i])) = ra[i];
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(sa + lds_tile_off(a_row[i], a_chk[i])) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(sb + lds_tile_off(b_row[i], b_chk[i])) = rb[i];
+        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(sb + lds_tile_off(b_row[i], b_chk[i])) = rb[i];
     };
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+    auto compute = [&](int cur) {
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -157,9 +152,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_kernel(ConvArgs g) {
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        gload(kt + 1);
+        compute(kt & 1);
+        lstore((kt + 1) & 1);
         __syncthreads();
     }
+    compute((nk - 1) & 1);
 
     // ---- epilogue.  acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31
     const int mw = m0 + wm * TM;

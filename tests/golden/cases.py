@@ -1,0 +1,48 @@
+"""Seed-defined parity cases shared by make_golden.py (reference side, build container only) and the tests
+(oracle / HIP side).  Weights and inputs are regenerated from (seed, name) by
+``stable_audio_tools.synthetic`` -- only the reference OUTPUTS are stored in tests/golden/*.npz."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "friendly-stable-audio-tools_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+from stable_audio_tools import model_configs as MC  # noqa: E402
+from stable_audio_tools import synthetic  # noqa: E402
+
+GOLDEN_DIR = HERE
+
+# reduced DiT used by the op-level goldens
+SMALL_DIT = dict(io_channels=64, embed_dim=256, depth=3, num_heads=4, cond_token_dim=128, global_cond_dim=96,
+                 project_cond_tokens=False, transformer_type="continuous_transformer")
+FULL_DIT = dict(io_channels=64, embed_dim=1536, depth=24, num_heads=24, cond_token_dim=768, global_cond_dim=1536,
+                project_cond_tokens=False, transformer_type="continuous_transformer")
+SMALL_VAE = dict(channels=16, c_mults=[1, 2, 4, 8, 16], strides=[2, 4, 4, 8, 8])
+FULL_VAE = dict(channels=128, c_mults=[1, 2, 4, 8, 16], strides=[2, 4, 4, 8, 8])
+
+
+def dit_inputs(b, t_len, cond_dim, global_dim, seed, lc=130):
+    x = synthetic.synth_input("x", (b, 64, t_len), seed)
+    c = synthetic.synth_input("c", (b, lc, cond_dim), seed + 1)
+    g = synthetic.synth_input("g", (b, global_dim), seed + 2)
+    t = (torch.arange(b, dtype=torch.float32) + 1) / (b + 1)
+    return x, t, c, g
+
+
+def vae_kwargs(v, decoder):
+    if decoder:
+        return dict(out_channels=2, channels=v["channels"], c_mults=v["c_mults"], strides=v["strides"], latent_dim=64, use_snake=True,
+                    final_tanh=False)
+    return dict(in_channels=2, channels=v["channels"], c_mults=v["c_mults"], strides=v["strides"], latent_dim=128, use_snake=True)
+
+
+def load(name):
+    import numpy as np
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    with np.load(path) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}

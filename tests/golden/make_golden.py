@@ -1,0 +1,192 @@
+"""Generates tests/golden/*.npz by running the REFERENCE (/root/reference, imported with the
+placeholder modules of _ref_import.py) on seed-defined weights and inputs.
+
+Runs only in the build container (the reference does not travel).  Usage:
+    python tests/golden/make_golden.py [ops] [small] [vae] [full] [full_long] [host]
+Stored: reference OUTPUTS only (fp32 .npz); weights/inputs are regenerated from seeds by
+``stable_audio_tools.synthetic`` (see cases.py).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _ref_import as R  # noqa: E402
+import cases  # noqa: E402
+from stable_audio_tools import synthetic  # noqa: E402
+
+R.import_reference()
+rdit = R.ref("models.dit")
+rtr = R.ref("models.transformer")
+rae = R.ref("models.autoencoders")
+rblocks = R.ref("models.blocks")
+rbott = R.ref("models.bottleneck")
+rcond = R.ref("models.conditioners")
+rdiff = R.ref("models.diffusion")
+raudio = R.ref("utils.audio_utils")
+rgen = R.ref("inference.generation")
+
+
+def save(name, **arrays):
+    path = os.path.join(cases.GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in arrays.items()})
+    print(f"wrote {path}: {os.path.getsize(path)/1024:.0f} KiB  " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in arrays.items()))
+
+
+def load_synth(module, seed):
+    sd = synthetic.synth_state_dict(module.state_dict(), seed)
+    module.load_state_dict(sd)
+    return module.eval()
+
+
+@torch.no_grad()
+def gen_ops():
+    """Per-op outputs of the reference's own modules inside the reduced DiT / VAE."""
+    m = load_synth(rdit.DiffusionTransformer(**cases.SMALL_DIT), 0)
+    blk = m.transformer.layers[1]
+    x = synthetic.synth_input("h", (2, 77, 256), 100)
+    ctx = synthetic.synth_input("ctx", (2, 130, 128), 101)
+    freqs = m.transformer.rotary_pos_emb.forward_from_seq_len(77)
+    out = {}
+    out["layernorm"] = blk.pre_norm(x)
+    q = synthetic.synth_input("q", (2, 4, 77, 64), 102)
+    out["rope_freqs"] = freqs[0]
+    out["rope_q"] = rtr.apply_rotary_pos_emb(q, freqs[0])
+    out["self_attn"] = blk.self_attn(x, rotary_pos_emb=freqs)
+    out["cross_attn"] = blk.cross_attn(x, context=ctx)
+    out["ff"] = blk.ff(x)
+    out["block"] = blk(x, context=ctx, rotary_pos_emb=freqs)
+    t = torch.tensor([0.13, 0.77])
+    out["timestep_embed"] = m.to_timestep_embed(m.timestep_features(t[:, None]))
+    nc = load_synth(rcond.NumberConditioner(768, min_val=0, max_val=512), 1)
+    emb, mask = nc([0.0, 47.5, 600.0, -3.0])
+    out["number_cond"] = emb
+    out["number_mask"] = mask
+    # codec ops
+    sn = load_synth(rblocks.SnakeBeta(16), 2)
+    xs = synthetic.synth_input("snake_x", (2, 16, 50), 103, 2.0)
+    out["snake"] = sn(xs)
+    for dil in (1, 3, 9):
+        ru = load_synth(rae.ResidualUnit(16, 16, dil, use_snake=True), 3 + dil)
+        out[f"resunit_d{dil}"] = ru(synthetic.synth_input("ru_x", (2, 16, 64), 104))
+    for s in (2, 4, 8):
+        db = load_synth(rae.DecoderBlock(32, 16, s, use_snake=True), 20 + s)
+        out[f"decblock_s{s}"] = db(synthetic.synth_input("db_x", (1, 32, 11), 105))
+        eb = load_synth(rae.EncoderBlock(16, 32, s, use_snake=True), 30 + s)
+        out[f"encblock_s{s}"] = eb(synthetic.synth_input("eb_x", (1, 16, 16 * s), 106))
+    ms = synthetic.synth_input("ms", (2, 8, 10), 107)
+    torch.manual_seed(1234)
+    out["vae_sample_seed1234"] = rbott.vae_sample(*ms.chunk(2, dim=1))[0]
+    a = synthetic.synth_input("i16", (2, 4099), 108, 0.7)
+    out["int16_quiet"] = raudio.float_to_int16_audio(a).float()
+    out["int16_loud"] = raudio.float_to_int16_audio(a * 4).float()
+    out["int16_max"] = raudio.float_to_int16_audio(a, maximize=True).float()
+    save("ops", **out)
+
+
+@torch.no_grad()
+def gen_small():
+    """Reduced DiT: DiffusionTransformer.forward with CFG 1 / 7 / 7+scale_phi."""
+    m = load_synth(rdit.DiffusionTransformer(**cases.SMALL_DIT), 0)
+    out = {}
+    for t_len in (64, 77):
+        x, t, c, g = cases.dit_inputs(2, t_len, 128, 96, 1)
+        out[f"cfg1_T{t_len}"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=1.0)
+        out[f"cfg7_T{t_len}"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=7.0, cross_attn_cond_mask=torch.ones(2, 130))
+    x, t, c, g = cases.dit_inputs(2, 64, 128, 96, 1)
+    out["cfg7_phi04_T64"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=7.0, scale_phi=0.4)
+    out["zero_ctx_T64"] = m(x, t, cross_attn_cond=torch.zeros_like(c), global_embed=g, cfg_scale=1.0)
+    # DiTWrapper path incl. the 0.5 scaling convention is exercised through get_conditioning_inputs below
+    save("dit_small", **out)
+
+
+@torch.no_grad()
+def gen_vae():
+    out = {}
+    dec = load_synth(rae.OobleckDecoder(**cases.vae_kwargs(cases.SMALL_VAE, True)), 5)
+    enc = load_synth(rae.OobleckEncoder(**cases.vae_kwargs(cases.SMALL_VAE, False)), 6)
+    z = synthetic.synth_input("z", (2, 64, 9), 7)
+    a = synthetic.synth_input("a", (2, 2, 2048 * 5), 8, 0.3)
+    out["small_decode"] = dec(z)
+    out["small_encode"] = enc(a)
+    # BASELINE config 1: full-size decoder, z[1,64,43] -> [1,2,88064]
+    t0 = time.time()
+    decf = load_synth(rae.OobleckDecoder(**cases.vae_kwargs(cases.FULL_VAE, True)), 0)
+    zf = synthetic.synth_input("z_full", (1, 64, 43), 1)
+    out["full_decode_T43"] = decf(zf)
+    encf = load_synth(rae.OobleckEncoder(**cases.vae_kwargs(cases.FULL_VAE, False)), 0)
+    af = synthetic.synth_input("a_full", (1, 2, 2048 * 16), 2, 0.3)
+    out["full_encode_T16"] = encf(af)
+    print(f"full-size codec goldens in {time.time()-t0:.1f}s")
+    save("vae", **out)
+    # chunked reconstruct / encode / decode of AudioAutoencoder with the reference's own RNG order
+    ae = rae.AudioAutoencoder(enc, dec, latent_dim=64, downsampling_ratio=2048, sample_rate=44100, io_channels=2,
+                              bottleneck=rbott.VAEBottleneck())
+    sig = synthetic.synth_input("sig", (1, 2, 2048 * 11 + 700), 9, 0.3)[..., : 2048 * 11]
+    out2 = {}
+    torch.manual_seed(77)
+    out2["reconstruct_chunked"] = ae.reconstruct_audio(sig, chunked=True, chunk_size=4, overlap=1, max_batch_size=3)
+    torch.manual_seed(78)
+    out2["encode_chunked"] = ae.encode_audio(sig, chunked=True, chunk_size=4, overlap=1, max_batch_size=2)
+    zz = synthetic.synth_input("zz", (1, 64, 11), 10)
+    out2["decode_chunked"] = ae.decode_audio(zz, chunked=True, chunk_size=4, overlap=1, max_batch_size=2)
+    out2["decode_unchunked"] = ae.decode_audio(zz, chunked=False)
+    save("vae_chunked", **out2)
+
+
+@torch.no_grad()
+def gen_full(long=False):
+    """Full-size SA-Open DiT (1.06 B parameters, seed 0): one _forward without CFG (CFG just doubles the batch)."""
+    t0 = time.time()
+    m = load_synth(rdit.DiffusionTransformer(**cases.FULL_DIT), 0)
+    print(f"full DiT built in {time.time()-t0:.1f}s")
+    t_len = 6144 if long else 1024
+    x, t, c, g = cases.dit_inputs(1, t_len, 768, 1536, 1)
+    t0 = time.time()
+    y = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=1.0)
+    print(f"full forward T={t_len} in {time.time()-t0:.1f}s, out std {y.std():.4f}")
+    save("dit_full_T%d" % t_len, out=y)
+
+
+@torch.no_grad()
+def gen_host():
+    """Host-side bookkeeping of the reference: get_conditioning_inputs, prepare_audio, build_mask."""
+    import json
+    cfg = json.load(open(os.path.join(R.REFERENCE_ROOT, "stable_audio_tools/configs/model_configs/txt2audio/stable_audio_open_1_0.json")))
+    cfg["model"]["conditioning"]["configs"] = [c for c in cfg["model"]["conditioning"]["configs"] if c["type"] != "t5"]
+    cfg["model"]["diffusion"]["config"].update(depth=1, embed_dim=128, num_heads=2)
+    cfg["model"]["pretransform"]["config"]["encoder"]["config"]["channels"] = 8
+    cfg["model"]["pretransform"]["config"]["decoder"]["config"]["channels"] = 8
+    model = R.ref("models.factory").create_model_from_config(cfg)
+    sd = synthetic.synth_state_dict(model.state_dict(), 4)
+    model.load_state_dict(sd)
+    cond = model.conditioner([{"seconds_start": 0, "seconds_total": 47}, {"seconds_start": 3.5, "seconds_total": 700}])
+    cond["prompt"] = [synthetic.synth_input("prompt", (2, 128, 768), 5), torch.ones(2, 128)]
+    cond = {k: cond[k] for k in ("prompt", "seconds_start", "seconds_total")}
+    ci = model.get_conditioning_inputs(cond)
+    out = {"cross_attn_cond": ci["cross_attn_cond"], "cross_attn_mask": ci["cross_attn_mask"], "global_cond": ci["global_cond"]}
+    pa = R.ref("inference.utils").prepare_audio
+    a = synthetic.synth_input("pa", (1, 1000), 6)
+    out["prepare_mono_to_stereo_pad"] = pa(a, 44100, 44100, 1500, 2, "cpu")
+    out["prepare_crop"] = pa(synthetic.synth_input("pa3", (3, 1000), 7), 44100, 44100, 600, 2, "cpu")
+    save("host", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "small", "vae", "host", "full"]
+    torch.set_num_threads(os.cpu_count())
+    if "ops" in which:
+        gen_ops()
+    if "small" in which:
+        gen_small()
+    if "vae" in which:
+        gen_vae()
+    if "host" in which:
+        gen_host()
+    if "full" in which:
+        gen_full(False)
+    if "full_long" in which:
+        gen_full(True)

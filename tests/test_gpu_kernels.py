@@ -155,7 +155,8 @@ def test_snake_vae_int16(dev):
     nz = _rand((2, 4, 50), 21)
     want = oob.vae_sample(ms, nz)
     z = torch.empty((2, 4, 50), device=dev)
-    _hip.check(lib.sat_vae_sample(_hip.ptr(ms.to(dev)), _hip.ptr(nz.to(dev)), _hip.ptr(z), 2, 4, 50, _hip.stream()))
+    msd, nzd = ms.to(dev), nz.to(dev)     # keep the device tensors alive across the call
+    _hip.check(lib.sat_vae_sample(_hip.ptr(msd), _hip.ptr(nzd), _hip.ptr(z), 2, 4, 50, _hip.stream()))
     assert_close("vae_sample", z, want, 1e-6)
 
     from stable_audio_tools.utils.audio_utils import float_to_int16_audio
@@ -183,7 +184,8 @@ def test_cfg_combine_and_sampler_update(dev):
         if scale_phi:
             cfg = scale_phi * (cfg * (cond.std(dim=1, keepdim=True) / cfg.std(dim=1, keepdim=True))) + (1 - scale_phi) * cfg
         out = torch.empty((b, c, t), device=dev)
-        _hip.check(lib.sat_cfg_combine(_hip.ptr(mo.to(dev)), _hip.ptr(out), b, c, t, 7.0, scale_phi, _hip.stream()))
+        mod = mo.to(dev)
+        _hip.check(lib.sat_cfg_combine(_hip.ptr(mod), _hip.ptr(out), b, c, t, 7.0, scale_phi, _hip.stream()))
         assert_close(f"cfg combine phi={scale_phi}", out, cfg, 1e-5)
 
     # the fused (a,b,c1,c2,cn) update must reproduce the multistep form of the oracle sampler on a linear denoiser

@@ -2,8 +2,10 @@
 same synthetic state dict and seeded inputs, at sizes the oracle finishes in seconds.
 
 Tolerances (bf16 GEMM operands, fp32 accumulate / residual / LN / softmax):
-  * vs the MATCHED-ROUNDING oracle (same bf16 rounding points): rel-L2 <= 3e-3 -- what remains is
-    accumulation order, P rounded against a running instead of the final max, and __sinf;
+  * vs the MATCHED-ROUNDING oracle (same bf16 rounding points): rel-L2 <= 3e-3 for the DiT -- what
+    remains is accumulation order and P rounded against a running instead of the final max; <= 1e-2
+    for the ~35-conv-deep codec, where a 1-ulp fp32 difference before a bf16 store flips the stored
+    value (2^-8 relative) for a small fraction of elements at every layer, plus __sinf;
   * vs the pure-fp32 oracle (= the reference's CPU path): reported, gated loosely (<= 3e-2 without
     CFG, <= 1.5e-1 at cfg_scale 7 -- CFG extrapolation amplifies rounding noise ~7x; SURVEY.md
     section 7 measured 1.5e-2 / 1.05e-1 for a bf16 autocast of the REFERENCE itself).
@@ -114,7 +116,7 @@ def test_oobleck_decode(dev, small_vae, b, t_len):
     want_m = oob.oobleck_decoder(dsd, z, strides=strides, rnd=bf16_round)
     assert got.shape == want_f.shape
     e_f = assert_close("decode vs fp32 oracle", got, want_f, 3e-2)
-    e_m = assert_close("decode vs matched oracle", got, want_m, 5e-3)
+    e_m = assert_close("decode vs matched oracle", got, want_m, 1e-2)
     print(f"\n[decode b={b} T={t_len}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
 
 
@@ -131,7 +133,7 @@ def test_oobleck_encode_and_vae(dev, small_vae, b, t_len):
     want_f = oob.oobleck_encoder(esd, audio, strides=strides)
     want_m = oob.oobleck_encoder(esd, audio, strides=strides, rnd=bf16_round)
     e_f = assert_close("encode vs fp32 oracle", got, want_f, 3e-2)
-    e_m = assert_close("encode vs matched oracle", got, want_m, 5e-3)
+    e_m = assert_close("encode vs matched oracle", got, want_m, 1e-2)
     print(f"\n[encode b={b} T={t_len}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
     noise = synthetic.synth_input("vn", (b, 64, t_len), 13)
     z = model.encode(audio.to(dev), noise=noise.to(dev))
