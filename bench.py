@@ -1,0 +1,198 @@
+"""Headline benchmark (BASELINE.json): audio-seconds/sec @ 44.1 kHz stereo, 100-step DPM-Solver++(3M) SDE,
+Stable-Audio-Open-1.0 shape, synthetic random-init weights + random T5 embeddings.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full ``generate_diffusion_cond`` call on this rank's prompts: conditioning -> 100 sampler steps
+(each = one CFG-batched DiT evaluation + the fused DPM++ update) -> Oobleck decode -> int16 quantisation, and for
+N > 1 one RCCL all-gather of the int16 audio.  Prompts are sharded rank-strided (reference generate.py:119-120),
+one full model replica per GPU, no collective on the data path except that final gather -> weak scaling.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "friendly-stable-audio-tools_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+SAMPLE_SIZE = 2097152
+SAMPLE_RATE = 44100
+SAMPLER = dict(sampler_type="dpmpp-3m-sde", sigma_min=0.3, sigma_max=500)
+CFG_SCALE = 7.0
+DIT_STEPS = 100
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(dev):
+    import stable_audio_tools as S
+    from stable_audio_tools import model_configs as MC, synthetic
+    from stable_audio_tools.models import _init
+    with _init.skip_init():
+        model = S.create_model_from_config(MC.stable_audio_open_1_0())
+    sd = synthetic.synth_state_dict(model.state_dict(), 0)
+    model.load_state_dict(sd)
+    return model.to(dev).eval(), sd
+
+
+def conditioning(model, prompt_ids, dev):
+    """Random 'T5' embeddings (seeded per prompt id) + the model's own number conditioners."""
+    from stable_audio_tools import synthetic
+    cond = model.conditioner([{"seconds_start": 0, "seconds_total": 47} for _ in prompt_ids])
+    emb = torch.stack([synthetic.synth_input(f"prompt{i}", (128, 768), 2) for i in prompt_ids]).to(dev)
+    cond["prompt"] = (emb, torch.ones(len(prompt_ids), 128, device=dev))
+    return {k: cond[k] for k in ("prompt", "seconds_start", "seconds_total")}
+
+
+def one_generation(model, cond, seed, dev, world):
+    from stable_audio_tools import _hip
+    from stable_audio_tools.inference.generation import generate_diffusion_cond
+    audio = generate_diffusion_cond(model, steps=DIT_STEPS, cfg_scale=CFG_SCALE, conditioning_tensors=cond, sample_size=SAMPLE_SIZE,
+                                    seed=seed, device=str(dev), **SAMPLER)
+    # per-item int16 quantisation on the device (reference generate.py:142-151 / audio_utils.py:21-26)
+    b, c, n = audio.shape
+    out = torch.empty((b, c, n), dtype=torch.int16, device=dev)
+    scratch = torch.empty(1, dtype=torch.int32, device=dev)
+    for i in range(b):
+        _hip.check(_hip.lib().sat_float_to_int16(_hip.ptr(audio[i]), _hip.ptr(out[i]), c * n, 0, _hip.ptr(scratch), _hip.stream()))
+    if world > 1:
+        from stable_audio_tools.inference.distributed import gather_sharded
+        return gather_sharded(out, world * b)          # the single RCCL collective (xGMI)
+    return out
+
+
+def cpu_baseline(sd):
+    """The oracle (torch fp32 restatement == the reference's CPU path) on the host cores, bounded sample:
+    ONE CFG denoiser evaluation at full SA-Open size + decode of 43 latent frames, extrapolated to
+    100 steps + 1024 frames."""
+    from oracle import dit as odit, oobleck as oob
+    from stable_audio_tools import synthetic
+    # host threads: the cores this process may run on, capped at 16 -- torch's CPU GEMMs stop scaling (and on a
+    # cgroup-limited box collapse) far below the 256 logical CPUs os.cpu_count() reports on the GPU host
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
+    torch.set_num_threads(cores)
+    dsd = {k[len("model.model."):]: v for k, v in sd.items() if k.startswith("model.model.")}
+    vsd = {k[len("pretransform.model.decoder."):]: v for k, v in sd.items() if k.startswith("pretransform.model.decoder.")}
+    x = synthetic.synth_input("x", (1, 64, 1024), 1)
+    c = synthetic.synth_input("c", (1, 130, 768), 2)
+    g = synthetic.synth_input("g", (1, 1536), 3)
+    t = torch.tensor([0.5])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        odit.dit_forward(dsd, x, t, c, g, 24, 24, cfg_scale=CFG_SCALE)
+        t_step = time.perf_counter() - t0
+        z = synthetic.synth_input("z", (1, 64, 43), 4)
+        oob.oobleck_decoder(vsd, z)      # warm-up
+        t0 = time.perf_counter()
+        oob.oobleck_decoder(vsd, z)
+        t_dec = time.perf_counter() - t0
+    total = DIT_STEPS * t_step + t_dec * (1024 / 43)
+    return {"value": (SAMPLE_SIZE / SAMPLE_RATE) / total, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 CFG DiT evaluation at full size ({t_step:.2f} s) x100 + Oobleck decode of 43 frames ({t_dec:.2f} s) x(1024/43), extrapolated"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="prompts per GPU (BASELINE config 2: 1; config 3: 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    model, sd = build_model(dev)
+    if rank != 0 or args.no_cpu_baseline:
+        sd = None
+    # rank-strided prompt sharding, as the reference's generate.py:119-120
+    prompt_ids = list(range(world * args.batch))[rank::world]
+    cond = conditioning(model, prompt_ids, dev)
+    dit = model.model.model
+
+    from stable_audio_tools import _hip
+    lib = _hip.lib()
+    for i in range(args.warmup):
+        one_generation(model, cond, 1000 + i, dev, world)
+    _hip.check(lib.sat_dit_profile(dit._plan, 1))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_generation(model, cond, 2000 + i, dev, world)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: FFN-in SwiGLU GEMM, timed live with HIP events on the launch stream (one layer per forward)
+    tot = ctypes.c_double()
+    cnt = ctypes.c_int32()
+    m, n, k = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    _hip.check(lib.sat_dit_profile_read(dit._plan, ctypes.byref(tot), ctypes.byref(cnt), ctypes.byref(m), ctypes.byref(n), ctypes.byref(k)))
+    _hip.check(lib.sat_dit_profile(dit._plan, 0))
+
+    if rank == 0:
+        audio_seconds = world * args.batch * (SAMPLE_SIZE / SAMPLE_RATE) * args.steps
+        avg_ms = tot.value / max(cnt.value, 1)
+        flops = 2.0 * m.value * n.value * k.value          # algorithmic FLOPs of one launch (ff_in 38.69 GFLOP/seq/layer)
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_ffn_traffic.json")
+        if os.path.exists(tpath) and args.batch == 1:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-Open-1.0 shape",
+            "value": audio_seconds / elapsed,
+            "unit": "audio-seconds/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic (random-init weights of the SA-Open-1.0 architecture, random T5 embeddings)",
+            "config": {"workload": "Stable-Audio-Open-1.0 DiT shape (24 layers, D=1536, S=1025, CFG 7 -> 2 sequences/prompt) + Oobleck decode, "
+                                   f"{args.batch} prompt(s)/GPU x 47.55 s, 100 DPM-Solver++(3M) SDE steps", "prompts_per_gpu": args.batch,
+                       "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
+            "roofline": {"bound": "mfma", "kernel": f"FFN-in SwiGLU GEMM M={m.value} N={n.value} K={k.value} (bf16 MFMA, fp32 acc)", "achieved": achieved,
+                         "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "avg_launch_us": avg_ms * 1e3, "launches_timed": cnt.value},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

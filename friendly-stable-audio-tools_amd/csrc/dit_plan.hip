@@ -67,7 +67,13 @@ struct sat_dit_plan {
     float* ge = nullptr;            // [bf, D] projected global embedding
     bf16_t* kc = nullptr;           // [depth][bf, kvh, lcpad, 64]
     bf16_t* vct = nullptr;          // [depth][bf, kvh, 64, lcpad]
+    // optional HIP-event timing of the FFN-in (SwiGLU) GEMM of one layer per forward (sat_dit_profile)
+    bool prof_on = false;
+    int prof_n = 0;
+    std::vector<hipEvent_t> prof_ev;   // pairs
+    long long prof_m = 0, prof_nn = 0, prof_k = 0;
 };
+static const int kProfMaxPairs = 4096;
 
 namespace {
 
@@ -256,7 +262,23 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         SAT_TRY(sat_launch_layernorm(w.X, L.ff_g, L.ff_b, w.A, M, D, s));
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
+        const bool prof = p->prof_on && l == c.depth / 2 && p->prof_n < kProfMaxPairs;
+        if (prof) {
+            if ((int)p->prof_ev.size() < 2 * (p->prof_n + 1)) {
+                hipEvent_t e0, e1;
+                SAT_HIP(hipEventCreate(&e0));
+                SAT_HIP(hipEventCreate(&e1));
+                p->prof_ev.push_back(e0);
+                p->prof_ev.push_back(e1);
+            }
+            SAT_HIP(hipEventRecord(p->prof_ev[2 * p->prof_n], s));
+        }
         SAT_TRY(sat_launch_gemm(EPI_SWIGLU, g, s));
+        if (prof) {
+            SAT_HIP(hipEventRecord(p->prof_ev[2 * p->prof_n + 1], s));
+            p->prof_n++;
+            p->prof_m = g.M; p->prof_nn = g.N; p->prof_k = g.K;
+        }
         g = GemmArgs{};
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
@@ -298,6 +320,7 @@ extern "C" void sat_dit_plan_destroy(sat_dit_plan* p) {
     if (!p) return;
     if (p->arena) (void)hipFree(p->arena);
     if (p->ctx_buf) (void)hipFree(p->ctx_buf);
+    for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     delete p;
 }
 
@@ -434,6 +457,30 @@ extern "C" int sat_dit_denoise_cfg(sat_dit_plan* p, const float* x_dev, float si
     Workspace w = carve(p, bf, t_len, (char*)ws);
     SAT_TRY(run_forward(p, x_dev, b, c_in, nullptr, t, w.mo, bf, t_len, ws, ws_bytes, s));
     return glue_cfg_denoise(w.mo, x_dev, denoised_dev, b, p->cfg.io_channels, t_len, use_cfg, cfg_scale, scale_phi, c_out, c_skip, s);
+}
+
+extern "C" int sat_dit_profile(sat_dit_plan* p, int32_t enable) {
+    SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_profile: null plan");
+    p->prof_on = enable != 0;
+    p->prof_n = 0;
+    return 0;
+}
+
+extern "C" int sat_dit_profile_read(sat_dit_plan* p, double* total_ms, int32_t* launches, int64_t* m, int64_t* n, int64_t* k) {
+    SAT_CHECK_ARG(p && total_ms && launches, SAT_E_INVALID, "dit_profile_read: null argument");
+    double tot = 0.0;
+    for (int i = 0; i < p->prof_n; ++i) {
+        SAT_HIP(hipEventSynchronize(p->prof_ev[2 * i + 1]));
+        float ms = 0.f;
+        SAT_HIP(hipEventElapsedTime(&ms, p->prof_ev[2 * i], p->prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = p->prof_n;
+    if (m) *m = p->prof_m;
+    if (n) *n = p->prof_nn;
+    if (k) *k = p->prof_k;
+    return 0;
 }
 
 extern "C" int sat_cfg_combine(const float* model_out_dev, float* out_dev, int32_t b, int32_t c, int32_t t, float cfg_scale,

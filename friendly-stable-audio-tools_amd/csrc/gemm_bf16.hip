@@ -15,6 +15,96 @@
 
 namespace {
 
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
+                                              const int l31) {
+    const int M = g.M, N = g.N;
+    (void)N;
+    // acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31   (guide section 3)
+
+    if constexpr (EPI == EPI_F32) {
+        float* __restrict__ C = g.C;
+        const int ldc = g.ldc;
+        float bia[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bia[j] = g.bias ? g.bias[nw + j * 32 + l31] : 0.f;
+        const bool accum = g.accumulate != 0;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            // residual reads are issued as one batch per 32-row block (32 loads in flight), then added
+            float old[16][NI];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    old[r][j] = (accum && m < M) ? C[(size_t)m * ldc + nw + j * 32 + l31] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) C[(size_t)m * ldc + nw + j * 32 + l31] = acc[i][j][r] + bia[j] + old[r][j];
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        bf16_t* __restrict__ H = g.H;
+        const int ldh = N >> 1;
+        const float bv = g.bias ? g.bias[nw + l31] : 0.f;
+        const float bg = g.bias ? g.bias[nw + 32 + l31] : 0.f;
+        const int hc = (nw >> 1) + l31;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < M) {
+                    float v = acc[i][0][r] + bv;
+                    float gt = acc[i][1][r] + bg;
+                    H[(size_t)m * ldh + hc] = f32_to_bf16(v * silu_f(gt));
+                }
+            }
+    } else {   // EPI_HEADS
+        const HeadsEpi& he = g.heads;
+        const int hp = he.heads * 64;
+        const int part = nw / hp;
+        const int head = (nw - part * hp) >> 6;
+        const int kind = he.kind[part];
+        bf16_t* __restrict__ dst = he.out[part];
+        const int S = he.S, Spad = he.Spad;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const bool valid = m < M;
+                int mm = valid ? m : M - 1;
+                int b = mm / S;
+                int s = mm - b * S;
+                float v0 = acc[i][0][r], v1 = acc[i][1][r];
+                if (kind & 2) {   // wave-uniform
+                    float p = __shfl_xor(v0, 16, 64);
+                    int jf = l31 & 15;
+                    float cs = he.rope_cos[s * 16 + jf], sn = he.rope_sin[s * 16 + jf];
+                    v0 = (l31 < 16) ? (v0 * cs - p * sn) : (v0 * cs + p * sn);
+                }
+                if (valid) {
+                    if (kind & 1) {
+                        size_t base = ((size_t)(b * he.heads + head) * 64) * Spad + s;
+                        dst[base + (size_t)l31 * Spad] = f32_to_bf16(v0);
+                        dst[base + (size_t)(32 + l31) * Spad] = f32_to_bf16(v1);
+                    } else {
+                        size_t base = ((size_t)(b * he.heads + head) * Spad + s) * 64;
+                        dst[base + l31] = f32_to_bf16(v0);
+                        dst[base + 32 + l31] = f32_to_bf16(v1);
+                    }
+                }
+            }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
@@ -136,99 +226,131 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     }
     compute((nk - 1) & 1);
 
-    // ------------------------------------------------------------------ epilogue
-    // acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31   (guide section 3)
-    const int mw = m0 + wm * TM;
-    const int nw = n0 + wn * TN;
-
-    if constexpr (EPI == EPI_F32) {
-        float* __restrict__ C = g.C;
-        const int ldc = g.ldc;
-        float bia[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bia[j] = g.bias ? g.bias[nw + j * 32 + l31] : 0.f;
-        const bool accum = g.accumulate != 0;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            // residual reads are issued as one batch per 32-row block (32 loads in flight), then added
-            float old[16][NI];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    old[r][j] = (accum && m < M) ? C[(size_t)m * ldc + nw + j * 32 + l31] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < M) {
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) C[(size_t)m * ldc + nw + j * 32 + l31] = acc[i][j][r] + bia[j] + old[r][j];
-                }
-            }
-        }
-    } else if constexpr (EPI == EPI_SWIGLU) {
-        bf16_t* __restrict__ H = g.H;
-        const int ldh = N >> 1;
-        const float bv = g.bias ? g.bias[nw + l31] : 0.f;
-        const float bg = g.bias ? g.bias[nw + 32 + l31] : 0.f;
-        const int hc = (nw >> 1) + l31;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < M) {
-                    float v = acc[i][0][r] + bv;
-                    float gt = acc[i][1][r] + bg;
-                    H[(size_t)m * ldh + hc] = f32_to_bf16(v * silu_f(gt));
-                }
-            }
-    } else {   // EPI_HEADS
-        const HeadsEpi& he = g.heads;
-        const int hp = he.heads * 64;
-        const int part = nw / hp;
-        const int head = (nw - part * hp) >> 6;
-        const int kind = he.kind[part];
-        bf16_t* __restrict__ dst = he.out[part];
-        const int S = he.S, Spad = he.Spad;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const bool valid = m < M;
-                int mm = valid ? m : M - 1;
-                int b = mm / S;
-                int s = mm - b * S;
-                float v0 = acc[i][0][r], v1 = acc[i][1][r];
-                if (kind & 2) {   // wave-uniform
-                    float p = __shfl_xor(v0, 16, 64);
-                    int jf = l31 & 15;
-                    float cs = he.rope_cos[s * 16 + jf], sn = he.rope_sin[s * 16 + jf];
-                    v0 = (l31 < 16) ? (v0 * cs - p * sn) : (v0 * cs + p * sn);
-                }
-                if (valid) {
-                    if (kind & 1) {
-                        size_t base = ((size_t)(b * he.heads + head) * 64) * Spad + s;
-                        dst[base + (size_t)l31 * Spad] = f32_to_bf16(v0);
-                        dst[base + (size_t)(32 + l31) * Spad] = f32_to_bf16(v1);
-                    } else {
-                        size_t base = ((size_t)(b * he.heads + head) * Spad + s) * 64;
-                        dst[base + l31] = f32_to_bf16(v0);
-                        dst[base + 32 + l31] = f32_to_bf16(v1);
-                    }
-                }
-            }
-    }
+    gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS variant: tiles are staged with global_load_lds_dwordx4 (LDS-DMA, no VGPR round
+// trip, no ds_write pass).  The LDS image is the same XOR-swizzled one; because an LDS-DMA writes
+// wave-uniform base + lane*16, the swizzle is applied to the per-lane SOURCE address (guide
+// section 5.4 rule 21): lane l of the piece that covers rows 8p..8p+7 lands at row 8p + l/8,
+// position l%8, so it fetches logical chunk (l%8) ^ ((row>>1)&7) of that row.
+// ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM;
+    constexpr int TN = BN / WN;
+    static_assert(TN == 64, "wave tile is TM x 64");
+    constexpr int MI = TM / 32;
+    constexpr int NI = 2;
+    constexpr int A_CH = BM * 8 / NT;
+    constexpr int B_CH = BN * 8 / NT;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_n = N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    if (tiles_m <= tiles_n) {
+        tn = bid / tiles_m;
+        tm = bid - tn * tiles_m;
+    } else {
+        tm = bid / tiles_n;
+        tn = bid - tm * tiles_n;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    // per-lane source pointers (swizzle folded in); LDS destinations are wave-uniform
+    const bf16_t* a_ptr[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        int q = i * NT + tid;
+        int row = q >> 3, pos = q & 7;
+        int c = pos ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < M ? gm : M - 1;
+        a_ptr[i] = g.A + (size_t)gm * K + c * 8;
+    }
+    const bf16_t* b_ptr[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        int q = i * NT + tid;
+        int row = q >> 3, pos = q & 7;
+        int c = pos ^ ((row >> 1) & 7);
+        b_ptr[i] = g.W + (size_t)(n0 + row) * K + c * 8;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto stage_in = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE_BYTES;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = K / 64;
+    stage_in(0, 0);
+    __syncthreads();          // hipcc emits s_waitcnt vmcnt(0) in front of the barrier while an LDS-DMA is in flight
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        stage_in(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+
+    gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, bool GLDS = false>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
-    auto kern = gemm_kernel<BM, BN, WM, WN, EPI>;
+    auto kern = GLDS ? gemm_glds_kernel<BM, BN, WM, WN, EPI> : gemm_kernel<BM, BN, WM, WN, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -244,15 +366,22 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
     int v = a.variant;
-    if (v == 0) {   // default heuristic: big tiles only when they still fill the chip
-        long t256 = (long)cdiv(a.M, 256) * (a.N / 256 > 0 ? a.N / 256 : 1);
-        v = (a.N % 256 == 0 && t256 >= 512) ? 3 : 1;
+    if (v == 0) {
+        // measured on MI355X (profiles/r01_gemm_variants.txt): the direct-to-LDS 256x256 tile wins whenever it
+        // yields >= ~160 workgroups (FFN-in, QKV at B=1; everything at B>=4); below that the 128x128 tile fills
+        // more CUs (to_out / FFN-out at B=1: 204 tiles instead of 54).
+        long t256 = (long)cdiv(a.M, 256) * (a.N / 256);
+        v = (a.N % 256 == 0 && t256 >= 160) ? 7 : 5;
     }
     switch (v) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
         case 2: return launch_cfg<256, 128, 4, 2, EPI>(a, stream);
         case 3: return launch_cfg<256, 256, 2, 4, EPI>(a, stream);
         case 4: return launch_cfg<128, 256, 1, 4, EPI>(a, stream);
+        case 5: return launch_cfg<128, 128, 2, 2, EPI, true>(a, stream);
+        case 6: return launch_cfg<256, 128, 4, 2, EPI, true>(a, stream);
+        case 7: return launch_cfg<256, 256, 2, 4, EPI, true>(a, stream);
+        case 8: return launch_cfg<128, 256, 1, 4, EPI, true>(a, stream);
         default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
     }
 }

@@ -41,6 +41,9 @@ _SIGNATURES = {
     "sat_dit_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "sat_dit_denoise_cfg": (c_int32, [c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int32, c_int32, c_void_p,
                                       c_size_t, c_void_p]),
+    "sat_dit_profile": (c_int32, [c_void_p, c_int32]),
+    "sat_dit_profile_read": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64),
+                                       POINTER(c_int64)]),
     "sat_cfg_combine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "sat_dpmpp3m_update": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                      c_float, c_int64, c_void_p]),

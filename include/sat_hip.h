@@ -105,6 +105,13 @@ int sat_dit_denoise_cfg(sat_dit_plan* plan, const float* x_dev, float sigma, flo
                         float* denoised_dev, int32_t b, int32_t t_len,
                         void* workspace_dev, size_t workspace_bytes, sat_stream_t stream);
 
+/* Measurement hook for bench.py: while enabled, every forward brackets the FFN-in (SwiGLU) GEMM
+ * launch of ONE transformer layer (depth/2) with a hipEvent pair on the launch stream (at most
+ * 4096 pairs; enabling resets the count).  sat_dit_profile_read synchronises on the recorded
+ * events and returns the summed elapsed time, the number of launches and the GEMM shape. */
+int sat_dit_profile(sat_dit_plan* plan, int32_t enable);
+int sat_dit_profile_read(sat_dit_plan* plan, double* total_ms, int32_t* launches, int64_t* m, int64_t* n, int64_t* k);
+
 /* Batched-CFG combine alone (models/dit.py:336-345): model_out_dev [2*b, c, t] (cond half, then
  * uncond half) -> out_dev [b, c, t] = uncond + (cond - uncond) * cfg_scale, with the optional
  * std rescale when scale_phi != 0. */

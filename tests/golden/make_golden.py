@@ -175,6 +175,27 @@ def gen_host():
     save("host", **out)
 
 
+def gen_keys():
+    """State-dict keys + shapes of the reference's SA-Open-1.0 model (T5 entry removed) and of the VAE config:
+    the checkpoint-compatibility contract."""
+    import json
+    base = os.path.join(R.REFERENCE_ROOT, "stable_audio_tools/configs/model_configs")
+    cfg = json.load(open(os.path.join(base, "txt2audio/stable_audio_open_1_0.json")))
+    cfg["model"]["conditioning"]["configs"] = [c for c in cfg["model"]["conditioning"]["configs"] if c["type"] != "t5"]
+    m = R.ref("models.factory").create_model_from_config(cfg)
+    keys = {k: list(v.shape) for k, v in m.state_dict().items()}
+    vcfg = json.load(open(os.path.join(base, "autoencoders/stable_audio_2_0_vae.json")))
+    v = R.ref("models.factory").create_model_from_config(vcfg)
+    vkeys = {k: list(t.shape) for k, t in v.state_dict().items()}
+    info = {"sa_open_1_0": keys, "vae": vkeys,
+            "attrs": {"io_channels": m.io_channels, "sample_rate": m.sample_rate, "min_input_length": m.min_input_length,
+                      "diffusion_objective": m.diffusion_objective, "pretransform_ratio": m.pretransform.downsampling_ratio,
+                      "vae_latent_dim": v.latent_dim, "vae_ratio": v.downsampling_ratio, "vae_min_length": v.min_length}}
+    path = os.path.join(cases.GOLDEN_DIR, "state_dict_keys.json")
+    json.dump(info, open(path, "w"))
+    print("wrote", path, len(keys), len(vkeys))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "small", "vae", "host", "full"]
     torch.set_num_threads(os.cpu_count())
@@ -186,6 +207,8 @@ if __name__ == "__main__":
         gen_vae()
     if "host" in which:
         gen_host()
+    if "keys" in which:
+        gen_keys()
     if "full" in which:
         gen_full(False)
     if "full_long" in which:

@@ -1,0 +1,96 @@
+"""The C-ABI library: loads, exports every symbol declared in include/sat_hip.h, and the product refuses to
+run without a HIP device (no CPU fallback, no route into the oracle).  No compute calls here."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "friendly-stable-audio-tools_amd")
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sat_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sat_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from stable_audio_tools import _hip
+    lib = _hip.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"libsat_hip.so does not export {name}"
+    assert sorted(_hip.exported_symbols()) == declared, "ctypes signature table and header disagree"
+    assert lib.sat_version() >= 1
+
+
+def test_library_has_no_torch_dependency():
+    from stable_audio_tools import _hip
+    out = subprocess.run(["ldd", _hip.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libtorch" not in out and "libc10" not in out, "the C ABI must not link against torch"
+    assert "libamdhip64" in out
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments with SAT_E_* codes and a message instead of crashing."""
+    import ctypes
+    from stable_audio_tools import _hip
+    lib = _hip.lib()
+    plan = ctypes.c_void_p()
+    bad = _hip.SatDitCfg(64, 1000, 2, 10, 0, 0, 0, 128)        # dim_heads != 64
+    assert lib.sat_dit_plan_create(ctypes.byref(bad), ctypes.byref(plan)) == -2
+    assert b"dim_heads" in lib.sat_last_error()
+    ok = _hip.SatDitCfg(64, 256, 2, 4, 128, 128, 64, 128)
+    assert lib.sat_dit_plan_create(ctypes.byref(ok), ctypes.byref(plan)) == 0
+    need = ctypes.c_size_t()
+    assert lib.sat_dit_workspace_bytes(plan, 2, 64, ctypes.byref(need)) == -5      # not finalized
+    assert lib.sat_dit_plan_set_tensor(plan, b"x", None, 4) == -1
+    lib.sat_dit_plan_destroy(plan)
+    ocfg = _hip.SatOobleckCfg()
+    ocfg.is_decoder, ocfg.io_channels, ocfg.channels, ocfg.latent_dim, ocfg.n_blocks = 1, 2, 100, 64, 2
+    assert lib.sat_oobleck_plan_create(ctypes.byref(ocfg), ctypes.byref(plan)) == -2
+    assert lib.sat_dpmpp3m_update(None, None, None, None, None, 0.0, 1.0, 0.0, 0.0, 0.0, 10, None) == -1
+
+
+def test_product_has_no_cpu_path():
+    from stable_audio_tools import _hip
+    from stable_audio_tools import model_configs as MC
+    import stable_audio_tools as S
+    model = S.create_model_from_config(MC.reduced(MC.stable_audio_vae()))
+    with pytest.raises(_hip.SatError):
+        model.decode(torch.zeros(1, 64, 4))          # CPU tensors / CPU module -> loud failure
+    with pytest.raises(_hip.SatError):
+        model.bottleneck.encode(torch.zeros(1, 128, 4))
+    from stable_audio_tools.utils.audio_utils import float_to_int16_audio
+    with pytest.raises(_hip.SatError):
+        float_to_int16_audio(torch.zeros(2, 8))
+    dit = S.create_model_from_config(MC.reduced(MC.stable_audio_open_1_0()))
+    with pytest.raises(_hip.SatError):
+        dit.model(torch.zeros(1, 64, 8), torch.zeros(1), cross_attn_cond=torch.zeros(1, 4, 128), global_cond=torch.zeros(1, 256))
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "/root/reference" in src:
+                    bad.append(os.path.join(base, f))
+    assert not bad, f"product files reference the oracle / the reference tree: {bad}"
+    for f in ("bench.py",):
+        src = open(os.path.join(ROOT, f)).read()
+        assert "/root/reference" not in src
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from stable_audio_tools import _hip
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_hip.SatError, match="not built"):
+        _hip.lib()

@@ -46,10 +46,10 @@ def test_cast_bf16(dev):
     assert torch.equal(y.cpu(), x.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("m,n,k", [(2050, 1536, 1536), (130, 256, 128), (1, 512, 64), (257, 768, 6144)])
 def test_gemm_f32(dev, variant, m, n, k):
-    if variant in (3, 4) and n % 256:
+    if variant in (3, 4, 7, 8) and n % 256:
         pytest.skip("256-column tile needs n % 256 == 0")
     _hip, lib = _lib()
     a = _rand((m, k), 5).to(torch.bfloat16)

@@ -179,3 +179,53 @@ def test_generate_diffusion_cond_small(dev, small_dit):
     vsd = _sub(sd, "pretransform.model.decoder.")
     strides = cfg["model"]["pretransform"]["config"]["decoder"]["config"]["strides"]
     assert_close("pretransform.decode", model.pretransform.decode(lat), oob.oobleck_decoder(vsd, lat.cpu(), strides=strides, rnd=bf16_round), 1.5e-2)
+
+
+@pytest.mark.parametrize("t_len", [1024, 6144])
+def test_full_size_dit_vs_reference_golden(dev, t_len):
+    """Full-size SA-Open DiT (24 layers, D=1536, 1.06 B synthetic parameters, seed 0) against the output of the
+    REFERENCE itself (tests/golden/dit_full_T*.npz: fp32 CPU run of /root/reference in the build container) at the
+    SA-Open (T=1024) and SA-2.0 (T=6144) context lengths.  bf16 GEMM operands vs the fp32 reference: gate 3e-2
+    (SURVEY.md section 7 measured 1.5e-2 for a bf16 autocast of the reference itself)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    path = os.path.join(cases.GOLDEN_DIR, f"dit_full_T{t_len}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated")
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.models import _init
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    want = cases.load(f"dit_full_T{t_len}")["out"]
+    with _init.skip_init():
+        dit = DiffusionTransformer(**cases.FULL_DIT)
+    dit.load_state_dict(synthetic.synth_state_dict(dit.state_dict(), 0))
+    dit = dit.to(dev).eval()
+    x, t, c, g = cases.dit_inputs(1, t_len, 768, 1536, 1)
+    got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
+    e = assert_close(f"full-size DiT T={t_len} vs reference", got, want, 3e-2)
+    print(f"\n[full DiT T={t_len}] rel-L2 vs the reference's fp32 output {e:.2e} (out std {want.std():.3f})")
+    del dit
+    torch.cuda.empty_cache()
+
+
+def test_full_size_decoder_vs_reference_golden(dev):
+    """BASELINE config 1 shape: full-size Oobleck decoder, z[1,64,43] -> [1,2,88064], vs the reference's fp32 output."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.models import _init
+    from stable_audio_tools.models.autoencoders import OobleckDecoder, OobleckEncoder
+    g = cases.load("vae")
+    with _init.skip_init():
+        dec = OobleckDecoder(**cases.vae_kwargs(cases.FULL_VAE, True))
+    dec.load_state_dict(synthetic.synth_state_dict(dec.state_dict(), 0))
+    got = dec.to(dev)(synthetic.synth_input("z_full", (1, 64, 43), 1).to(dev))
+    e = assert_close("full-size decode vs reference", got, g["full_decode_T43"], 3e-2)
+    with _init.skip_init():
+        enc = OobleckEncoder(**cases.vae_kwargs(cases.FULL_VAE, False))
+    enc.load_state_dict(synthetic.synth_state_dict(enc.state_dict(), 0))
+    got = enc.to(dev)(synthetic.synth_input("a_full", (1, 2, 2048 * 16), 2, 0.3).to(dev))
+    e2 = assert_close("full-size encode vs reference", got, g["full_encode_T16"], 3e-2)
+    print(f"\n[full codec] decode rel-L2 {e:.2e}, encode rel-L2 {e2:.2e} vs the reference's fp32 output")

@@ -1,0 +1,196 @@
+"""Pins the oracle (oracle/*.py) against outputs of the REFERENCE itself (tests/golden/*.npz, produced in the
+build container by tests/golden/make_golden.py from /root/reference).  Weights and inputs are regenerated from
+seeds; only reference outputs are stored.  fp32 on CPU: agreement to ~1e-6 (summation order only)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import cases  # noqa: E402
+from oracle import dit as odit, oobleck as oob  # noqa: E402
+from stable_audio_tools import synthetic  # noqa: E402
+from util import rel_l2  # noqa: E402
+
+TOL = 2e-5
+
+
+def _template_sd(builder):
+    """state-dict template (names/shapes) of the PRODUCT module tree -- identical keys to the reference's."""
+    from stable_audio_tools.models import _init
+    with _init.skip_init():
+        m = builder()
+    return m.state_dict()
+
+
+@pytest.fixture(scope="module")
+def small_dit_sd():
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    return synthetic.synth_state_dict(_template_sd(lambda: DiffusionTransformer(**cases.SMALL_DIT)), 0)
+
+
+def test_ops_dit(small_dit_sd):
+    g = cases.load("ops")
+    sd = small_dit_sd
+    pf = "transformer.layers.1."
+    x = synthetic.synth_input("h", (2, 77, 256), 100)
+    ctx = synthetic.synth_input("ctx", (2, 130, 128), 101)
+    freqs = odit.rotary_freqs(sd["transformer.rotary_pos_emb.inv_freq"], 77)
+    assert rel_l2(freqs, g["rope_freqs"]) < 1e-7
+    assert rel_l2(odit.layer_norm(x, sd[pf + "pre_norm.gamma"], sd[pf + "pre_norm.beta"]), g["layernorm"]) < TOL
+    q = synthetic.synth_input("q", (2, 4, 77, 64), 102)
+    assert rel_l2(odit.apply_rotary(q, freqs), g["rope_q"]) < TOL
+    assert rel_l2(odit.self_attention(sd, pf + "self_attn.", x, freqs, 4), g["self_attn"]) < TOL
+    assert rel_l2(odit.cross_attention(sd, pf + "cross_attn.", x, ctx, 4, 64), g["cross_attn"]) < TOL
+    assert rel_l2(odit.feed_forward(sd, pf + "ff.", x), g["ff"]) < TOL
+    assert rel_l2(odit.transformer_block(sd, pf, x, ctx, freqs, 4, 64), g["block"]) < TOL
+    t = torch.tensor([0.13, 0.77])
+    te = odit._mlp(sd, "to_timestep_embed.", odit.fourier_features(sd["timestep_features.weight"], t[:, None]), bias=True)
+    assert rel_l2(te, g["timestep_embed"]) < TOL
+
+
+def test_dit_small_forward(small_dit_sd):
+    g = cases.load("dit_small")
+    sd = small_dit_sd
+    for t_len in (64, 77):
+        x, t, c, gl = cases.dit_inputs(2, t_len, 128, 96, 1)
+        assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=1.0), g[f"cfg1_T{t_len}"]) < TOL
+        assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=7.0), g[f"cfg7_T{t_len}"]) < TOL
+    x, t, c, gl = cases.dit_inputs(2, 64, 128, 96, 1)
+    assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=7.0, scale_phi=0.4), g["cfg7_phi04_T64"]) < TOL
+    zero = odit.dit_forward(sd, x, t, torch.zeros_like(c), gl, 3, 4)
+    assert rel_l2(zero, g["zero_ctx_T64"]) < TOL
+    # an all-zero context contributes exactly nothing (no-bias to_cond_embed / to_kv / to_out): same as no cross-attention
+    none = odit.dit_inner_forward(sd, x, t, None, gl, 3, 4)
+    assert torch.equal(zero, none)
+    # matched-rounding mode stays close to fp32 and is deterministic
+    r1 = odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=7.0, rnd=odit.bf16_round)
+    assert rel_l2(r1, g["cfg7_T64"]) < 3e-2
+
+
+def test_ops_codec_and_quantisation():
+    g = cases.load("ops")
+    from stable_audio_tools.models.blocks import SnakeBeta
+    from stable_audio_tools.models import autoencoders as ae
+    sn = synthetic.synth_state_dict(_template_sd(lambda: SnakeBeta(16)), 2)
+    xs = synthetic.synth_input("snake_x", (2, 16, 50), 103, 2.0)
+    assert rel_l2(oob.snake_beta(xs, sn["alpha"], sn["beta"]), g["snake"]) < TOL
+    for dil in (1, 3, 9):
+        sd = synthetic.synth_state_dict(_template_sd(lambda: ae.ResidualUnit(16, 16, dil, use_snake=True)), 3 + dil)
+        out = oob.residual_unit(sd, "", synthetic.synth_input("ru_x", (2, 16, 64), 104), dil)
+        assert rel_l2(out, g[f"resunit_d{dil}"]) < TOL
+    for s in (2, 4, 8):
+        sd = synthetic.synth_state_dict(_template_sd(lambda: ae.DecoderBlock(32, 16, s, use_snake=True)), 20 + s)
+        x = synthetic.synth_input("db_x", (1, 32, 11), 105)
+        h = oob.snake_beta(x, sd["layers.0.alpha"], sd["layers.0.beta"])
+        v = F.conv_transpose1d(h, oob.fold_weight_norm(sd["layers.1.weight_g"], sd["layers.1.weight_v"]), sd["layers.1.bias"],
+                               stride=s, padding=(s + 1) // 2)
+        for ri, dil in enumerate((1, 3, 9)):
+            v = oob.residual_unit(sd, f"layers.{2 + ri}.", v, dil)
+        assert v.shape[-1] == 11 * s
+        assert rel_l2(v, g[f"decblock_s{s}"]) < TOL
+        sd = synthetic.synth_state_dict(_template_sd(lambda: ae.EncoderBlock(16, 32, s, use_snake=True)), 30 + s)
+        v = synthetic.synth_input("eb_x", (1, 16, 16 * s), 106)
+        for ri, dil in enumerate((1, 3, 9)):
+            v = oob.residual_unit(sd, f"layers.{ri}.", v, dil)
+        h = oob.snake_beta(v, sd["layers.3.alpha"], sd["layers.3.beta"])
+        v = F.conv1d(h, oob.fold_weight_norm(sd["layers.4.weight_g"], sd["layers.4.weight_v"]), sd["layers.4.bias"], stride=s,
+                     padding=(s + 1) // 2)
+        assert rel_l2(v, g[f"encblock_s{s}"]) < TOL
+    # vae_sample: the reference draws randn_like(mean) from the global generator (bottleneck.py:48)
+    ms = synthetic.synth_input("ms", (2, 8, 10), 107)
+    torch.manual_seed(1234)
+    noise = torch.randn_like(ms[:, :4])
+    assert rel_l2(oob.vae_sample(ms, noise), g["vae_sample_seed1234"]) < 1e-6
+    # float_to_int16_audio (utils/audio_utils.py:21-26): truncation, peak floored at 1 unless maximize
+    a = synthetic.synth_input("i16", (2, 4099), 108, 0.7)
+
+    def q(x, maximize=False):
+        div = x.abs().max().item()
+        if not maximize:
+            div = max(div, 1.0)
+        return x.div(div).mul(32767).to(torch.int16).float()
+
+    assert torch.equal(q(a), g["int16_quiet"]) and torch.equal(q(a * 4), g["int16_loud"]) and torch.equal(q(a, True), g["int16_max"])
+
+
+def test_vae_full_and_small():
+    g = cases.load("vae")
+    from stable_audio_tools.models import autoencoders as ae
+    dsd = synthetic.synth_state_dict(_template_sd(lambda: ae.OobleckDecoder(**cases.vae_kwargs(cases.SMALL_VAE, True))), 5)
+    esd = synthetic.synth_state_dict(_template_sd(lambda: ae.OobleckEncoder(**cases.vae_kwargs(cases.SMALL_VAE, False))), 6)
+    z = synthetic.synth_input("z", (2, 64, 9), 7)
+    a = synthetic.synth_input("a", (2, 2, 2048 * 5), 8, 0.3)
+    assert rel_l2(oob.oobleck_decoder(dsd, z), g["small_decode"]) < TOL
+    assert rel_l2(oob.oobleck_encoder(esd, a), g["small_encode"]) < TOL
+    # BASELINE config 1: full-size decoder on z[1,64,43] -> [1,2,88064]
+    dsd = synthetic.synth_state_dict(_template_sd(lambda: ae.OobleckDecoder(**cases.vae_kwargs(cases.FULL_VAE, True))), 0)
+    out = oob.oobleck_decoder(dsd, synthetic.synth_input("z_full", (1, 64, 43), 1))
+    assert out.shape == (1, 2, 88064)
+    assert rel_l2(out, g["full_decode_T43"]) < TOL
+    esd = synthetic.synth_state_dict(_template_sd(lambda: ae.OobleckEncoder(**cases.vae_kwargs(cases.FULL_VAE, False))), 0)
+    assert rel_l2(oob.oobleck_encoder(esd, synthetic.synth_input("a_full", (1, 2, 2048 * 16), 2, 0.3)), g["full_encode_T16"]) < TOL
+
+
+def test_chunked_codec_paths():
+    """AudioAutoencoder.encode_audio / decode_audio / reconstruct_audio chunking + Bartlett OLA, incl. the
+    reference's RNG order (manual_seed, then one randn_like per encode call in chunk-batch order)."""
+    g = cases.load("vae_chunked")
+    from stable_audio_tools.models import autoencoders as ae
+    dsd = synthetic.synth_state_dict(_template_sd(lambda: ae.OobleckDecoder(**cases.vae_kwargs(cases.SMALL_VAE, True))), 5)
+    esd = synthetic.synth_state_dict(_template_sd(lambda: ae.OobleckEncoder(**cases.vae_kwargs(cases.SMALL_VAE, False))), 6)
+    dec = lambda z: oob.oobleck_decoder(dsd, z)
+    sig = synthetic.synth_input("sig", (1, 2, 2048 * 11 + 700), 9, 0.3)[..., : 2048 * 11]
+
+    def batched(fn, chunks, max_bs):
+        return [fn(torch.cat(chunks[i:i + max_bs], dim=0)) for i in range(0, len(chunks), max_bs)]
+
+    # reconstruct: 5 chunks of 4 latents (hop 3), encode+decode in batches of 3; the VAE noise is drawn per batch
+    torch.manual_seed(77)
+    cs, hop = 4 * 2048, 3 * 2048
+    n_chunk = 4
+    pad = cs + hop * n_chunk - sig.shape[-1]
+    padded = F.pad(sig, (0, pad))
+    chunks = [padded[..., i * hop: i * hop + cs] for i in range(n_chunk)]
+    outs = []
+    for grp in batched(lambda x: x, chunks, 3):
+        ms = oob.oobleck_encoder(esd, grp)
+        zz = oob.vae_sample(ms, torch.randn_like(ms[:, :64]))
+        outs += list(dec(zz).split(1, dim=0))
+    it = iter(outs)
+    rec = oob.reconstruct_audio_chunked(lambda chunk, i: next(it), sig, 4, 1, 2048)
+    assert rel_l2(rec, g["reconstruct_chunked"]) < TOL
+    # decode_audio chunked (reflect pad) and its agreement with the un-chunked decode away from the seams
+    zz = synthetic.synth_input("zz", (1, 64, 11), 10)
+    assert rel_l2(oob.decode_audio_chunked(dec, zz, 4, 1, 2048), g["decode_chunked"]) < TOL
+    assert rel_l2(dec(zz), g["decode_unchunked"]) < TOL
+    # encode_audio chunked: latent-domain OLA
+    torch.manual_seed(78)
+    n_chunk = 4
+    pad = cs + hop * (n_chunk - 1) - sig.shape[-1]
+    padded = F.pad(sig, (0, pad))
+    chunks = [padded[..., i * hop: i * hop + cs] for i in range(n_chunk)]
+    zs = []
+    for grp in batched(lambda x: x, chunks, 2):
+        ms = oob.oobleck_encoder(esd, grp)
+        zs += list(oob.vae_sample(ms, torch.randn_like(ms[:, :64])).split(1, dim=0))
+    it2 = iter(zs)
+    enc = oob.encode_audio_chunked(lambda chunk: next(it2), sig, 4, 1, 2048, 64)
+    assert rel_l2(enc, g["encode_chunked"]) < TOL
+
+
+def test_full_dit_golden_exists_and_oracle_matches():
+    """Full-size SA-Open DiT (1.06 B parameters, seed 0), one forward at T=1024: ~15 s of CPU."""
+    path = os.path.join(cases.GOLDEN_DIR, "dit_full_T1024.npz")
+    if not os.path.exists(path):
+        pytest.skip("dit_full_T1024.npz not generated")
+    if os.environ.get("SAT_SKIP_SLOW"):
+        pytest.skip("SAT_SKIP_SLOW set")
+    g = cases.load("dit_full_T1024")
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    sd = synthetic.synth_state_dict(_template_sd(lambda: DiffusionTransformer(**cases.FULL_DIT)), 0)
+    x, t, c, gl = cases.dit_inputs(1, 1024, 768, 1536, 1)
+    out = odit.dit_forward(sd, x, t, c, gl, 24, 24)
+    assert rel_l2(out, g["out"]) < 5e-5

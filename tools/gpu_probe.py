@@ -46,8 +46,8 @@ def gemm_bench():
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
-        for v in (1, 2, 3, 4):
-            if v in (3, 4) and n % 256:
+        for v in (1, 2, 3, 4, 5, 6, 7, 8):
+            if v in (3, 4, 7, 8) and n % 256:
                 continue
             f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
             ms = timeit(f)
