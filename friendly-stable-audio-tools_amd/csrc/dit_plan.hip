@@ -64,6 +64,7 @@ struct sat_dit_plan {
     size_t ctx_cap = 0;
     int ctx_bf = 0, ctx_lc = 0, ctx_lcpad = 0;
     bool has_global = false;
+    int ctx_null_from = -1;         // sequences >= this index have an all-zero context (sat_dit_set_null_context_from)
     float* ge = nullptr;            // [bf, D] projected global embedding
     bf16_t* kc = nullptr;           // [depth][bf, kvh, lcpad, 64]
     bf16_t* vct = nullptr;          // [depth][bf, kvh, 64, lcpad]
@@ -244,19 +245,26 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g = GemmArgs{};
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
-        // ---- cross-attention branch (transformer.py:694-695)
+        // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
+        // unconditional CFG half, dit.py:294-300) get k = v = 0 from the bias-free to_cond_embed / to_kv, hence an
+        // attention output of exactly 0 and, through the bias-free to_out, a branch contribution of exactly 0:
+        // the branch runs only on the first `bc` sequences (rows are ordered by sequence).
         if (cross) {
-            SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, M, D, s));
-            g = GemmArgs{};
-            g.A = w.A; g.W = L.w_cq; g.M = M; g.N = D; g.K = D;
-            g.heads.out[0] = w.Q; g.heads.kind[0] = 0; g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
-            SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
-            const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lcpad * 64;
-            SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bf, H, p->kvh_cross, S,
-                                         p->ctx_lc, Spad, p->ctx_lcpad, s));
-            g = GemmArgs{};
-            g.A = w.AO; g.W = L.w_co; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
-            SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
+            const int bc = (p->ctx_null_from >= 0 && p->ctx_null_from < bf) ? p->ctx_null_from : bf;
+            const int Mc = bc * S;
+            if (bc > 0) {
+                SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s));
+                g = GemmArgs{};
+                g.A = w.A; g.W = L.w_cq; g.M = Mc; g.N = D; g.K = D;
+                g.heads.out[0] = w.Q; g.heads.kind[0] = 0; g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
+                SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
+                const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lcpad * 64;
+                SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
+                                             p->ctx_lc, Spad, p->ctx_lcpad, s));
+                g = GemmArgs{};
+                g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
+                SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
+            }
         }
         // ---- feed-forward branch (transformer.py:700)
         SAT_TRY(sat_launch_layernorm(w.X, L.ff_g, L.ff_b, w.A, M, D, s));
@@ -426,8 +434,17 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
         }
     }
     p->ctx_bf = bf;
+    p->ctx_null_from = -1;
     p->ctx_lc = cross ? lc : 0;
     p->ctx_lcpad = lcpad;
+    return 0;
+}
+
+extern "C" int sat_dit_set_null_context_from(sat_dit_plan* p, int32_t first_null_seq) {
+    SAT_CHECK_ARG(p && p->finalized, SAT_E_STATE, "dit_set_null_context_from: plan not finalized");
+    SAT_CHECK_ARG(first_null_seq >= -1 && first_null_seq <= p->ctx_bf, SAT_E_INVALID, "dit_set_null_context_from: %d not in [-1, %d]",
+                  first_null_seq, p->ctx_bf);
+    p->ctx_null_from = first_null_seq;
     return 0;
 }
 

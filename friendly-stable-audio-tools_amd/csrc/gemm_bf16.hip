@@ -346,6 +346,192 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs g) {
     gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deep-prefetch variant: NS-stage LDS ring filled by LDS-DMA, prefetch distance NS-1, ONE raw
+// s_barrier per K-tile and COUNTED s_waitcnt vmcnt (never 0 in steady state) so that NS-2 tiles
+// stay in flight across every barrier (guide T3+T4).  This is what hides the L2/HBM -> LDS latency
+// when only one workgroup fits a CU (B=1: 204..432 workgroups on 256 CUs).
+//   iteration k:  wait(tile k landed) ; barrier ; issue tile k+NS-1 -> stage (k-1)%NS ; compute k
+// BK = 64 (128-B rows, 8 chunks) or 32 (64-B rows, 4 chunks; swizzle c ^ ((row>>2)&3)).
+// ---------------------------------------------------------------------------------------------
+template <int BK>
+__device__ __forceinline__ int lds_off_bk(int row, int chunk) {
+    if constexpr (BK == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM;
+    constexpr int TN = BN / WN;
+    static_assert(TN == 64, "wave tile is TM x 64");
+    constexpr int MI = TM / 32;
+    constexpr int NI = 2;
+    constexpr int CPR = BK / 8;                    // 16-B chunks per row
+    constexpr int A_CH = BM * CPR / NT;
+    constexpr int B_CH = BN * CPR / NT;
+    constexpr int LPT = A_CH + B_CH;               // LDS-DMA instructions per tile per thread
+    constexpr int ROWB = BK * 2;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int D = NS - 1;                      // prefetch distance
+    static_assert(A_CH >= 1 && B_CH >= 1 && (D - 1) * LPT < 64, "bad pipeline geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_n = N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    if (tiles_m <= tiles_n) {
+        tn = bid / tiles_m;
+        tm = bid - tn * tiles_m;
+    } else {
+        tm = bid / tiles_n;
+        tn = bid - tm * tiles_n;
+    }
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    const bool dbg_same = g.variant >= 100;      // micro-benchmark aid: every tile loads tile (0,0) (all L2 hits)
+    const bf16_t* a_ptr[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        int q = i * NT + tid;
+        int row = q / CPR, pos = q % CPR;
+        int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
+        int gm = (dbg_same ? 0 : m0) + row;
+        gm = gm < M ? gm : M - 1;
+        a_ptr[i] = g.A + (size_t)gm * K + c * 8;
+    }
+    const bf16_t* b_ptr[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        int q = i * NT + tid;
+        int row = q / CPR, pos = q % CPR;
+        int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
+        b_ptr[i] = g.W + (size_t)((dbg_same ? 0 : n0) + row) * K + c * 8;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto stage_in = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    // fragments are double-buffered across the k-steps: the ds_reads of step ks+1 are issued BEFORE the MFMAs of
+    // step ks, so the wave waits with a counted lgkmcnt and LDS latency hides behind the matrix pipe
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE_BYTES;
+        const char* sb = sa + BM * ROWB;
+        constexpr int KS = BK / 16;
+        bf16x8 af[2][MI], bfr[2][NI];
+        auto frag = [&](int ks, int buf) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[buf][i] = *reinterpret_cast<const bf16x8*>(sa + lds_off_bk<BK>(wm * TM + i * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bfr[buf][j] = *reinterpret_cast<const bf16x8*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
+        };
+        frag(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);        // the first fragments: DS reads only
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) frag(ks + 1, (ks + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+            // pin the interleave: one ds_read of the NEXT step's fragments behind each MFMA of this step
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int r = 0; r < MI + NI; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - (MI + NI), 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
+            }
+        }
+    };
+
+    const int nk = K / BK;
+    // prologue: tiles 0..D-1 in flight (nk >= D is guaranteed by the launcher)
+#pragma unroll
+    for (int s = 0; s < D; ++s) stage_in(s, s);
+    int rd = 0;          // stage of tile k
+    int wr = D;          // stage that receives tile k+D (== stage of tile k-1)
+    // steady state: tiles k+1..k+D-1 stay in flight across the barrier
+    for (int k = 0; k < nk - D; ++k) {
+        wait_vmcnt<(D - 1) * LPT>();
+        __builtin_amdgcn_s_barrier();
+        stage_in(k + D, wr);
+        compute(rd);
+        rd = (rd + 1 == NS) ? 0 : rd + 1;
+        wr = (wr + 1 == NS) ? 0 : wr + 1;
+    }
+    // drain: nothing left to issue
+    for (int k = nk - D; k < nk; ++k) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        compute(rd);
+        rd = (rd + 1 == NS) ? 0 : rd + 1;
+    }
+
+    gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
+int launch_pipe(const GemmArgs& a, hipStream_t stream) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int LDS = NS * (BM + BN) * BK * 2;
+    static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
+    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
+    SAT_CHECK_ARG(a.K % BK == 0 && a.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
+    int tiles = cdiv(a.M, BM) * (a.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, a);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, bool GLDS = false>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
@@ -365,13 +551,15 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
-    int v = a.variant;
+    int v = a.variant >= 100 ? a.variant - 100 : a.variant;
     if (v == 0) {
-        // measured on MI355X (profiles/r01_gemm_variants.txt): the direct-to-LDS 256x256 tile wins whenever it
-        // yields >= ~160 workgroups (FFN-in, QKV at B=1; everything at B>=4); below that the 128x128 tile fills
-        // more CUs (to_out / FFN-out at B=1: 204 tiles instead of 54).
+        // measured on MI355X (profiles/r01_gemm_variants.txt): the 256x256 tile (16 waves, direct-to-LDS, 2 stages)
+        // wins whenever it yields >= ~160 workgroups (FFN-in, QKV at B=1; everything at B>=4); below that the
+        // 128x128 tile with 8 waves and a 3-stage ring fills more CUs (to_out / FFN-out at B=1: 204 vs 54 workgroups).
         long t256 = (long)cdiv(a.M, 256) * (a.N / 256);
-        v = (a.N % 256 == 0 && t256 >= 160) ? 7 : 5;
+        if (a.N % 256 == 0 && t256 >= 160 && a.K >= 128) v = 22;
+        else if (a.K >= 192) v = 15;
+        else v = 5;
     }
     switch (v) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
@@ -382,6 +570,21 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 6: return launch_cfg<256, 128, 4, 2, EPI, true>(a, stream);
         case 7: return launch_cfg<256, 256, 2, 4, EPI, true>(a, stream);
         case 8: return launch_cfg<128, 256, 1, 4, EPI, true>(a, stream);
+        case 9: return launch_pipe<128, 128, 64, 2, 2, 4, EPI>(a, stream);
+        case 10: return launch_pipe<128, 128, 64, 2, 2, 3, EPI>(a, stream);
+        case 11: return launch_pipe<256, 256, 32, 2, 4, 4, EPI>(a, stream);
+        case 12: return launch_pipe<256, 128, 64, 4, 2, 3, EPI>(a, stream);
+        case 13: return launch_pipe<256, 256, 32, 2, 4, 3, EPI>(a, stream);
+        case 14: return launch_pipe<128, 128, 32, 2, 2, 4, EPI>(a, stream);
+        case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI>(a, stream);
+        case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);
+        case 17: return launch_pipe<64, 128, 64, 2, 2, 3, EPI>(a, stream);
+        case 18: return launch_pipe<128, 128, 64, 2, 2, 2, EPI>(a, stream);
+        case 19: return launch_pipe<64, 128, 64, 2, 2, 4, EPI>(a, stream);
+        case 20: return launch_pipe<128, 128, 64, 4, 2, 2, EPI>(a, stream);
+        case 21: return launch_pipe<256, 256, 32, 4, 4, 3, EPI>(a, stream);
+        case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI>(a, stream);
+        case 23: return launch_pipe<256, 128, 64, 8, 2, 3, EPI>(a, stream);
         default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
     }
 }

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "sat_dit_plan_finalize": (c_int32, [c_void_p, c_void_p]),
     "sat_dit_workspace_bytes": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_size_t)]),
     "sat_dit_prepare_context": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "sat_dit_set_null_context_from": (c_int32, [c_void_p, c_int32]),
     "sat_dit_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "sat_dit_denoise_cfg": (c_int32, [c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int32, c_int32, c_void_p,
                                       c_size_t, c_void_p]),

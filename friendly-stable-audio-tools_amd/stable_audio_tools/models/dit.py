@@ -110,12 +110,14 @@ class DiffusionTransformer(nn.Module):
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.timestep_features.weight.device)
         return self._ws
 
-    def prepare_context(self, cross_attn_cond, global_embed):
+    def prepare_context(self, cross_attn_cond, global_embed, null_from=-1):
         """Per-generation constants (cond/global MLPs + per-layer cross K/V).  ``cross_attn_cond``
         [bf, Lc, cond_token_dim] and ``global_embed`` [bf, global_cond_dim] already hold the
-        CFG-doubled batch (cond half first, null/negative half second)."""
+        CFG-doubled batch (cond half first, null/negative half second).  ``null_from``: index of the
+        first sequence whose context is the all-zero null embed (its cross-attention is exactly 0)."""
         plan = self._ensure_plan()
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if t is not None else None for t in (cross_attn_cond, global_embed))
+        key = key + (null_from,)
         if key == self._ctx_key:
             return
         c = None if cross_attn_cond is None else cross_attn_cond.detach().float().contiguous()
@@ -125,6 +127,8 @@ class DiffusionTransformer(nn.Module):
         if c is not None and c.shape[2] != self.cond_token_dim:
             raise ValueError(f"cross_attn_cond has {c.shape[2]} channels, model expects {self.cond_token_dim}")
         _hip.check(_hip.lib().sat_dit_prepare_context(plan, _hip.ptr(c), bf, lc, _hip.ptr(g), _hip.stream()))
+        if null_from >= 0 and c is not None:
+            _hip.check(_hip.lib().sat_dit_set_null_context_from(plan, int(null_from)))
         self._ctx_key = key
         self._ctx_keep = (cross_attn_cond, global_embed)
 
@@ -136,7 +140,7 @@ class DiffusionTransformer(nn.Module):
 
     # ------------------------------------------------------------------ reference-semantics forward
     @torch.no_grad()
-    def _forward(self, x, t, cross_attn_cond=None, global_embed=None, **ignored):
+    def _forward(self, x, t, cross_attn_cond=None, global_embed=None, null_from=-1, **ignored):
         """dit.py:135-226 on the given batch (no CFG logic)."""
         self._ensure_plan()
         x = x.detach().float().contiguous()
@@ -145,7 +149,7 @@ class DiffusionTransformer(nn.Module):
         if cross_attn_cond is None and global_embed is None:
             self.prepare_context_bf(bf)
         else:
-            self.prepare_context(cross_attn_cond, global_embed)
+            self.prepare_context(cross_attn_cond, global_embed, null_from)
         ws = self._workspace(bf, t_len)
         out = torch.empty_like(x)
         _hip.check(_hip.lib().sat_dit_forward(self._plan, _hip.ptr(x), _hip.ptr(t), _hip.ptr(out), bf, t_len, _hip.ptr(ws),
@@ -164,7 +168,8 @@ class DiffusionTransformer(nn.Module):
         if cfg_scale != 1.0 and cross_attn_cond is not None:
             b = x.shape[0]
             bc, bg = self._cfg_batch(cross_attn_cond, global_embed, negative_cross_attn_cond, negative_cross_attn_mask)
-            out = self._forward(torch.cat([x, x], dim=0), torch.cat([t, t], dim=0), bc, bg)
+            out = self._forward(torch.cat([x, x], dim=0), torch.cat([t, t], dim=0), bc, bg,
+                                null_from=b if negative_cross_attn_cond is None else -1)
             res = torch.empty_like(out[:b])
             # CFG combine (+ optional std rescale), dit.py:336-345, as a HIP kernel: denoise form with c_out=1, c_skip=0
             _hip.check(_hip.lib().sat_cfg_combine(_hip.ptr(out), _hip.ptr(res), b, out.shape[1], out.shape[2], float(cfg_scale),
@@ -198,7 +203,8 @@ class DiffusionTransformer(nn.Module):
             bc, bg = cross_attn_cond, global_embed
         if bc is None and bg is None:
             raise ValueError("prepare_generation needs conditioning tensors")
-        self.prepare_context(bc, bg)
+        null_from = cross_attn_cond.shape[0] if (use_cfg and negative_cross_attn_cond is None) else -1
+        self.prepare_context(bc, bg, null_from)
 
     @torch.no_grad()
     def denoise(self, x, sigma: float, cfg_scale: float = 1.0, scale_phi: float = 0.0, out=None):

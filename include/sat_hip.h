@@ -90,6 +90,12 @@ int sat_dit_workspace_bytes(const sat_dit_plan* plan, int32_t bf, int32_t t_len,
 int sat_dit_prepare_context(sat_dit_plan* plan, const float* cross_attn_cond_dev, int32_t bf, int32_t lc,
                             const float* global_cond_dev, sat_stream_t stream);
 
+/* Declares that sequences first_null_seq .. bf-1 of the prepared context are ALL-ZERO (the null embed of the
+ * unconditional CFG half, models/dit.py:294-300).  Their cross-attention branch contributes exactly 0
+ * (bias-free to_cond_embed / to_kv / to_out) and is skipped; results are unchanged.  -1 = none (default
+ * after every sat_dit_prepare_context). */
+int sat_dit_set_null_context_from(sat_dit_plan* plan, int32_t first_null_seq);
+
 /* DiffusionTransformer._forward (models/dit.py:135-226) on bf sequences:
  * x_dev [bf, io_channels, t_len], t_dev [bf] (timestep in [0,1]) -> out_dev [bf, io_channels, t_len]. */
 int sat_dit_forward(sat_dit_plan* plan, const float* x_dev, const float* t_dev, float* out_dev,

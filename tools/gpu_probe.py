@@ -46,13 +46,25 @@ def gemm_bench():
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
-        for v in (1, 2, 3, 4, 5, 6, 7, 8):
-            if v in (3, 4, 7, 8) and n % 256:
+        for v in (13, 15, 20, 21, 22, 23):
+            if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22) and n % 256:
                 continue
             f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
             ms = timeit(f)
             print(f"gemm {name:14s} v{v} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
         del a, w, c
+
+
+def gemm_pmc():
+    """few launches of selected variants for rocprofv3 --pmc runs"""
+    for name, m, n, k, vs in [("ff_in", 2050, 12288, 1536, (7, 5, 13)), ("ff_out", 2050, 1536, 6144, (5, 10)), ("ff_inB8", 16400, 12288, 1536, (7,))]:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        c = torch.zeros(m, n, device=dev)
+        for v in vs:
+            for _ in range(3):
+                _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
+        torch.cuda.synchronize()
 
 
 def attn_bench():
@@ -116,6 +128,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     if "gemm" in which:
         section("gemm", gemm_bench)
+    if "gemm_pmc" in which:
+        section("gemm_pmc", gemm_pmc)
     if "attn" in which:
         section("attention", attn_bench)
     if "ln" in which:
