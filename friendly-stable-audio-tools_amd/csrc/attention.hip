@@ -89,12 +89,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     float m_run = -1e30f;   // running max, in log2-scaled units
     float l_run = 0.f;      // this lane's partial row sum (its 32 of every 64 keys)
 
-    const int n_tiles = (Sk + KV_TILE - 1) / KV_TILE;
+    // K rows / V^T columns of sequence b start at ob = (b*Sk) & 3 (see EPI_HEADS in gemm_bf16.hip)
+    const int ob = (b * Sk) & 3;
+    const int k_end = ob + Sk;
+    const int n_tiles = (k_end + KV_TILE - 1) / KV_TILE;
+    // a wave whose 32 queries are all beyond Sq (tail workgroup) still stages tiles and joins the barriers,
+    // but skips the matrix and softmax work
+    const bool wave_active = __builtin_amdgcn_readfirstlane(blockIdx.x * Q_BLOCK + wave * 32) < Sq;
     gload(0);
     lstore(0);
     __syncthreads();
 
     auto process = [&](int tile) {
+        if (!wave_active) return;
         const int cur = tile & 1;
         const char* sk = smem + cur * (2 * KV_TILE * 128);
         const char* sv = sk + KV_TILE * 128;
@@ -111,15 +118,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[t], sacc[kb], 0, 0, 0);
             }
         }
-        // ---- mask the tail keys (wave-uniform branch, last tile only)
-        if (tile == n_tiles - 1 && (Sk & (KV_TILE - 1)) != 0) {
+        // ---- mask the columns outside [ob, ob + Sk) (wave-uniform branch: first and last tile only)
+        if ((tile == 0 && ob != 0) || (tile == n_tiles - 1 && (k_end & (KV_TILE - 1)) != 0)) {
             const int key0 = tile * KV_TILE + 4 * half;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2);
-                    if (key >= Sk) sacc[kb][r] = -INFINITY;
+                    if (key < ob || key >= k_end) sacc[kb][r] = -INFINITY;
                 }
         }
         // ---- online softmax (per query = per lane pair)
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
             for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[kb][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc * scale_log2);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
         bf16x8 pb[2][2];
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = exp2f(fmaf(sacc[kb][r], scale_log2, -m_new));
+                float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], scale_log2, -m_new));
                 psum += p;
                 pb[kb][r >> 3][r & 7] = f32_to_bf16(p);
             }
@@ -194,6 +201,7 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
     SAT_CHECK_ARG(sq > 0 && sk > 0 && sq_pad >= sq && sk_pad >= sk, SAT_E_INVALID, "attention: bad lengths");
     SAT_CHECK_ARG(sq_pad % Q_BLOCK == 0 && sk_pad % KV_TILE == 0, SAT_E_INVALID,
                   "attention: sq_pad %% 128 and sk_pad %% 64 must be 0 (got %d, %d)", sq_pad, sk_pad);
+    SAT_CHECK_ARG(sk_pad >= sk + 3, SAT_E_INVALID, "attention: sk_pad must be >= sk + 3 (key-side shift), got %d for sk=%d", sk_pad, sk);
     const float scale_log2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
     dim3 grid(cdiv(sq, Q_BLOCK), h, b);
     hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, q, k, vt, out, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);

@@ -180,7 +180,7 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     const int D = c.embed_dim, H = c.num_heads;
     const int S = T + 1;
     const size_t M = (size_t)bf * S;
-    const int Spad = (int)round_up(S, 128);
+    const int Spad = (int)round_up(S + 3, 128);
     Workspace w;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -217,7 +217,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     Workspace w = carve(p, bf, T, (char*)ws);
     SAT_CHECK_ARG(ws_bytes >= w.total, SAT_E_WORKSPACE, "dit forward: workspace %zu < required %zu", ws_bytes, w.total);
     const int D = c.embed_dim, H = c.num_heads, C = c.io_channels;
-    const int S = T + 1, M = bf * S, Spad = (int)round_up(S, 128);
+    const int S = T + 1, M = bf * S, Spad = (int)round_up(S + 3, 128);
 
     // pads of q/k/vt must be finite (zero): one memset per forward
     SAT_HIP(hipMemsetAsync(w.Q, 0, 3 * (size_t)round_up((int64_t)w.qkv_bytes, 256), s));
@@ -237,7 +237,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_qkv; g.M = M; g.N = 3 * D; g.K = D;
         g.heads.out[0] = w.Q; g.heads.out[1] = w.K; g.heads.out[2] = w.Vt;
-        g.heads.kind[0] = 2; g.heads.kind[1] = 2; g.heads.kind[2] = 1;
+        g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
         g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
         g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
         SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
@@ -382,7 +382,7 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
     SAT_CHECK_ARG(bf > 0, SAT_E_INVALID, "dit_prepare_context: bf must be positive");
     SAT_CHECK_ARG(!cross || (cond && lc > 0), SAT_E_INVALID, "dit_prepare_context: model has cross-attention but no cond given");
     SAT_CHECK_ARG(!(global_cond && Dg == 0), SAT_E_INVALID, "dit_prepare_context: model has no global conditioning");
-    const int lcpad = cross ? (int)round_up(lc, 64) : 0;
+    const int lcpad = cross ? (int)round_up(lc + 3, 64) : 0;
     const int R = bf * lc;
     // layout of the context buffer
     size_t off = 0;
@@ -427,7 +427,7 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
             GemmArgs g{};
             g.A = ce; g.W = p->layers[l].w_ckv; g.M = R; g.N = 2 * Dc; g.K = Dc;
             g.heads.out[0] = p->kc + l * per_layer; g.heads.out[1] = p->vct + l * per_layer;
-            g.heads.kind[0] = 0; g.heads.kind[1] = 1; g.heads.parts = 2; g.heads.heads = p->kvh_cross;
+            g.heads.kind[0] = 4; g.heads.kind[1] = 1 | 4; g.heads.parts = 2; g.heads.heads = p->kvh_cross;
             g.heads.S = lc; g.heads.Spad = lcpad;
             g.variant = 1;
             SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
@@ -548,7 +548,7 @@ extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_
                                  float* rope_scratch, int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant,
                                  sat_stream_t stream) {
     SAT_CHECK_ARG(a && w && inv_freq && q && k && vt && rope_scratch, SAT_E_INVALID, "qkv_rope: null pointer");
-    SAT_CHECK_ARG(d % 64 == 0 && s_pad >= s_len && s_pad % 128 == 0, SAT_E_INVALID, "qkv_rope: bad dims");
+    SAT_CHECK_ARG(d % 64 == 0 && s_pad >= s_len + 3 && s_pad % 128 == 0, SAT_E_INVALID, "qkv_rope: bad dims (s_pad >= s + 3, %% 128)");
     hipStream_t s = (hipStream_t)stream;
     const int H = d / 64;
     const size_t bytes = (size_t)b * H * s_pad * 64 * 2;
@@ -561,7 +561,7 @@ extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_
     GemmArgs g{};
     g.A = (const bf16_t*)a; g.W = (const bf16_t*)w; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant;
     g.heads.out[0] = (bf16_t*)q; g.heads.out[1] = (bf16_t*)k; g.heads.out[2] = (bf16_t*)vt;
-    g.heads.kind[0] = 2; g.heads.kind[1] = 2; g.heads.kind[2] = 1;
+    g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
     g.heads.parts = 3; g.heads.heads = H; g.heads.S = s_len; g.heads.Spad = s_pad;
     g.heads.rope_cos = cs; g.heads.rope_sin = sn;
     return sat_launch_gemm(EPI_HEADS, g, s);

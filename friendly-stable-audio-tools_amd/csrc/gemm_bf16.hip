@@ -74,32 +74,72 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         const int kind = he.kind[part];
         bf16_t* __restrict__ dst = he.out[part];
         const int S = he.S, Spad = he.Spad;
+        // K rows / V^T columns of sequence b are shifted by o_b = (b*S) & 3 (kind bit 2) so that the 4 consecutive
+        // tokens a lane holds (rows 4q..4q+3 of the GEMM) land on an 8-byte aligned V^T span: one dwordx2 store
+        // instead of four 2-byte scatters.  The attention kernel applies the same shift to its key index.
+        const bool shift = (kind & 4) != 0;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const bool valid = m < M;
-                int mm = valid ? m : M - 1;
-                int b = mm / S;
-                int s = mm - b * S;
-                float v0 = acc[i][0][r], v1 = acc[i][1][r];
-                if (kind & 2) {   // wave-uniform
-                    float p = __shfl_xor(v0, 16, 64);
-                    int jf = l31 & 15;
-                    float cs = he.rope_cos[s * 16 + jf], sn = he.rope_sin[s * 16 + jf];
-                    v0 = (l31 < 16) ? (v0 * cs - p * sn) : (v0 * cs + p * sn);
-                }
-                if (valid) {
-                    if (kind & 1) {
-                        size_t base = ((size_t)(b * he.heads + head) * 64) * Spad + s;
-                        dst[base + (size_t)l31 * Spad] = f32_to_bf16(v0);
-                        dst[base + (size_t)(32 + l31) * Spad] = f32_to_bf16(v1);
-                    } else {
-                        size_t base = ((size_t)(b * he.heads + head) * Spad + s) * 64;
-                        dst[base + l31] = f32_to_bf16(v0);
-                        dst[base + 32 + l31] = f32_to_bf16(v1);
+            for (int rq = 0; rq < 4; ++rq) {
+                const int mb = mw + i * 32 + 8 * rq + 4 * half;          // first of 4 consecutive rows, multiple of 4
+                float v0[4], v1[4];
+                int bb[4], ss[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rq * 4 + e;
+                    int mm = mb + e;
+                    mm = mm < M ? mm : M - 1;
+                    bb[e] = mm / S;
+                    ss[e] = mm - bb[e] * S;
+                    v0[e] = acc[i][0][r];
+                    v1[e] = acc[i][1][r];
+                    if (kind & 2) {   // wave-uniform: partial RoPE on d < 32 (pairs d, d^16)
+                        float p = __shfl_xor(v0[e], 16, 64);
+                        int jf = l31 & 15;
+                        float cs = he.rope_cos[ss[e] * 16 + jf], sn = he.rope_sin[ss[e] * 16 + jf];
+                        v0[e] = (l31 < 16) ? (v0[e] * cs - p * sn) : (v0[e] * cs + p * sn);
                     }
+                }
+                if (kind & 1) {
+                    if (mb + 3 < M && bb[0] == bb[3]) {
+                        const int ob = shift ? ((bb[0] * S) & 3) : 0;
+                        const size_t base = ((size_t)(bb[0] * he.heads + head) * 64) * Spad + ss[0] + ob;
+                        bf16x4 p0, p1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            p0[e] = f32_to_bf16(v0[e]);
+                            p1[e] = f32_to_bf16(v1[e]);
+                        }
+                        if (shift) {     // aligned: (ss[0] + ob) % 4 == mb % 4 == 0
+                            *reinterpret_cast<bf16x4*>(dst + base + (size_t)l31 * Spad) = p0;
+                            *reinterpret_cast<bf16x4*>(dst + base + (size_t)(32 + l31) * Spad) = p1;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                dst[base + e + (size_t)l31 * Spad] = p0[e];
+                                dst[base + e + (size_t)(32 + l31) * Spad] = p1[e];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (mb + e < M) {
+                                const int ob = shift ? ((bb[e] * S) & 3) : 0;
+                                const size_t base = ((size_t)(bb[e] * he.heads + head) * 64) * Spad + ss[e] + ob;
+                                dst[base + (size_t)l31 * Spad] = f32_to_bf16(v0[e]);
+                                dst[base + (size_t)(32 + l31) * Spad] = f32_to_bf16(v1[e]);
+                            }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (mb + e < M) {
+                            const int ob = shift ? ((bb[e] * S) & 3) : 0;
+                            const size_t base = ((size_t)(bb[e] * he.heads + head) * Spad + ss[e] + ob) * 64;
+                            dst[base + l31] = f32_to_bf16(v0[e]);
+                            dst[base + 32 + l31] = f32_to_bf16(v1[e]);
+                        }
                 }
             }
     }

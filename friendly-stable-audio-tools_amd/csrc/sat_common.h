@@ -99,7 +99,8 @@ enum { EPI_F32 = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_HEADS = 3 };
 
 struct HeadsEpi {
     bf16_t* out[3];      // per part destination
-    int kind[3];         // bit0: transposed ([B,Hh,64,Spad]) else [B,Hh,Spad,64]; bit1: apply RoPE
+    int kind[3];         // bit0: transposed ([B,Hh,64,Spad]) else [B,Hh,Spad,64]; bit1: apply RoPE;
+                         // bit2: key-side tensor (K / V^T): rows/columns of sequence b shifted by (b*S)&3
     int parts;           // N == parts * heads * 64
     int heads;           // heads per part
     int S;               // valid rows per sequence (row m -> b = m / S, s = m % S)

@@ -200,12 +200,16 @@ int sat_gemm_swiglu_bf16(const void* a_bf16_dev, const float* w_f32_dev, const f
                          void* wpack_dev, float* bpack_dev, void* h_bf16_dev,
                          int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream);
 /* Attention core (models/transformer.py:496-536): q [b,h,sq_pad,64], k [b,kvh,sk_pad,64],
- * vt [b,kvh,64,sk_pad] bf16 -> out [b*sq, h*64] bf16; softmax(q k^T / 8) v, GQA h/kvh. */
+ * vt [b,kvh,64,sk_pad] bf16 -> out [b*sq, h*64] bf16; softmax(q k^T / 8) v, GQA h/kvh.
+ * Key-side layout: the sk keys of sequence i occupy rows (of k) / columns (of vt) [o_i, o_i + sk) with
+ * o_i = (i*sk) & 3; everything outside must be finite (zero).  sq_pad % 128 == 0, sk_pad % 64 == 0,
+ * sk_pad >= sk + 3.  (The shift lets the QKV GEMM epilogue store V^T with aligned 8-byte stores.) */
 int sat_attention_bf16(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
                        int32_t b, int32_t h, int32_t kvh, int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad,
                        sat_stream_t stream);
 /* Fused QKV projection + partial RoPE + head split (models/transformer.py:430-452):
- * a [b*s, d] bf16, w_qkv [3d, d] bf16 -> q,k [b,h,s_pad,64], vt [b,h,64,s_pad] bf16.
+ * a [b*s, d] bf16, w_qkv [3d, d] bf16 -> q,k [b,h,s_pad,64], vt [b,h,64,s_pad] bf16 (k / vt in the key-side
+ * layout of sat_attention_bf16; s_pad % 128 == 0, s_pad >= s + 3).
  * inv_freq_dev [16] fp32 (RotaryEmbedding.inv_freq, models/transformer.py:114-115). */
 int sat_qkv_rope_bf16(const void* a_bf16_dev, const void* w_bf16_dev, const float* inv_freq_dev,
                       void* q_dev, void* k_dev, void* vt_dev, float* rope_scratch_dev,

@@ -84,11 +84,13 @@ def test_gemm_swiglu(dev, variant):
     assert_close("swiglu", out, want, 4e-3)
 
 
-def _pad_heads(x, s_pad):
-    # [B,H,S,64] -> zero-padded [B,H,s_pad,64]
+def _pad_heads(x, s_pad, key_side=False):
+    # [B,H,S,64] -> zero-padded [B,H,s_pad,64]; key-side tensors (K, V) of sequence b start at row (b*S) & 3
     b, h, s, d = x.shape
     out = torch.zeros((b, h, s_pad, d), dtype=x.dtype)
-    out[:, :, :s] = x
+    for i in range(b):
+        ob = (i * s) & 3 if key_side else 0
+        out[i, :, ob:ob + s] = x[i]
     return out
 
 
@@ -103,10 +105,10 @@ def test_attention(dev, b, h, kvh, sq, sk):
     k[0, 0, sk - 1] = q[0, 0, min(5, sq - 1)] * 3
     want = odit._merge(odit.attention_core(q.float(), k.float(), v.float(), rnd=bf16_round))
     sq_pad = (sq + 127) // 128 * 128
-    sk_pad = (sk + 63) // 64 * 64
+    sk_pad = (sk + 3 + 63) // 64 * 64
     qd = _pad_heads(q, sq_pad).to(dev)
-    kd = _pad_heads(k, sk_pad).to(dev)
-    vtd = _pad_heads(v, sk_pad).transpose(2, 3).contiguous().to(dev)
+    kd = _pad_heads(k, sk_pad, key_side=True).to(dev)
+    vtd = _pad_heads(v, sk_pad, key_side=True).transpose(2, 3).contiguous().to(dev)
     out = torch.empty((b * sq, h * 64), dtype=torch.bfloat16, device=dev)
     _hip.check(lib.sat_attention_bf16(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, h, kvh, sq, sk, sq_pad, sk_pad,
                                       _hip.stream()))
@@ -137,9 +139,13 @@ def test_qkv_rope(dev, variant):
     _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd),
                                      _hip.ptr(scratch), b, s, s_pad, d, variant, _hip.stream()))
     assert_close("rope q", qd[:, :, :s], q, 4e-3)
-    assert_close("rope k", kd[:, :, :s], k, 4e-3)
-    assert_close("v^T", vtd[:, :, :, :s], v.transpose(2, 3), 4e-3)
-    assert (qd[:, :, s:] == 0).all() and (vtd[:, :, :, s:] == 0).all(), "pads must be zero"
+    for i in range(b):     # key-side tensors of sequence i start at row/column (i*s) & 3
+        ob = (i * s) & 3
+        assert_close("rope k", kd[i, :, ob:ob + s], k[i], 4e-3)
+        assert_close("v^T", vtd[i, :, :, ob:ob + s], v[i].transpose(1, 2), 4e-3)
+        assert (kd[i, :, :ob] == 0).all() and (kd[i, :, ob + s:] == 0).all(), "K pads must be zero"
+        assert (vtd[i, :, :, :ob] == 0).all() and (vtd[i, :, :, ob + s:] == 0).all(), "V^T pads must be zero"
+    assert (qd[:, :, s:] == 0).all(), "Q pads must be zero"
 
 
 def test_snake_vae_int16(dev):
