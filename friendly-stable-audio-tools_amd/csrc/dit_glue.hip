@@ -74,14 +74,14 @@ __global__ void fold_in_kernel(const float* __restrict__ Win, const float* __res
     for (int j = 0; j < C; ++j) acc += Win[n * C + j] * Wpre[j * C + c];
     Weff[i] = acc;
 }
-// Weff[c][n] = Wout[c][n] + sum_j Wpost[c][j] * Wout[j][n]   ((I + postprocess_conv) o project_out)
-__global__ void fold_out_kernel(const float* __restrict__ Wout, const float* __restrict__ Wpost, float* __restrict__ Weff, int D, int C) {
+// WeffT[n][c] = Wout[c][n] + sum_j Wpost[c][j] * Wout[j][n]   ((I + postprocess_conv) o project_out), stored [D][C]
+__global__ void fold_out_kernel(const float* __restrict__ Wout, const float* __restrict__ Wpost, float* __restrict__ WeffT, int D, int C) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * D) return;
     int c = i / D, n = i - c * D;
     float acc = Wout[i];
     for (int j = 0; j < C; ++j) acc += Wpost[c * C + j] * Wout[j * D + n];
-    Weff[i] = acc;
+    WeffT[(size_t)n * C + c] = acc;
 }
 
 // X[b, 1+t, n] = xscale * sum_c Weff[n][c] * x[b % xB][c][t]       (C <= 64)
@@ -116,31 +116,65 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
     }
 }
 
-// out[b][c][t] = sum_n Weff[c][n] * X[b, 1+t, n] ; one wave per (b,t) row, D % 256 == 0
-template <int NV>
-__global__ __launch_bounds__(256) void output_proj_kernel(const float* __restrict__ X, const float* __restrict__ Weff,
+// out[b][c][t] = sum_n WeffT[n][c] * X[b, 1+t, n].  Lane = output channel (C <= 64): the weight row WeffT[n][:] is one
+// coalesced 256-B read shared by the whole workgroup through L1, x[n] is an LDS broadcast; OP_ROWS rows per wave.
+constexpr int OP_ROWS = 2;
+__global__ __launch_bounds__(256) void output_proj_kernel(const float* __restrict__ X, const float* __restrict__ WeffT,
                                                           float* __restrict__ out, int Bf, int C, int T, int S, int D) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Bf * T) return;
-    const int b = row / T, t = row - b * T;
-    const float4* xr = reinterpret_cast<const float4*>(X + ((size_t)b * S + 1 + t) * D);
-    float4 v[NV];
+    extern __shared__ __attribute__((aligned(16))) char smem_op[];
+    float* xs = reinterpret_cast<float*>(smem_op);          // [4 waves * OP_ROWS][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * OP_ROWS;
+    const int total = Bf * T;
+    float* xw = xs + (size_t)wave * OP_ROWS * D;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
-    float mine = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float4* wr = reinterpret_cast<const float4*>(Weff + (size_t)c * D);
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            float4 w = wr[i * 64 + lane];
-            acc += (w.x * v[i].x + w.y * v[i].y) + (w.z * v[i].z + w.w * v[i].w);
-        }
-        acc = wave_sum(acc);
-        if (lane == c) mine = acc;
+    for (int r = 0; r < OP_ROWS; ++r) {
+        int row = row0 + r;
+        row = row < total ? row : total - 1;
+        const int b = row / T, t = row - b * T;
+        const float4* src = reinterpret_cast<const float4*>(X + ((size_t)b * S + 1 + t) * D);
+        float4* dst = reinterpret_cast<float4*>(xw + (size_t)r * D);
+        for (int i = lane; i < D / 4; i += 64) dst[i] = src[i];
     }
-    if (lane < C) out[((size_t)b * C + lane) * T + t] = mine;
+    __syncthreads();
+    const int c = lane < C ? lane : C - 1;
+    float acc[OP_ROWS];
+#pragma unroll
+    for (int r = 0; r < OP_ROWS; ++r) acc[r] = 0.f;
+    for (int n = 0; n < D; n += 4) {
+        float w0 = WeffT[(size_t)(n + 0) * C + c], w1 = WeffT[(size_t)(n + 1) * C + c];
+        float w2 = WeffT[(size_t)(n + 2) * C + c], w3 = WeffT[(size_t)(n + 3) * C + c];
+#pragma unroll
+        for (int r = 0; r < OP_ROWS; ++r) {
+            float4 xv = *reinterpret_cast<const float4*>(xw + (size_t)r * D + n);
+            acc[r] += (w0 * xv.x + w1 * xv.y) + (w2 * xv.z + w3 * xv.w);
+        }
+    }
+    if (lane < C) {
+#pragma unroll
+        for (int r = 0; r < OP_ROWS; ++r) {
+            int row = row0 + r;
+            if (row < total) {
+                const int b = row / T, t = row - b * T;
+                out[((size_t)b * C + lane) * T + t] = acc[r];
+            }
+        }
+    }
+}
+
+// CFG combine (models/dit.py:338-339) + VDenoiser without the std rescale: pure elementwise, one thread per element
+__global__ __launch_bounds__(256) void cfg_denoise_ew_kernel(const float* __restrict__ mo, const float* __restrict__ x,
+                                                             float* __restrict__ den, int64_t n_per_half, int use_cfg,
+                                                             float cfg_scale, float c_out, float c_skip) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_per_half) return;
+    float vc = mo[i];
+    float g = vc;
+    if (use_cfg) {
+        float vu = mo[i + n_per_half];
+        g = vu + (vc - vu) * cfg_scale;
+    }
+    den[i] = g * c_out + x[i] * c_skip;
 }
 
 // models/dit.py:336-345 (CFG combine + optional std rescale) then VDenoiser:
@@ -290,25 +324,28 @@ int glue_input_proj(const float* x, const float* Weff, float* X, int Bf, int xB,
     return 0;
 }
 
-int glue_output_proj(const float* X, const float* Weff, float* out, int Bf, int C, int T, int S, int D, hipStream_t s) {
-    SAT_CHECK_ARG(C <= 64 && D % 256 == 0 && D / 256 <= 8, SAT_E_UNSUPPORTED, "output_proj: C=%d D=%d unsupported", C, D);
-    dim3 grid(cdiv((int64_t)Bf * T, 4)), block(256);
-    switch (D / 256) {
-        case 1: hipLaunchKernelGGL(output_proj_kernel<1>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
-        case 2: hipLaunchKernelGGL(output_proj_kernel<2>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
-        case 3: hipLaunchKernelGGL(output_proj_kernel<3>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
-        case 4: hipLaunchKernelGGL(output_proj_kernel<4>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
-        case 5: hipLaunchKernelGGL(output_proj_kernel<5>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
-        case 6: hipLaunchKernelGGL(output_proj_kernel<6>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
-        case 7: hipLaunchKernelGGL(output_proj_kernel<7>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
-        default: hipLaunchKernelGGL(output_proj_kernel<8>, grid, block, 0, s, X, Weff, out, Bf, C, T, S, D); break;
+int glue_output_proj(const float* X, const float* WeffT, float* out, int Bf, int C, int T, int S, int D, hipStream_t s) {
+    SAT_CHECK_ARG(C <= 64 && D % 4 == 0, SAT_E_UNSUPPORTED, "output_proj: C=%d D=%d unsupported", C, D);
+    const int lds = 4 * OP_ROWS * D * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(output_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
     }
+    hipLaunchKernelGGL(output_proj_kernel, dim3(cdiv((int64_t)Bf * T, 4 * OP_ROWS)), dim3(256), lds, s, X, WeffT, out, Bf, C, T, S, D);
     SAT_LAUNCH_CHECK();
     return 0;
 }
 
 int glue_cfg_denoise(const float* mo, const float* x, float* den, int B, int C, int T, int use_cfg, float cfg_scale,
                      float scale_phi, float c_out, float c_skip, hipStream_t s) {
+    if (!(use_cfg && scale_phi != 0.0f)) {
+        const int64_t n = (int64_t)B * C * T;
+        hipLaunchKernelGGL(cfg_denoise_ew_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mo, x, den, n, use_cfg, cfg_scale,
+                           c_out, c_skip);
+        SAT_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(cfg_denoise_kernel, dim3(cdiv((int64_t)B * T, 256)), dim3(256), 0, s, mo, x, den, B, C, T, use_cfg,
                        cfg_scale, scale_phi, c_out, c_skip);
     SAT_LAUNCH_CHECK();

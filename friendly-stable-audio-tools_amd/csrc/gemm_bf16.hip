@@ -30,25 +30,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         for (int j = 0; j < NI; ++j) bia[j] = g.bias ? g.bias[nw + j * 32 + l31] : 0.f;
         const bool accum = g.accumulate != 0;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            // residual reads are issued as one batch per 32-row block (32 loads in flight), then added
-            float old[16][NI];
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            for (int rh = 0; rh < 2; ++rh) {
+                // residual reads are issued as one batch per 16-row half block (16 loads in flight), then added
+                float old[8][NI];
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    old[r][j] = (accum && m < M) ? C[(size_t)m * ldc + nw + j * 32 + l31] : 0.f;
-            }
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = rh * 8 + r8;
+                    int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < M) {
+                    for (int j = 0; j < NI; ++j)
+                        old[r8][j] = (accum && m < M) ? C[(size_t)m * ldc + nw + j * 32 + l31] : 0.f;
+                }
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) C[(size_t)m * ldc + nw + j * 32 + l31] = acc[i][j][r] + bia[j] + old[r][j];
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = rh * 8 + r8;
+                    int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < M) {
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) C[(size_t)m * ldc + nw + j * 32 + l31] = acc[i][j][r] + bia[j] + old[r8][j];
+                    }
                 }
             }
-        }
     } else if constexpr (EPI == EPI_SWIGLU) {
         bf16_t* __restrict__ H = g.H;
         const int ldh = N >> 1;
@@ -448,7 +452,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
-    const bool dbg_same = g.variant >= 100;      // micro-benchmark aid: every tile loads tile (0,0) (all L2 hits)
+    const bool dbg_same = g.variant >= 100 && g.variant < 200;   // micro-benchmark aid: every tile loads tile (0,0) (all L2 hits)
+    const bool dbg_noload = g.variant >= 200 && g.variant < 300;  // micro-benchmark aid: no LDS-DMA inside the K loop (wrong results)
+    const bool dbg_nomfma = g.variant >= 300;                     // micro-benchmark aid: no ds_read/MFMA inside the K loop (wrong results)
     const bf16_t* a_ptr[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
@@ -537,8 +543,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     for (int k = 0; k < nk - D; ++k) {
         wait_vmcnt<(D - 1) * LPT>();
         __builtin_amdgcn_s_barrier();
-        stage_in(k + D, wr);
-        compute(rd);
+        if (!dbg_noload) stage_in(k + D, wr);
+        if (!dbg_nomfma) compute(rd);
         rd = (rd + 1 == NS) ? 0 : rd + 1;
         wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
@@ -551,6 +557,187 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
 
     gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM;
+    constexpr int TN = BN / WN;
+    static_assert(TN % 64 == 0, "wave tile is TM x (NJ*64)");
+    constexpr int MI = TM / 32;
+    constexpr int NJ = TN / 64;                    // 64-column spans per wave (one head / one value+gate pair each)
+    constexpr int NI = 2 * NJ;
+    constexpr int CPR = BK / 8;                    // 16-B chunks per row
+    constexpr int A_CH = BM * CPR / NT;
+    constexpr int B_CH = BN * CPR / NT;
+    constexpr int LPT = A_CH + B_CH;               // LDS-DMA instructions per tile per thread
+    constexpr int ROWB = BK * 2;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int D = NS - 1;                      // prefetch distance
+    static_assert(A_CH >= 1 && B_CH >= 1 && (D - 1) * LPT < 64, "bad pipeline geometry");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int M = g.M, N = g.N, K = g.K;
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_n = N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // grouped rasterisation: bands of GM row-tiles swept across N, m fastest inside the band, so the 32 workgroups
+    // an XCD runs concurrently form an 8 x 4 patch that shares 8 A panels + 4 W panels through its L2
+    constexpr int GM = 8;
+    const int band = bid / (GM * tiles_n);
+    const int first_m = band * GM;
+    const int gm_rows = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int local = bid - band * (GM * tiles_n);
+    const int tn = local / gm_rows;
+    const int tm = first_m + (local - tn * gm_rows);
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+
+    const bool dbg_same = g.variant >= 100 && g.variant < 200;   // micro-benchmark aid: every tile loads tile (0,0) (all L2 hits)
+    const bool dbg_noload = g.variant >= 200 && g.variant < 300;  // micro-benchmark aid: no LDS-DMA inside the K loop (wrong results)
+    const bool dbg_nomfma = g.variant >= 300;                     // micro-benchmark aid: no ds_read/MFMA inside the K loop (wrong results)
+    const bf16_t* a_ptr[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        int q = i * NT + tid;
+        int row = q / CPR, pos = q % CPR;
+        int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
+        int gm = (dbg_same ? 0 : m0) + row;
+        gm = gm < M ? gm : M - 1;
+        a_ptr[i] = g.A + (size_t)gm * K + c * 8;
+    }
+    const bf16_t* b_ptr[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        int q = i * NT + tid;
+        int row = q / CPR, pos = q % CPR;
+        int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
+        b_ptr[i] = g.W + (size_t)((dbg_same ? 0 : n0) + row) * K + c * 8;
+    }
+
+    f32x16 acc[NJ][MI][2];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
+
+    auto stage_in = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    // Fragments are double-buffered across the k-steps AND across K-tiles: the ds_reads of the next step are issued
+    // interleaved with the MFMAs of the current one (pinned with sched_group_barrier), and the last step of tile k
+    // prefetches step 0 of tile k+1, so no MFMA ever waits on LDS latency right after a barrier.
+    constexpr int KS = BK / 16;
+    static_assert(KS % 2 == 0, "fragment buffer parity must wrap");
+    bf16x8 af[2][MI], bfr[2][NI];
+    auto frag = [&](int stage, int ks, int buf) {
+        const char* sa = smem + stage * STAGE_BYTES;
+        const char* sb = sa + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            af[buf][i] = *reinterpret_cast<const bf16x8*>(sa + lds_off_bk<BK>(wm * TM + i * 32 + l31, ks * 2 + half));
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            bfr[buf][j] = *reinterpret_cast<const bf16x8*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
+    };
+    auto compute = [&](int stage, int next_stage, bool has_next) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool pre = (ks + 1 < KS) || has_next;
+            if (ks + 1 < KS) frag(stage, ks + 1, (ks + 1) & 1);
+            else if (has_next) frag(next_stage, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[j >> 1][i][j & 1] =
+                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[j >> 1][i][j & 1], 0, 0, 0);
+            if (pre) {
+#pragma unroll
+                for (int r = 0; r < MI + NI; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - (MI + NI), 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
+            }
+        }
+    };
+
+    const int nk = K / BK;
+    // prologue: tiles 0..D-1 in flight (nk >= NS is guaranteed by the launcher)
+#pragma unroll
+    for (int s = 0; s < D; ++s) stage_in(s, s);
+    wait_vmcnt<(D - 1) * LPT>();                 // tile 0 landed (own part) ...
+    __builtin_amdgcn_s_barrier();                // ... and everybody's
+    frag(0, 0, 0);
+    int rd = 0;          // stage of tile k
+    int wr = D;          // stage that receives tile k+D (== stage of tile k-1)
+    // steady state.  Top of iteration k: tile k visible, its step-0 fragments already requested.  Waiting for tile k+1
+    // here (instead of at the top of iteration k+1) is what lets the last k-step prefetch across the tile boundary.
+    for (int k = 0; k < nk - D; ++k) {
+        wait_vmcnt<(D - 2) * LPT>();
+        __builtin_amdgcn_s_barrier();            // tile k+1 visible; everybody is done with stage wr (tile k-1)
+        if (!dbg_noload) stage_in(k + D, wr);
+        const int nx = (rd + 1 == NS) ? 0 : rd + 1;
+        if (!dbg_nomfma) compute(rd, nx, true);
+        rd = nx;
+        wr = (wr + 1 == NS) ? 0 : wr + 1;
+    }
+    // drain: nothing left to issue
+    for (int k = nk - D; k < nk; ++k) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int nx = (rd + 1 == NS) ? 0 : rd + 1;
+        compute(rd, nx, k + 1 < nk);
+        rd = nx;
+    }
+
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) gemm_epilogue<EPI, MI, 2>(g, acc[q], m0 + wm * TM, n0 + wn * TN + q * 64, half, l31);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
+int launch_pipe2(const GemmArgs& a, hipStream_t stream) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int LDS = NS * (BM + BN) * BK * 2;
+    static_assert(LDS <= 160 * 1024 && NS >= 3, "pipe2 needs a >= 3-stage ring within 160 KiB");
+    auto kern = gemm_pipe2_kernel<BM, BN, BK, WM, WN, NS, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
+    SAT_CHECK_ARG(a.K % BK == 0 && a.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
+    int tiles = cdiv(a.M, BM) * (a.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, a);
+    SAT_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
@@ -591,7 +778,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
-    int v = a.variant >= 100 ? a.variant - 100 : a.variant;
+    int v = a.variant % 100;
     if (v == 0) {
         // measured on MI355X (profiles/r01_gemm_variants.txt): the 256x256 tile (16 waves, direct-to-LDS, 2 stages)
         // wins whenever it yields >= ~160 workgroups (FFN-in, QKV at B=1; everything at B>=4); below that the
@@ -625,6 +812,13 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 21: return launch_pipe<256, 256, 32, 4, 4, 3, EPI>(a, stream);
         case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI>(a, stream);
         case 23: return launch_pipe<256, 128, 64, 8, 2, 3, EPI>(a, stream);
+        case 24: return launch_pipe2<256, 256, 32, 2, 4, 3, EPI>(a, stream);
+        case 25: return launch_pipe2<256, 256, 32, 4, 4, 3, EPI>(a, stream);
+        case 26: return launch_pipe2<256, 256, 32, 4, 4, 4, EPI>(a, stream);
+        case 27: return launch_pipe2<128, 128, 64, 4, 2, 3, EPI>(a, stream);
+        case 28: return launch_pipe2<128, 128, 64, 4, 2, 4, EPI>(a, stream);
+        case 29: return launch_pipe2<256, 128, 64, 4, 2, 3, EPI>(a, stream);
+        case 30: return launch_pipe2<256, 256, 32, 4, 2, 4, EPI>(a, stream);
         default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
     }
 }

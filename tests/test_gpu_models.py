@@ -229,3 +229,108 @@ def test_full_size_decoder_vs_reference_golden(dev):
     got = enc.to(dev)(synthetic.synth_input("a_full", (1, 2, 2048 * 16), 2, 0.3).to(dev))
     e2 = assert_close("full-size encode vs reference", got, g["full_encode_T16"], 3e-2)
     print(f"\n[full codec] decode rel-L2 {e:.2e}, encode rel-L2 {e2:.2e} vs the reference's fp32 output")
+
+
+def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
+    """AudioAutoencoder.encode_audio / decode_audio / reconstruct_audio with chunking + Bartlett overlap-add (the
+    reconstruct_audios.py path, autoencoders.py:410-645) and generate_diffusion_cond with init_audio (variation path,
+    generation.py:170-217) against the oracle, VAE noise injected."""
+    from oracle import dit as odit, oobleck as oob, sampler as osamp
+    from stable_audio_tools import synthetic
+    cfg, vae, sd = small_vae
+    ratio = cfg["model"]["downsampling_ratio"]
+    strides = cfg["model"]["decoder"]["config"]["strides"]
+    dsd, esd = _sub(sd, "decoder."), _sub(sd, "encoder.")
+    dec = lambda z: oob.oobleck_decoder(dsd, z, strides=strides, rnd=bf16_round)
+    # chunked decode == oracle chunked decode; and agrees with the un-chunked decode away from the seams
+    z = synthetic.synth_input("zc", (2, 64, 23), 51)
+    got = vae.decode_audio(z.to(dev), chunked=True, chunk_size=8, overlap=2, max_batch_size=3)
+    want = oob.decode_audio_chunked(dec, z, 8, 2, ratio)
+    assert got.shape == want.shape == (2, 2, 23 * ratio)
+    assert_close("decode_audio chunked", got, want, 1e-2)
+    # chunked encode with injected VAE noise: patch the bottleneck's draw through the `noise=` hook per call
+    audio = synthetic.synth_input("ac", (1, 2, 19 * ratio), 52, 0.3)
+    noises = [synthetic.synth_input(f"vn{i}", (2, 64, 8), 60 + i) for i in range(4)]
+    calls = {"i": 0}
+    orig_encode = vae.bottleneck.encode
+
+    def encode_with_noise(x, return_info=False, **kw):
+        nz = noises[calls["i"]][: x.shape[0]].to(x.device)
+        calls["i"] += 1
+        return orig_encode(x, return_info=return_info, noise=nz)
+
+    vae.bottleneck.encode = encode_with_noise
+    try:
+        got = vae.encode_audio(audio.to(dev), chunked=True, chunk_size=8, overlap=2, max_batch_size=2)
+        n_calls = calls["i"]
+        calls["i"] = 0
+        rec = vae.reconstruct_audio(audio.to(dev), chunked=True, chunk_size=8, overlap=2, max_batch_size=2)
+    finally:
+        vae.bottleneck.encode = orig_encode
+    # oracle: same chunk batching (max_batch_size=2) and the same noise per call
+    it = {"i": 0}
+
+    def enc_chunks(chunks):
+        outs = []
+        for i in range(0, len(chunks), 2):
+            grp = torch.cat(chunks[i:i + 2], dim=0)
+            ms = oob.oobleck_encoder(esd, grp, strides=cfg["model"]["encoder"]["config"]["strides"], rnd=bf16_round)
+            outs += list(oob.vae_sample(ms, noises[it["i"]][: grp.shape[0]]).split(1, dim=0))
+            it["i"] += 1
+        return outs
+
+    import math
+    import torch.nn.functional as F
+    cs, hop = 8 * ratio, 6 * ratio
+    n_chunk = int(math.ceil((audio.shape[-1] - cs) / hop)) + 1
+    padded = F.pad(audio, (0, cs + hop * (n_chunk - 1) - audio.shape[-1]))
+    zs = iter(enc_chunks([padded[..., i * hop: i * hop + cs] for i in range(n_chunk)]))
+    want = oob.encode_audio_chunked(lambda c: next(zs), audio, 8, 2, ratio, 64)
+    assert n_calls == it["i"]
+    assert_close("encode_audio chunked", got, want, 1.5e-2)
+    it["i"] = 0
+    n_chunk_r = n_chunk                      # reconstruct pads with hop * n_chunk (reference quirk) but slices n_chunk chunks
+    padded = F.pad(audio, (0, cs + hop * n_chunk_r - audio.shape[-1]))
+    zs2 = enc_chunks([padded[..., i * hop: i * hop + cs] for i in range(n_chunk_r)])
+    outs = iter([dec(zz) for zz in zs2])
+    want = oob.reconstruct_audio_chunked(lambda c, i: next(outs), audio, 8, 2, ratio)
+    assert rec.shape == audio.shape
+    assert_close("reconstruct_audio chunked", rec, want, 2e-2)
+
+    # audio-to-audio (init_audio, init_noise_level): encode -> x = init + noise*sigma_max' -> sample -> latents
+    from stable_audio_tools.inference.generation import generate_diffusion_cond
+    cfgd, model, sdd = small_dit
+    dc = cfgd["model"]["diffusion"]["config"]
+    pr = cfgd["model"]["pretransform"]["config"]
+    ratio_d = pr["downsampling_ratio"]
+    t_len, steps, b = 16, 4, 2
+    init = synthetic.synth_input("init", (2, t_len * ratio_d - 100), 70, 0.3)           # shorter than target: zero-padded
+    prompt = synthetic.synth_input("prompt_a2a", (b, 128, dc["cond_token_dim"]), 71)
+    cond = model.conditioner([{"seconds_start": 0, "seconds_total": 5}] * b)
+    cond["prompt"] = (prompt.to(dev), torch.ones(b, 128, device=dev))
+    cond = {k: cond[k] for k in ("prompt", "seconds_start", "seconds_total")}
+    noise = synthetic.synth_input("noise_a2a", (b, 64, t_len), 72)
+    vnoise = synthetic.synth_input("vn_a2a", (1, 64, t_len), 73)
+    step_noise = [synthetic.synth_input(f"sn_a2a{i}", (b, 64, t_len), 80 + i) for i in range(steps)]
+    itn = iter(step_noise)
+    bn = model.pretransform.model.bottleneck
+    orig = bn.encode
+    bn.encode = lambda x, return_info=False, **kw: orig(x, return_info=return_info, noise=vnoise.to(x.device))
+    try:
+        lat = generate_diffusion_cond(model, steps=steps, cfg_scale=7.0, conditioning_tensors=cond, sample_size=t_len * ratio_d, seed=1,
+                                      device=str(dev), init_audio=(44100, init), init_noise_level=4.0, return_latents=True,
+                                      sampler_type="dpmpp-3m-sde", sigma_min=0.3, sigma_max=500, noise=noise,
+                                      noise_sampler=lambda s, sn: next(itn).to(dev))
+    finally:
+        bn.encode = orig
+    padded = F.pad(init, (0, 100)).unsqueeze(0)
+    esd2 = _sub(sdd, "pretransform.model.encoder.")
+    ms = oob.oobleck_encoder(esd2, padded, strides=pr["encoder"]["config"]["strides"], rnd=bf16_round)
+    z0 = oob.vae_sample(ms, vnoise).repeat(b, 1, 1)
+    ci = model.get_conditioning_inputs(cond)
+    cac, gc = ci["cross_attn_cond"].cpu().float(), ci["global_cond"].cpu().float()
+    sig = osamp.get_sigmas_polyexponential(steps, 0.3, 4.0, 1.0)          # sigma_max <- init_noise_level (generation.py:214-217)
+    dsd2 = _sub(sdd, "model.model.")
+    fn = lambda xin, tt: odit.dit_forward(dsd2, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
+    want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), z0 + noise * sig[0], sig, lambda i, s, sn: step_noise[i])
+    assert_close("audio-to-audio latents", lat, want, 2e-2)
