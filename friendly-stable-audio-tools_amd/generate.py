@@ -1,0 +1,134 @@
+"""Counterpart of the reference's ``generate.py`` (:23-153): YAML condition tree -> prompts (x n_sample_per_cond)
+-> rank-strided shards -> ``generate_diffusion_cond`` -> int16 WAV per item.
+
+Same flags as the reference plus what an offline MI355X box needs:
+  --model-config / --ckpt-path   instead of the Hugging Face download of --model-name
+  --synthetic-weights SEED       random-init weights of the configured architecture (benchmarks)
+  --text-embeds random           T5/CLAP encoders are out of scope for this build: the "prompt" entry of the
+                                 conditioning is a seed-from-text Gaussian embedding [128, cond_dim]
+Launch with ``python -m torch.distributed.run --nproc-per-node N generate.py ...`` for N GPUs: one process per GPU,
+full replica each, prompts ``items[rank::world]``, every rank writes its own files (as the reference does).
+"""
+import argparse
+import hashlib
+import json
+import math
+import os
+from pathlib import Path
+
+import torch
+import yaml
+
+from stable_audio_tools import create_model_from_config, get_pretrained_model, model_configs
+from stable_audio_tools.inference.generation import generate_diffusion_cond
+from stable_audio_tools.models.utils import load_ckpt_state_dict
+from stable_audio_tools.utils.audio_utils import float_to_int16_audio
+from stable_audio_tools.utils.torch_common import copy_state_dict, count_parameters, get_rank, get_world_size
+from stable_audio_tools.utils.wav_io import save_wav_int16
+
+
+def get_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--output-dir", type=str, required=True)
+    p.add_argument("--cond-yaml-path", type=str, required=True)
+    p.add_argument("--model-name", type=str, default=None, help="HF model name (needs network), e.g. stabilityai/stable-audio-open-1.0")
+    p.add_argument("--model-config", type=str, default=None, help="model config json; default: the built-in SA-Open-1.0 shape")
+    p.add_argument("--ckpt-path", type=str, default=None)
+    p.add_argument("--synthetic-weights", type=int, default=None, metavar="SEED")
+    p.add_argument("--text-embeds", choices=["random"], default="random")
+    p.add_argument("--sampler-type", type=str, default="dpmpp-3m-sde")
+    p.add_argument("--sample-steps", type=int, default=100)
+    p.add_argument("--cfg-scale", type=float, default=7.0)
+    p.add_argument("--n-sample-per-cond", type=int, default=1)
+    p.add_argument("--batch-size", type=int, default=10)
+    p.add_argument("--clip-length", action="store_true")
+    p.add_argument("--seed", type=int, default=-1)
+    return p.parse_args()
+
+
+def flatten_conditions(tree, parent="", sep="/"):
+    """Nested {group: {...: {name: {prompt:..., seconds_start:..., seconds_total:...}}}} -> {"group/.../name": cond}
+    (reference generate.py:38-50: inner-most dicts are the conditions; at least two levels)."""
+    out = {}
+    for key, val in tree.items():
+        assert isinstance(val, dict), "the condition file is a tree of dicts"
+        path = f"{parent}{sep}{key}" if parent else key
+        if all(not isinstance(v, dict) for v in val.values()):
+            assert parent, "conditions must sit at least one level below the root"
+            out[path] = dict(val)
+        else:
+            assert all(isinstance(v, dict) for v in val.values()), "a level mixes conditions and sub-trees"
+            out.update(flatten_conditions(val, path, sep))
+    return out
+
+
+def text_embedding(prompt: str, dim: int, tokens: int = 128):
+    seed = int.from_bytes(hashlib.sha256(prompt.encode()).digest()[:7], "little")
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(tokens, dim, generator=g)
+
+
+def main():
+    args = get_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)      # RCCL; only rank/world bookkeeping is used
+    rank, world = get_rank(), get_world_size()
+
+    if args.model_name:
+        model, model_config = get_pretrained_model(args.model_name)
+    else:
+        model_config = json.load(open(args.model_config)) if args.model_config else model_configs.stable_audio_open_1_0()
+        if args.model_config:     # text encoders are supplied as embeddings
+            cc = model_config["model"]["conditioning"]["configs"]
+            model_config["model"]["conditioning"]["configs"] = [c for c in cc if c["type"] in ("number", "int")]
+        model = create_model_from_config(model_config)
+        if args.ckpt_path:
+            copy_state_dict(model, load_ckpt_state_dict(args.ckpt_path))
+        elif args.synthetic_weights is not None:
+            from stable_audio_tools import synthetic
+            model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), args.synthetic_weights))
+    sample_rate, sample_size = model_config["sample_rate"], model_config["sample_size"]
+    model = model.to(device).eval()
+    cond_dim = model_config["model"]["conditioning"]["cond_dim"]
+
+    conds = flatten_conditions(yaml.safe_load(open(args.cond_yaml_path)))
+    paths, items = [], []
+    for p, c in conds.items():
+        for i in range(args.n_sample_per_cond):
+            paths.append(f"{p}_item-{i + 1}")
+            items.append(c)
+    if rank == 0:
+        print(f"=== model: diffusion {count_parameters(model.model) / 1e6:.3f} M params, sample size {sample_size} "
+              f"({sample_size / sample_rate:.3f} s), {len(conds)} prompts x {args.n_sample_per_cond}, {world} rank(s)")
+    paths, items = paths[rank::world], items[rank::world]                   # reference generate.py:119-120
+    batch = max(args.batch_size // 2, 1) if args.cfg_scale != 1.0 else args.batch_size   # generate.py:75
+
+    for i in range(int(math.ceil(len(items) / batch))):
+        p_i, c_i = paths[i * batch:(i + 1) * batch], items[i * batch:(i + 1) * batch]
+        cond = model.conditioner(c_i)
+        if "prompt" not in cond:
+            emb = torch.stack([text_embedding(str(c["prompt"]), cond_dim) for c in c_i]).to(device)
+            cond["prompt"] = (emb, torch.ones(len(c_i), emb.shape[1], device=device))
+        order = model.cross_attn_cond_ids + [k for k in cond if k not in model.cross_attn_cond_ids]
+        cond = {k: cond[k] for k in order if k in cond}
+        audio = generate_diffusion_cond(model, steps=args.sample_steps, cfg_scale=args.cfg_scale, conditioning_tensors=cond,
+                                        sample_size=sample_size, sigma_min=0.3, sigma_max=500, sampler_type=args.sampler_type,
+                                        device=str(device), seed=args.seed)
+        for n in range(audio.shape[0]):
+            pcm = float_to_int16_audio(audio[n])
+            if args.clip_length:
+                pcm = pcm[:, : int(c_i[n]["seconds_total"] * sample_rate)]
+            out = Path(args.output_dir) / f"{p_i[n]}.wav"
+            out.parent.mkdir(parents=True, exist_ok=True)
+            save_wav_int16(out, pcm, sample_rate)
+    print(f"->->-> Rank-{rank}: Finished.")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

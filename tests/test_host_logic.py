@@ -161,3 +161,29 @@ def test_utils_and_file_scan(tmp_path):
     found = sorted(os.path.relpath(f, tmp_path) for f in get_audio_filenames(str(tmp_path)))
     assert found == ["a/drums_loop.mp3", "a/y.FLAC", "x.wav"]
     assert [os.path.basename(f) for f in get_audio_filenames([str(tmp_path)], keywords=["DRUMS"])] == ["drums_loop.mp3"]
+
+
+def test_scripts_host_side(tmp_path):
+    """generate.py condition-tree flattening (reference generate.py:38-50) and the stdlib WAV round trip."""
+    import importlib.util
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "friendly-stable-audio-tools_amd")
+    spec = importlib.util.spec_from_file_location("sat_generate", os.path.join(pkg, "generate.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    tree = {"drums": {"funk": {"prompt": "funk break", "seconds_start": 0, "seconds_total": 8},
+                      "sub": {"slow": {"prompt": "slow", "seconds_start": 0, "seconds_total": 20}}},
+            "pads": {"warm": {"prompt": "warm pad", "seconds_start": 0, "seconds_total": 30}}}
+    flat = gen.flatten_conditions(tree)
+    assert list(flat) == ["drums/funk", "drums/sub/slow", "pads/warm"] and flat["pads/warm"]["seconds_total"] == 30
+    with pytest.raises(AssertionError):
+        gen.flatten_conditions({"prompt": "x"})
+    e1, e2 = gen.text_embedding("a", 768), gen.text_embedding("a", 768)
+    assert e1.shape == (128, 768) and torch.equal(e1, e2) and not torch.equal(e1, gen.text_embedding("b", 768))
+    from stable_audio_tools.utils.wav_io import load_wav, save_wav_float, save_wav_int16
+    pcm = torch.randint(-32768, 32767, (2, 1000), dtype=torch.int32).to(torch.int16)
+    save_wav_int16(tmp_path / "a.wav", pcm, 44100)
+    back, sr = load_wav(tmp_path / "a.wav")
+    assert sr == 44100 and back.shape == (2, 1000) and torch.equal((back * 32768).round().to(torch.int16), pcm)
+    save_wav_float(tmp_path / "b.wav", torch.tensor([[0.5, -2.0, 1.0]]), 8000)
+    b, sr = load_wav(tmp_path / "b.wav")
+    assert sr == 8000 and torch.allclose(b, torch.tensor([[0.5, -1.0, 1.0]]), atol=1e-4)
