@@ -24,7 +24,7 @@ namespace {
 constexpr int KV_TILE = 64;
 constexpr int Q_BLOCK = 128;
 
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                         int H, int KVH, int Sq, int Sk, int Sq_pad, int Sk_pad,
                                                         float scale_log2) {
@@ -106,18 +106,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         const char* sk = smem + cur * (2 * KV_TILE * 128);
         const char* sv = sk + KV_TILE * 128;
 
-        // ---- S^T = K Q^T : two 32-key blocks
+        // ---- S^T = K Q^T : two 32-key blocks.  All 8 K fragments are requested up front so that the MFMAs never
+        // wait on a just-issued ds_read.
+        bf16x8 kf[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                kf[kb][t] = *reinterpret_cast<const bf16x8*>(sk + lds_tile_off(kb * 32 + l31, t * 2 + half));
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(sk + lds_tile_off(kb * 32 + l31, t * 2 + half));
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[t], sacc[kb], 0, 0, 0);
-            }
+            for (int t = 0; t < 4; ++t) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][t], qf[t], sacc[kb], 0, 0, 0);
         }
+        // V^T fragments do not depend on the softmax: request them now, their LDS latency hides behind the VALU work
+        bf16x8 vf[2][4];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int ku = 0; ku < 4; ++ku)
+                vf[db][ku] = *reinterpret_cast<const bf16x8*>(sv + lds_tile_off(db * 32 + l31, ku * 2 + half));
+        __builtin_amdgcn_sched_barrier(0);
         // ---- mask the columns outside [ob, ob + Sk) (wave-uniform branch: first and last tile only)
         if ((tile == 0 && ob != 0) || (tile == n_tiles - 1 && (k_end & (KV_TILE - 1)) != 0)) {
             const int key0 = tile * KV_TILE + 4 * half;
@@ -162,11 +175,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    bf16x8 a = *reinterpret_cast<const bf16x8*>(sv + lds_tile_off(db * 32 + l31, (kb * 2 + u) * 2 + half));
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[kb][u], oacc[db], 0, 0, 0);
-                }
-
+                for (int u = 0; u < 2; ++u)
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][kb * 2 + u], pb[kb][u], oacc[db], 0, 0, 0);
     };
     for (int tile = 0; tile < n_tiles - 1; ++tile) {
         gload(tile + 1);
