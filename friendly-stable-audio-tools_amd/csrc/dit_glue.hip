@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
 
 // out[b][c][t] = sum_n WeffT[n][c] * X[b, 1+t, n].  Lane = output channel (C <= 64): the weight row WeffT[n][:] is one
 // coalesced 256-B read shared by the whole workgroup through L1, x[n] is an LDS broadcast; OP_ROWS rows per wave.
-constexpr int OP_ROWS = 2;
+constexpr int OP_ROWS = 1;
 __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restrict__ X, const float* __restrict__ WeffT,
                                                           float* __restrict__ out, int Bf, int C, int T, int S, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem_op[];
@@ -141,13 +141,18 @@ __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restric
     float acc[OP_ROWS];
 #pragma unroll
     for (int r = 0; r < OP_ROWS; ++r) acc[r] = 0.f;
-    for (int n = 0; n < D; n += 4) {
-        float w0 = WeffT[(size_t)(n + 0) * C + c], w1 = WeffT[(size_t)(n + 1) * C + c];
-        float w2 = WeffT[(size_t)(n + 2) * C + c], w3 = WeffT[(size_t)(n + 3) * C + c];
+    // 16 independent weight loads in flight per lane (the loop is L2-latency bound otherwise)
+    for (int n = 0; n < D; n += 16) {
+        float w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = WeffT[(size_t)(n + u) * C + c];
 #pragma unroll
         for (int r = 0; r < OP_ROWS; ++r) {
-            float4 xv = *reinterpret_cast<const float4*>(xw + (size_t)r * D + n);
-            acc[r] += (w0 * xv.x + w1 * xv.y) + (w2 * xv.z + w3 * xv.w);
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                float4 xv = *reinterpret_cast<const float4*>(xw + (size_t)r * D + n + u4 * 4);
+                acc[r] += (w[u4 * 4] * xv.x + w[u4 * 4 + 1] * xv.y) + (w[u4 * 4 + 2] * xv.z + w[u4 * 4 + 3] * xv.w);
+            }
         }
     }
     if (lane < C) {
@@ -325,7 +330,7 @@ int glue_input_proj(const float* x, const float* Weff, float* X, int Bf, int xB,
 }
 
 int glue_output_proj(const float* X, const float* WeffT, float* out, int Bf, int C, int T, int S, int D, hipStream_t s) {
-    SAT_CHECK_ARG(C <= 64 && D % 4 == 0, SAT_E_UNSUPPORTED, "output_proj: C=%d D=%d unsupported", C, D);
+    SAT_CHECK_ARG(C <= 64 && D % 16 == 0, SAT_E_UNSUPPORTED, "output_proj: C=%d D=%d unsupported", C, D);
     const int lds = 4 * OP_ROWS * D * 4;
     static bool attr_set = false;
     if (!attr_set) {

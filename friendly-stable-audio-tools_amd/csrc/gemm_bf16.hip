@@ -410,7 +410,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
+// DBG (micro-benchmark ablations, wrong results): 0 production; 1 all tiles load tile (0,0); 2 no LDS-DMA in the loop;
+// 3 no ds_read/MFMA; 4 = 2 + no barrier; 5 = 4 + no ds_read (MFMA on register-resident fragments)
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
@@ -452,9 +454,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
-    const bool dbg_same = g.variant >= 100 && g.variant < 200;   // micro-benchmark aid: every tile loads tile (0,0) (all L2 hits)
-    const bool dbg_noload = g.variant >= 200 && g.variant < 300;  // micro-benchmark aid: no LDS-DMA inside the K loop (wrong results)
-    const bool dbg_nomfma = g.variant >= 300;                     // micro-benchmark aid: no ds_read/MFMA inside the K loop (wrong results)
+    constexpr bool dbg_same = DBG == 1;
+    constexpr bool dbg_noload = DBG == 2 || DBG >= 4;
+    constexpr bool dbg_nomfma = DBG == 3;
+    constexpr bool dbg_nobar = DBG >= 4;
+    constexpr bool dbg_nolds = DBG >= 5;
     const bf16_t* a_ptr[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
@@ -540,11 +544,32 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     int rd = 0;          // stage of tile k
     int wr = D;          // stage that receives tile k+D (== stage of tile k-1)
     // steady state: tiles k+1..k+D-1 stay in flight across the barrier
-    for (int k = 0; k < nk - D; ++k) {
-        wait_vmcnt<(D - 1) * LPT>();
+    bf16x8 fa0[MI], fb0[NI];       // ablation only: fragments that stay in registers
+    if constexpr (dbg_nolds) {
+        wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (!dbg_noload) stage_in(k + D, wr);
-        if (!dbg_nomfma) compute(rd);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(smem + lds_off_bk<BK>(wm * TM + i * 32 + l31, half));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) fb0[j] = *reinterpret_cast<const bf16x8*>(smem + BM * ROWB + lds_off_bk<BK>(wn * TN + j * 32 + l31, half));
+    }
+    for (int k = 0; k < nk - D; ++k) {
+        if constexpr (!dbg_nobar) {
+            wait_vmcnt<(D - 1) * LPT>();
+            __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (!dbg_noload) stage_in(k + D, wr);
+        if constexpr (dbg_nolds) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+        } else if constexpr (!dbg_nomfma) {
+            compute(rd);
+        }
         rd = (rd + 1 == NS) ? 0 : rd + 1;
         wr = (wr + 1 == NS) ? 0 : wr + 1;
     }
@@ -603,9 +628,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
-    const bool dbg_same = g.variant >= 100 && g.variant < 200;   // micro-benchmark aid: every tile loads tile (0,0) (all L2 hits)
-    const bool dbg_noload = g.variant >= 200 && g.variant < 300;  // micro-benchmark aid: no LDS-DMA inside the K loop (wrong results)
-    const bool dbg_nomfma = g.variant >= 300;                     // micro-benchmark aid: no ds_read/MFMA inside the K loop (wrong results)
+    constexpr bool dbg_same = false, dbg_noload = false, dbg_nomfma = false;
     const bf16_t* a_ptr[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
@@ -740,12 +763,12 @@ int launch_pipe2(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
     constexpr int LDS = NS * (BM + BN) * BK * 2;
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
-    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI>;
+    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -778,13 +801,31 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
-    int v = a.variant % 100;
+    if (a.variant >= 100) {   // micro-benchmark ablations (tools/gpu_probe.py), EPI_F32 only
+        if constexpr (EPI == EPI_F32) {
+            switch (a.variant) {
+                case 122: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 1>(a, stream);
+                case 222: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 2>(a, stream);
+                case 322: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 3>(a, stream);
+                case 422: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 4>(a, stream);
+                case 522: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 5>(a, stream);
+                case 213: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 2>(a, stream);
+                case 413: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 4>(a, stream);
+                case 513: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 5>(a, stream);
+                case 415: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 4>(a, stream);
+                case 515: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 5>(a, stream);
+            }
+        }
+        sat_set_error("gemm: unknown ablation variant %d", a.variant);
+        return SAT_E_INVALID;
+    }
+    int v = a.variant;
     if (v == 0) {
         // measured on MI355X (profiles/r01_gemm_variants.txt): the 256x256 tile (16 waves, direct-to-LDS, 2 stages)
         // wins whenever it yields >= ~160 workgroups (FFN-in, QKV at B=1; everything at B>=4); below that the
         // 128x128 tile with 8 waves and a 3-stage ring fills more CUs (to_out / FFN-out at B=1: 204 vs 54 workgroups).
         long t256 = (long)cdiv(a.M, 256) * (a.N / 256);
-        if (a.N % 256 == 0 && t256 >= 160 && a.K >= 128) v = 22;
+        if (a.N % 256 == 0 && t256 >= 160 && a.K >= 128) v = (cdiv(a.M, 256) > 16) ? 26 : 22;   // 26: grouped raster + 4-stage ring (large M)
         else if (a.K >= 192) v = 15;
         else v = 5;
     }
@@ -818,7 +859,6 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 27: return launch_pipe2<128, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 28: return launch_pipe2<128, 128, 64, 4, 2, 4, EPI>(a, stream);
         case 29: return launch_pipe2<256, 128, 64, 4, 2, 3, EPI>(a, stream);
-        case 30: return launch_pipe2<256, 256, 32, 4, 2, 4, EPI>(a, stream);
         default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
     }
 }
