@@ -453,6 +453,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
     const int m0 = tm * BM;
     const int n0 = tn * BN;
+    // waves whose TM rows lie entirely beyond M (the M-tail tile: 2 valid rows of 256 at B=1) keep staging tiles and
+    // joining barriers but skip their LDS reads, MFMAs and epilogue
+    const bool wave_rows_valid = (m0 + wm * TM) < M;
 
     constexpr bool dbg_same = DBG == 1;
     constexpr bool dbg_noload = DBG == 2 || DBG >= 4;
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                     for (int j = 0; j < NI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
         } else if constexpr (!dbg_nomfma) {
-            compute(rd);
+            if (wave_rows_valid) compute(rd);
         }
         rd = (rd + 1 == NS) ? 0 : rd + 1;
         wr = (wr + 1 == NS) ? 0 : wr + 1;
@@ -577,11 +580,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     for (int k = nk - D; k < nk; ++k) {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        compute(rd);
+        if (wave_rows_valid) compute(rd);
         rd = (rd + 1 == NS) ? 0 : rd + 1;
     }
 
-    gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+    if (wave_rows_valid) gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>

@@ -46,7 +46,7 @@ def gemm_bench():
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
-        for v in (22, 26, 30, 31, 32, 33):
+        for v in (22, 15, 7, 5):
             if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26, 30, 31, 32) and n % 256:
                 continue
             f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
