@@ -404,12 +404,6 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
     else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 // DBG (micro-benchmark ablations, wrong results): 0 production; 1 all tiles load tile (0,0); 2 no LDS-DMA in the loop;
 // 3 no ds_read/MFMA; 4 = 2 + no barrier; 5 = 4 + no ds_read (MFMA on register-resident fragments)
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>

@@ -43,11 +43,65 @@ struct ConvArgs {
     long long out_limit;
     float* out_cf;           // channel-first fp32 output [B][cf_channels][M] (final convs) or null
     int cf_channels;
+    const bf16_t* zero_page; // >= 128 B of zeros: LDS-DMA source of the rows that fall into the conv padding
 };
 
 __device__ __forceinline__ float snake_f(float v, float a, float ib) {
     float s = __sinf(v * a);
     return v + ib * (s * s);
+}
+
+template <int MI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& g, f32x16 (&acc)[MI][2], const int mw, const int nw, const int b,
+                                              const int half, const int l31) {
+    constexpr int NI = 2;
+    // ---- epilogue.  acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31
+    float bia[NI], sa_[NI], sib[NI];
+    int nn[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        nn[j] = nw + j * 32 + l31;
+        int co = nn[j] % g.Cout;
+        bia[j] = g.bias ? g.bias[co] : 0.f;
+        sa_[j] = g.out_snk ? g.sn_a[co] : 0.f;
+        sib[j] = g.out_snk ? g.sn_ib[co] : 0.f;
+    }
+    if (g.out_cf) {
+        float* __restrict__ o = g.out_cf + (size_t)b * g.cf_channels * g.M;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < g.M) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        if (nn[j] < g.cf_channels) o[(size_t)nn[j] * g.M + m] = acc[i][j][r] + bia[j];
+                }
+            }
+        return;
+    }
+    const bf16_t* res = g.res ? g.res + (size_t)b * g.out_bstride : nullptr;
+    bf16_t* oraw = g.out_raw ? g.out_raw + (size_t)b * g.out_bstride : nullptr;
+    bf16_t* __restrict__ osnk = g.out_snk ? g.out_snk + (size_t)b * g.out_bstride : nullptr;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < g.M) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    long long flat = (long long)m * g.N + g.out_shift + nn[j];
+                    if (flat >= 0 && flat < g.out_limit) {
+                        float v = acc[i][j][r] + bia[j];
+                        if (res) v += bf16_to_f32(res[flat]);
+                        if (oraw) oraw[flat] = f32_to_bf16(v);
+                        if (osnk) osnk[flat] = f32_to_bf16(snake_f(v, sa_[j], sib[j]));
+                    }
+                }
+            }
+        }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -165,55 +219,144 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_kernel(ConvArgs g) {
     }
     compute((nk - 1) & 1);
 
-    // ---- epilogue.  acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31
-    const int mw = m0 + wm * TM;
-    const int nw = n0 + wn * TN;
-    float bia[NI], sa_[NI], sib[NI];
-    int nn[NI];
+    conv_epilogue<MI>(g, acc, m0 + wm * TM, n0 + wn * TN, b, half, l31);
+}
+
+// Direct-to-LDS, deep-prefetch variant of conv_kernel (same structure as gemm_pipe_kernel in gemm_bf16.hip): LDS-DMA
+// (global_load_lds_dwordx4) into an NS-stage ring, counted vmcnt, one raw barrier per K-tile, 8 waves, MFMA/ds_read
+// interleave pinned.  Rows that fall into the conv zero padding are fetched from a zero page (an LDS-DMA cannot
+// write an immediate); the XOR swizzle is folded into the per-lane source address.
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void conv_pipe_kernel(ConvArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM;
+    constexpr int TN = BN / WN;
+    static_assert(TN == 64, "wave tile is TM x 64");
+    constexpr int MI = TM / 32;
+    constexpr int NI = 2;
+    constexpr int A_CH = BM * 8 / NT;
+    constexpr int B_CH = BN * 8 / NT;
+    constexpr int LPT = A_CH + B_CH;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int D = NS - 1;
+    static_assert(A_CH >= 1 && B_CH >= 1 && (D > 0) && (D - 1) * LPT < 64, "bad pipeline geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int tiles_n = g.N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n;
+    const int tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int Cin = g.Cin, Tin = g.Tin;
+    const int cpt = Cin >> 6;
+    const int nk = g.taps * cpt;
+    const bf16_t* __restrict__ inb = g.in + (size_t)b * Tin * Cin;
+
+    int a_m[A_CH], a_coff[A_CH];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        nn[j] = nw + j * 32 + l31;
-        int co = nn[j] % g.Cout;
-        bia[j] = g.bias ? g.bias[co] : 0.f;
-        sa_[j] = g.out_snk ? g.sn_a[co] : 0.f;
-        sib[j] = g.out_snk ? g.sn_ib[co] : 0.f;
+    for (int i = 0; i < A_CH; ++i) {
+        int q = i * NT + tid;
+        int row = q >> 3, pos = q & 7;
+        a_m[i] = (m0 + row) * g.stride;
+        a_coff[i] = (pos ^ ((row >> 1) & 7)) * 8;
     }
-    if (g.out_cf) {
-        float* __restrict__ o = g.out_cf + (size_t)b * g.cf_channels * g.M;
+    int b_off[B_CH];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < g.M) {
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        if (nn[j] < g.cf_channels) o[(size_t)nn[j] * g.M + m] = acc[i][j][r] + bia[j];
-                }
-            }
-        return;
+    for (int i = 0; i < B_CH; ++i) {
+        int q = i * NT + tid;
+        int row = q >> 3, pos = q & 7;
+        b_off[i] = row * Cin + (pos ^ ((row >> 1) & 7)) * 8;
     }
-    const bf16_t* res = g.res ? g.res + (size_t)b * g.out_bstride : nullptr;
-    bf16_t* oraw = g.out_raw ? g.out_raw + (size_t)b * g.out_bstride : nullptr;
-    bf16_t* __restrict__ osnk = g.out_snk ? g.out_snk + (size_t)b * g.out_bstride : nullptr;
+
+    f32x16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < g.M) {
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    long long flat = (long long)m * g.N + g.out_shift + nn[j];
-                    if (flat >= 0 && flat < g.out_limit) {
-                        float v = acc[i][j][r] + bia[j];
-                        if (res) v += bf16_to_f32(res[flat]);
-                        if (oraw) oraw[flat] = f32_to_bf16(v);
-                        if (osnk) osnk[flat] = f32_to_bf16(snake_f(v, sa_[j], sib[j]));
-                    }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto stage_in = [&](int kt, int stage) {
+        const int tap = kt / cpt;
+        const int ci0 = (kt - tap * cpt) << 6;
+        const int off = g.off0 + tap * g.doff;
+        char* sa = smem + stage * STAGE_BYTES;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int r = a_m[i] + off;
+            const bf16_t* src = (r >= 0 && r < Tin) ? inb + (size_t)r * Cin + ci0 + a_coff[i] : g.zero_page + a_coff[i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
+        }
+        const bf16_t* wt = g.W + ((size_t)tap * g.N + n0) * Cin + ci0;
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + b_off[i]),
+                                             (__attribute__((address_space(3))) void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE_BYTES;
+        const char* sb = sa + BM * 128;
+        bf16x8 af[2][MI], bfr[2][NI];
+        auto frag = [&](int ks, int buf) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[buf][i] = *reinterpret_cast<const bf16x8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                bfr[buf][j] = *reinterpret_cast<const bf16x8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+        };
+        frag(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) frag(ks + 1, (ks + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < 4) {
+                constexpr int NR = MI + NI, NM = MI * NI;
+#pragma unroll
+                for (int r = 0; r < (NR < NM ? NR : NM); ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+                if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x8, NM - NR, 0);
+                if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
             }
         }
+    };
+
+#pragma unroll
+    for (int s = 0; s < D; ++s) stage_in(s, s);       // nk >= D guaranteed by the launcher
+    int rd = 0, wr = D;
+    for (int k = 0; k < nk - D; ++k) {
+        wait_vmcnt<(D - 1) * LPT>();
+        __builtin_amdgcn_s_barrier();
+        stage_in(k + D, wr);
+        compute(rd);
+        rd = (rd + 1 == NS) ? 0 : rd + 1;
+        wr = (wr + 1 == NS) ? 0 : wr + 1;
+    }
+    for (int k = nk - D; k < nk; ++k) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        compute(rd);
+        rd = (rd + 1 == NS) ? 0 : rd + 1;
+    }
+    conv_epilogue<MI>(g, acc, m0 + wm * TM, n0 + wn * TN, b, half, l31);
 }
 
 // z [B][C][T] fp32 (channel-first) -> [B][T][C] bf16
@@ -317,30 +460,31 @@ __global__ void snake_params_kernel(const float* __restrict__ alpha, const float
     ib[i] = 1.0f / (expf(beta[i]) + 0.000000001f);
 }
 
+template <int BM, int BN, int WM, int WN, int NS>
+int launch_conv_cfg(const ConvArgs& a, int B, hipStream_t s) {
+    constexpr int LDS = NS * (BM + BN) * 128;
+    auto kern = conv_pipe_kernel<BM, BN, WM, WN, NS>;
+    static bool set = false;
+    if (!set) {
+        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, BM) * (a.N / BN), B), dim3(WM * WN * 64), LDS, s, a);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_conv(const ConvArgs& a, int B, hipStream_t s) {
     SAT_CHECK_ARG(a.Cin % 64 == 0, SAT_E_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", a.Cin);
     SAT_CHECK_ARG(a.N % 64 == 0, SAT_E_UNSUPPORTED, "conv: N=%d must be a multiple of 64", a.N);
+    SAT_CHECK_ARG(a.zero_page != nullptr, SAT_E_STATE, "conv: zero page missing");
+    const int nk = a.taps * (a.Cin / 64);
     if (a.N % 128 == 0) {
-        constexpr int BM = 128, BN = 128, LDS = 2 * (BM + BN) * 128;
-        auto kern = conv_kernel<BM, BN, 2, 2>;
-        static bool set = false;
-        if (!set) {
-            SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(cdiv(a.M, BM) * (a.N / BN), B), dim3(256), LDS, s, a);
-    } else {
-        constexpr int BM = 256, BN = 64, LDS = 2 * (BM + BN) * 128;
-        auto kern = conv_kernel<BM, BN, 4, 1>;
-        static bool set = false;
-        if (!set) {
-            SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-            set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(cdiv(a.M, BM) * (a.N / BN), B), dim3(256), LDS, s, a);
+        if (nk >= 3) return launch_conv_cfg<128, 128, 4, 2, 3>(a, B, s);
+        return launch_conv_cfg<128, 128, 4, 2, 2>(a, B, s);
     }
-    SAT_LAUNCH_CHECK();
-    return 0;
+    if (nk >= 3) return launch_conv_cfg<256, 64, 8, 1, 3>(a, B, s);
+    return launch_conv_cfg<256, 64, 8, 1, 2>(a, B, s);
 }
 
 struct Snake {
@@ -350,6 +494,7 @@ struct ConvW {
     bf16_t* W = nullptr;
     float* bias = nullptr;
     int Cin = 0, Cout = 0, taps = 0, N = 0;
+    const bf16_t* zero = nullptr;   // the plan's zero page (LDS-DMA source for padding rows)
 };
 
 }  // namespace
@@ -373,6 +518,7 @@ struct sat_oobleck_plan {
     };
     std::vector<Block> blocks;
     Snake final_snake;
+    bf16_t* zero_page = nullptr;
 };
 
 namespace {
@@ -413,7 +559,7 @@ int make_snake(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int C, Sn
 int make_conv(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, int Cout, int k, bool has_bias, ConvW* cw,
               hipStream_t s, float** w_f32 = nullptr) {
     const int Npad = (int)round_up(Cout, 64);
-    cw->Cin = Cin; cw->Cout = Cout; cw->taps = k; cw->N = Npad;
+    cw->Cin = Cin; cw->Cout = Cout; cw->taps = k; cw->N = Npad; cw->zero = p->zero_page;
     float* scale = (float*)ar.take((size_t)Cout * 4);
     if (w_f32) *w_f32 = (float*)ar.take((size_t)Cout * Cin * k * 4);
     else cw->W = (bf16_t*)ar.take((size_t)k * Npad * Cin * 2);
@@ -440,7 +586,7 @@ int make_conv(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, i
 
 // ConvTranspose1d weight [Cin][Cout][2s]
 int make_convT(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, int Cout, int stride, ConvW* cw, hipStream_t s) {
-    cw->Cin = Cin; cw->Cout = Cout; cw->taps = 2; cw->N = stride * Cout;
+    cw->Cin = Cin; cw->Cout = Cout; cw->taps = 2; cw->N = stride * Cout; cw->zero = p->zero_page;
     float* scale = (float*)ar.take((size_t)Cin * 4);
     cw->W = (bf16_t*)ar.take((size_t)2 * cw->N * Cin * 2);
     cw->bias = (float*)ar.take((size_t)Cout * 4);
@@ -469,6 +615,8 @@ int build(sat_oobleck_plan* p, Arena& ar, hipStream_t s) {
     const sat_oobleck_cfg& c = p->cfg;
     const int nb = c.n_blocks;
     p->blocks.resize(nb);
+    p->zero_page = (bf16_t*)ar.take(256);
+    if (!ar.dry) SAT_HIP(hipMemsetAsync(p->zero_page, 0, 256, s));
     if (c.is_decoder) {
         // autoencoders.py:174-191: channel list c_mults=[1]+c_mults ; blocks from deepest to shallowest
         const int ctop = c.c_mults[nb - 1] * c.channels;
@@ -541,6 +689,7 @@ Bufs carve(const sat_oobleck_plan* p, int B, int T, char* base) {
 
 ConvArgs base_args(const ConvW& w, const bf16_t* in, int Tin, int M) {
     ConvArgs a{};
+    a.zero_page = w.zero;
     a.in = in; a.Tin = Tin; a.Cin = w.Cin; a.W = w.W; a.taps = w.taps; a.N = w.N; a.M = M;
     a.stride = 1; a.off0 = 0; a.doff = 1; a.bias = w.bias; a.Cout = w.Cout;
     a.out_bstride = (long long)M * w.N; a.out_shift = 0; a.out_limit = (long long)M * w.N;

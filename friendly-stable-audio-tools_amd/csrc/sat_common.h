@@ -92,6 +92,14 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// counted wait on outstanding vector-memory operations (LDS-DMA pieces included); hipcc does not see inside the asm,
+// which is the point: the compiler never drains the in-flight prefetch ring with a vmcnt(0)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // ---------------------------------------------------------------------------------------
 // internal launchers shared between translation units
 // ---------------------------------------------------------------------------------------

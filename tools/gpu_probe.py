@@ -57,7 +57,7 @@ def gemm_bench():
 
 def gemm_pmc():
     """few launches of selected variants for rocprofv3 --pmc runs"""
-    for name, m, n, k, vs in [("ff_in", 2050, 12288, 1536, (7, 5, 13)), ("ff_out", 2050, 1536, 6144, (5, 10)), ("ff_inB8", 16400, 12288, 1536, (7,))]:
+    for name, m, n, k, vs in [("ff_inB8", 16400, 12288, 1536, (7, 22, 26, 13)), ("ff_in", 2050, 12288, 1536, (22, 26))]:
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
