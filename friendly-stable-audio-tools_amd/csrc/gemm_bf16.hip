@@ -415,13 +415,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int MI = TM / 32;
     constexpr int NI = 2;
     constexpr int CPR = BK / 8;                    // 16-B chunks per row
-    constexpr int A_CH = BM * CPR / NT;
-    constexpr int B_CH = BN * CPR / NT;
-    constexpr int LPT = A_CH + B_CH;               // LDS-DMA instructions per tile per thread
+    // One LDS-DMA instruction of one wave moves 64 chunks = 1 KiB.  A stage holds WL_A + WL_B of them (A rows first, then
+    // W rows, contiguous); wave w issues wave-loads w, w+NW, w+2NW, ...  When NW does not divide WL (256x192 on 12 waves:
+    // 56 wave-loads) the first WL%NW waves carry one more than the rest, and the counted vmcnt wait is per wave.
+    constexpr int NW = WM * WN;
+    constexpr int WL_A = BM * CPR / 64;
+    constexpr int WL = (BM + BN) * CPR / 64;
+    constexpr int LPT = (WL + NW - 1) / NW;        // max LDS-DMA instructions per tile per wave
+    constexpr int N_FULL = WL - (LPT - 1) * NW;    // waves [0, N_FULL) issue LPT, the others LPT-1
+    constexpr bool UNIFORM = (WL % NW) == 0;
     constexpr int ROWB = BK * 2;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int D = NS - 1;                      // prefetch distance
-    static_assert(A_CH >= 1 && B_CH >= 1 && (D - 1) * LPT < 64, "bad pipeline geometry");
+    static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -456,24 +462,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr bool dbg_nomfma = DBG == 3;
     constexpr bool dbg_nobar = DBG >= 4;
     constexpr bool dbg_nolds = DBG >= 5;
-    const bf16_t* a_ptr[A_CH];
+    const bf16_t* ld_ptr[LPT];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        int q = i * NT + tid;
+    for (int i = 0; i < LPT; ++i) {
+        const int L = i * NW + wave;               // wave-uniform
+        const bool is_a = L < WL_A;
+        int q = (is_a ? L : L - WL_A) * 64 + lane;
         int row = q / CPR, pos = q % CPR;
         int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
         int gm = (dbg_same ? 0 : m0) + row;
         gm = gm < M ? gm : M - 1;
-        a_ptr[i] = g.A + (size_t)gm * K + c * 8;
+        int gn = (dbg_same ? 0 : n0) + row;
+        gn = gn < N ? gn : N - 1;                  // only reachable by the unused slot of a short wave
+        ld_ptr[i] = is_a ? g.A + (size_t)gm * K + c * 8 : g.W + (size_t)gn * K + c * 8;
     }
-    const bf16_t* b_ptr[B_CH];
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-        int q = i * NT + tid;
-        int row = q / CPR, pos = q % CPR;
-        int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
-        b_ptr[i] = g.W + (size_t)((dbg_same ? 0 : n0) + row) * K + c * 8;
-    }
+    const bool wave_full = UNIFORM || wave < N_FULL;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -485,15 +488,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 
     auto stage_in = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE_BYTES;
-        char* sb = sa + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < LPT; ++i)
+            if (UNIFORM || i + 1 < LPT || wave_full)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[i] + kt * BK),
+                                                 (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+    // tiles k+1..k+D-1 may stay in flight: this wave issued LPT (or LPT-1) loads for each of them
+    auto wait_steady = [&]() {
+        if constexpr (UNIFORM || D == 1) {
+            wait_vmcnt<(D - 1) * LPT>();
+        } else {
+            if (wave_full) wait_vmcnt<(D - 1) * LPT>();
+            else wait_vmcnt<(D - 1) * (LPT - 1)>();
+        }
     };
     // fragments are double-buffered across the k-steps: the ds_reads of step ks+1 are issued BEFORE the MFMAs of
     // step ks, so the wave waits with a counted lgkmcnt and LDS latency hides behind the matrix pipe
@@ -552,7 +560,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
     for (int k = 0; k < nk - D; ++k) {
         if constexpr (!dbg_nobar) {
-            wait_vmcnt<(D - 1) * LPT>();
+            wait_steady();
             __builtin_amdgcn_s_barrier();
         }
         if constexpr (!dbg_noload) stage_in(k + D, wr);
@@ -591,13 +599,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
     constexpr int NJ = TN / 64;                    // 64-column spans per wave (one head / one value+gate pair each)
     constexpr int NI = 2 * NJ;
     constexpr int CPR = BK / 8;                    // 16-B chunks per row
-    constexpr int A_CH = BM * CPR / NT;
-    constexpr int B_CH = BN * CPR / NT;
-    constexpr int LPT = A_CH + B_CH;               // LDS-DMA instructions per tile per thread
+    // One LDS-DMA instruction of one wave moves 64 chunks = 1 KiB.  A stage holds WL_A + WL_B of them (A rows first, then
+    // W rows, contiguous); wave w issues wave-loads w, w+NW, w+2NW, ...  When NW does not divide WL (256x192 on 12 waves:
+    // 56 wave-loads) the first WL%NW waves carry one more than the rest, and the counted vmcnt wait is per wave.
+    constexpr int NW = WM * WN;
+    constexpr int WL_A = BM * CPR / 64;
+    constexpr int WL = (BM + BN) * CPR / 64;
+    constexpr int LPT = (WL + NW - 1) / NW;        // max LDS-DMA instructions per tile per wave
+    constexpr int N_FULL = WL - (LPT - 1) * NW;    // waves [0, N_FULL) issue LPT, the others LPT-1
+    constexpr bool UNIFORM = (WL % NW) == 0;
     constexpr int ROWB = BK * 2;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int D = NS - 1;                      // prefetch distance
-    static_assert(A_CH >= 1 && B_CH >= 1 && (D - 1) * LPT < 64, "bad pipeline geometry");
+    static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -626,24 +640,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
     const int n0 = tn * BN;
 
     constexpr bool dbg_same = false, dbg_noload = false, dbg_nomfma = false;
-    const bf16_t* a_ptr[A_CH];
+    const bf16_t* ld_ptr[LPT];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        int q = i * NT + tid;
+    for (int i = 0; i < LPT; ++i) {
+        const int L = i * NW + wave;               // wave-uniform
+        const bool is_a = L < WL_A;
+        int q = (is_a ? L : L - WL_A) * 64 + lane;
         int row = q / CPR, pos = q % CPR;
         int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
         int gm = (dbg_same ? 0 : m0) + row;
         gm = gm < M ? gm : M - 1;
-        a_ptr[i] = g.A + (size_t)gm * K + c * 8;
+        int gn = (dbg_same ? 0 : n0) + row;
+        gn = gn < N ? gn : N - 1;                  // only reachable by the unused slot of a short wave
+        ld_ptr[i] = is_a ? g.A + (size_t)gm * K + c * 8 : g.W + (size_t)gn * K + c * 8;
     }
-    const bf16_t* b_ptr[B_CH];
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-        int q = i * NT + tid;
-        int row = q / CPR, pos = q % CPR;
-        int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
-        b_ptr[i] = g.W + (size_t)((dbg_same ? 0 : n0) + row) * K + c * 8;
-    }
+    const bool wave_full = UNIFORM || wave < N_FULL;
 
     f32x16 acc[NJ][MI][2];
 #pragma unroll
@@ -657,15 +668,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
 
     auto stage_in = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE_BYTES;
-        char* sb = sa + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(sb + (i * NT + wave * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < LPT; ++i)
+            if (UNIFORM || i + 1 < LPT || wave_full)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[i] + kt * BK),
+                                                 (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024), 16, 0, 0);
+    };
+    // tiles k+1..k+D-1 may stay in flight: this wave issued LPT (or LPT-1) loads for each of them
+    auto wait_steady = [&]() {
+        if constexpr (UNIFORM || D == 1) {
+            wait_vmcnt<(D - 1) * LPT>();
+        } else {
+            if (wave_full) wait_vmcnt<(D - 1) * LPT>();
+            else wait_vmcnt<(D - 1) * (LPT - 1)>();
+        }
     };
     // Fragments are double-buffered across the k-steps AND across K-tiles: the ds_reads of the next step are issued
     // interleaved with the MFMAs of the current one (pinned with sched_group_barrier), and the last step of tile k
@@ -818,13 +834,28 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
     }
     int v = a.variant;
     if (v == 0) {
-        // measured on MI355X (profiles/r01_gemm_variants.txt): the 256x256 tile (16 waves, direct-to-LDS, 2 stages)
-        // wins whenever it yields >= ~160 workgroups (FFN-in, QKV at B=1; everything at B>=4); below that the
-        // 128x128 tile with 8 waves and a 3-stage ring fills more CUs (to_out / FFN-out at B=1: 204 vs 54 workgroups).
-        long t256 = (long)cdiv(a.M, 256) * (a.N / 256);
-        if (a.N % 256 == 0 && t256 >= 160 && a.K >= 128) v = (cdiv(a.M, 256) > 16) ? 26 : 22;   // 26: grouped raster + 4-stage ring (large M)
-        else if (a.K >= 192) v = 15;
-        else v = 5;
+        // Pick the tile whose (fill of the last round of 256 CUs) x (measured in-kernel rate relative to the 256x256
+        // tile) is best.  Rates from profiles/r01_gemm_variants.txt: 256x256 (16 waves) 1.0, 256x192 (12 waves) 0.95,
+        // 128x128 (8 waves, 3 stages) 0.7, 128x64 0.6.  At B=1 this gives FFN-in 256x256 (432 workgroups, 2 rounds),
+        // QKV 256x192 (216 instead of 162 workgroups), to_out / FFN-out 128x128 (204) and the cross-attention
+        // projections (M = 1025) 128x64 (216); at B >= 4 everything takes the 256x256 tile.
+        auto score = [&](int bm, int bn, double rate) {
+            if (a.N % bn) return 0.0;
+            long t = (long)cdiv(a.M, bm) * (a.N / bn);
+            long rounds = (t + 255) / 256;
+            return rate * (double)t / (double)(rounds * 256);
+        };
+        if (a.K >= 192) {
+            const double s256 = score(256, 256, 1.0), s192 = score(256, 192, 0.95), s128 = score(128, 128, 0.7), s64 = score(128, 64, 0.6);
+            const double best = s256 > s192 ? (s256 > s128 ? s256 : s128) : (s192 > s128 ? s192 : s128);
+            if (best == 0.0 && s64 == 0.0) v = 15;      // N is not a tile multiple: let the launcher report it
+            else if (s64 > best) v = 16;
+            else if (best == s256) v = (cdiv(a.M, 256) > 16) ? 26 : 22;   // 26: grouped raster + 4-stage ring (large M)
+            else if (best == s192) v = 30;
+            else v = 15;
+        } else {
+            v = 5;
+        }
     }
     switch (v) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
@@ -856,6 +887,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 27: return launch_pipe2<128, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 28: return launch_pipe2<128, 128, 64, 4, 2, 4, EPI>(a, stream);
         case 29: return launch_pipe2<256, 128, 64, 4, 2, 3, EPI>(a, stream);
+        case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
         default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
     }
 }

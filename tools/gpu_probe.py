@@ -40,14 +40,27 @@ def section(name, fn):
 
 
 def gemm_bench():
+    if os.environ.get("PROBE_QUANT"):
+        shapes = [("256 tiles", 2048, 8192, 1536), ("384 tiles", 2048, 12288, 1536), ("432 tiles", 2050, 12288, 1536), ("512 tiles", 2048, 16384, 1536),
+                  ("128 tiles", 2048, 4096, 1536), ("162 tiles", 2050, 4608, 1536)]
+        for name, m, n, k in shapes:
+            a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+            c = torch.zeros(m, n, device=dev)
+            f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, 22, _hip.stream()))
+            ms = timeit(f)
+            print(f"quant {name:10s} M={m} N={n}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
+        return
     shapes = [("ff_in(swiglu)", 2050, 12288, 1536), ("ff_out", 2050, 1536, 6144), ("qkv", 2050, 4608, 1536), ("proj", 2050, 1536, 1536),
-              ("ff_in B8", 16400, 12288, 1536), ("ff_out B8", 16400, 1536, 6144)]
+              ("cross q/out", 1025, 1536, 1536), ("ff_in B8", 16400, 12288, 1536), ("ff_out B8", 16400, 1536, 6144)]
     for name, m, n, k in shapes:
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
-        for v in (22, 15, 7, 5):
-            if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26, 30, 31, 32) and n % 256:
+        for v in (22, 15, 30, 17, 16, 20):
+            if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26) and n % 256:
+                continue
+            if v == 30 and n % 192:
                 continue
             f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
             ms = timeit(f)
