@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
                 float v = acc[i] + bv;
                 if (act == 1) v = silu_f(v);
                 if (add) v += add[(size_t)r * ldadd + n];
+                if (act == 2) v = silu_f(v);       // SiLU after the add (input of to_scale_shift_gate, transformer.py:653)
                 if (OUT_BF16)
                     reinterpret_cast<bf16_t*>(yv)[(size_t)r * ldy + n] = f32_to_bf16(v);
                 else
@@ -84,7 +85,20 @@ __global__ void fold_out_kernel(const float* __restrict__ Wout, const float* __r
     WeffT[(size_t)n * C + c] = acc;
 }
 
-// X[b, 1+t, n] = xscale * sum_c Weff[n][c] * x[b % xB][c][t]       (C <= 64)
+// adaLN (transformer.py:667-688): ssg[b][layer][6][D] = (scale_self, shift_self, gate_self, scale_ff, shift_ff, gate_ff) straight
+// from to_scale_shift_gate; rewritten in place to what the consumers multiply with: scale -> 1 + scale, gate -> sigmoid(1 - gate).
+__global__ __launch_bounds__(256) void adaln_finish_kernel(float* __restrict__ ssg, int64_t n, int D) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int chunk = (int)((i / D) % 6);
+    float v = ssg[i];
+    if (chunk == 0 || chunk == 3) v = 1.f + v;
+    else if (chunk == 2 || chunk == 5) v = 1.f / (1.f + __expf(-(1.f - v)));
+    ssg[i] = v;
+}
+
+// (S - T = number of prepended rows: 1 for global_cond_type 'prepend', 0 for 'adaLN')
+// X[b, (S-T)+t, n] = xscale * sum_c Weff[n][c] * x[b % xB][c][t]       (C <= 64)
 constexpr int IP_TT = 8;
 __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ Weff,
                                                          float* __restrict__ X, int xB, int C, int T, int S, int D, float xscale) {
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
 #pragma unroll
         for (int tt = 0; tt < IP_TT; ++tt) {
             int t = t0 + tt;
-            if (t < T) X[((size_t)b * S + 1 + t) * D + n] = acc[tt];
+            if (t < T) X[((size_t)b * S + (S - T) + t) * D + n] = acc[tt];
         }
     }
 }
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restric
         int row = row0 + r;
         row = row < total ? row : total - 1;
         const int b = row / T, t = row - b * T;
-        const float4* src = reinterpret_cast<const float4*>(X + ((size_t)b * S + 1 + t) * D);
+        const float4* src = reinterpret_cast<const float4*>(X + ((size_t)b * S + (S - T) + t) * D);
         float4* dst = reinterpret_cast<float4*>(xw + (size_t)r * D);
         for (int i = lane; i < D / 4; i += 64) dst[i] = src[i];
     }
@@ -304,6 +318,12 @@ int glue_small_linear(const float* x, int ldx, const float* W, const float* bias
     return 0;
 }
 
+int glue_adaln_finish(float* ssg, int64_t n, int D, hipStream_t s) {
+    hipLaunchKernelGGL(adaln_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ssg, n, D);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 int glue_fourier(const float* t, float t_const, const float* w, float* out, int B, int half_feat, hipStream_t s) {
     hipLaunchKernelGGL(fourier_kernel, dim3(cdiv(B * half_feat, 256)), dim3(256), 0, s, t, t_const, w, out, B, half_feat);
     SAT_LAUNCH_CHECK();
@@ -353,6 +373,27 @@ int glue_cfg_denoise(const float* mo, const float* x, float* den, int B, int C, 
     }
     hipLaunchKernelGGL(cfg_denoise_kernel, dim3(cdiv((int64_t)B * T, 256)), dim3(256), 0, s, mo, x, den, B, C, T, use_cfg,
                        cfg_scale, scale_phi, c_out, c_skip);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+// inference/sampling.py:178-190 (inpainting_callback): keep-region of the current step's binary mask is re-noised init data
+__global__ __launch_bounds__(256) void inpaint_mix_kernel(float* __restrict__ x, const float* __restrict__ init,
+                                                          const float* __restrict__ noise, const float* __restrict__ mask,
+                                                          float sigma, float strength, int64_t n, int T) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (mask[i % T] <= strength) x[i] = init[i] + noise[i] * sigma;
+    }
+}
+
+extern "C" int sat_inpaint_mix(float* x_dev, const float* init_dev, const float* noise_dev, const float* mask_dev, float sigma,
+                               float strength, int64_t rows, int32_t t, sat_stream_t stream) {
+    SAT_CHECK_ARG(x_dev && init_dev && noise_dev && mask_dev && rows > 0 && t > 0, SAT_E_INVALID, "inpaint_mix: bad argument");
+    const int64_t n = rows * t;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(inpaint_mix_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_dev, init_dev, noise_dev, mask_dev,
+                       sigma, strength, n, t);
     SAT_LAUNCH_CHECK();
     return 0;
 }

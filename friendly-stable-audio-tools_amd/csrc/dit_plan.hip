@@ -23,7 +23,7 @@ void sat_set_error(const char* fmt, ...) {
     g_last_error = buf;
 }
 extern "C" const char* sat_last_error(void) { return g_last_error.c_str(); }
-extern "C" int sat_version(void) { return 1; }
+extern "C" int sat_version(void) { return 2; }
 
 // ------------------------------------------------------------------------------ plan
 namespace {
@@ -59,6 +59,7 @@ struct sat_dit_plan {
     float *ce0_w, *ce2_w, *ge0_w, *ge2_w;
     float *win_eff, *wout_eff;
     float *rope_cos, *rope_sin, *inv_freq;
+    float* ssg_w = nullptr;         // adaLN: [depth * 6D, D] stacked to_scale_shift_gate weights
     // per-generation context (sat_dit_prepare_context)
     char* ctx_buf = nullptr;
     size_t ctx_cap = 0;
@@ -137,10 +138,16 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
         SAT_TRY(glue_fold_out(wout, wpost, p->wout_eff, D, C, s));
         SAT_TRY(sat_launch_rope_table(p->inv_freq, p->rope_cos, p->rope_sin, smax, s));
     }
+    if (c.adaln) p->ssg_w = (float*)ar.take((size_t)c.depth * 6 * D * D * 4);
     p->layers.resize(c.depth);
     for (int l = 0; l < c.depth; ++l) {
         LayerW& L = p->layers[l];
         const std::string pf = "transformer.layers." + std::to_string(l) + ".";
+        if (c.adaln && !ar.dry) {   // transformer.py:651-655: Sequential(SiLU, Linear(D, 6D, bias=False)) -> key "...1.weight"
+            const float* wsrc;
+            SAT_TRY(get_tensor(p, pf + "to_scale_shift_gate.1.weight", (int64_t)6 * D * D, &wsrc));
+            SAT_HIP(hipMemcpyAsync(p->ssg_w + (size_t)l * 6 * D * D, wsrc, (size_t)6 * D * D * 4, hipMemcpyDeviceToDevice, s));
+        }
         SAT_TRY(copy_f32(p, ar, pf + "pre_norm.gamma", D, &L.pre_g, s));
         SAT_TRY(copy_f32(p, ar, pf + "pre_norm.beta", D, &L.pre_b, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.gamma", D, &L.ff_g, s));
@@ -171,6 +178,7 @@ struct Workspace {
     float* X;
     bf16_t *A, *AO, *Q, *K, *Vt, *Hh;
     float *ff, *h1, *mo;
+    float *gsum, *ssg;      // adaLN: silu(global + timestep embed) [bf, D]; per-layer modulation [bf, depth, 6, D]
     size_t qkv_bytes;
     size_t total;
 };
@@ -178,7 +186,7 @@ struct Workspace {
 Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     const sat_dit_cfg& c = p->cfg;
     const int D = c.embed_dim, H = c.num_heads;
-    const int S = T + 1;
+    const int S = T + (c.adaln ? 0 : 1);
     const size_t M = (size_t)bf * S;
     const int Spad = (int)round_up(S + 3, 128);
     Workspace w;
@@ -200,6 +208,8 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     w.ff = (float*)take((size_t)bf * 256 * 4);
     w.h1 = (float*)take((size_t)bf * D * 4);
     w.mo = (float*)take((size_t)bf * c.io_channels * T * 4);
+    w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
+    w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
     w.total = off;
     return w;
 }
@@ -217,7 +227,9 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     Workspace w = carve(p, bf, T, (char*)ws);
     SAT_CHECK_ARG(ws_bytes >= w.total, SAT_E_WORKSPACE, "dit forward: workspace %zu < required %zu", ws_bytes, w.total);
     const int D = c.embed_dim, H = c.num_heads, C = c.io_channels;
-    const int S = T + 1, M = bf * S, Spad = (int)round_up(S + 3, 128);
+    const bool adaln = c.adaln != 0;
+    const int S = T + (adaln ? 0 : 1), M = bf * S, Spad = (int)round_up(S + 3, 128);
+    const int ssg_ld = c.depth * 6 * D;      // per-sequence stride of the adaLN modulation vectors
 
     // pads of q/k/vt must be finite (zero): one memset per forward
     SAT_HIP(hipMemsetAsync(w.Q, 0, 3 * (size_t)round_up((int64_t)w.qkv_bytes, 256), s));
@@ -225,7 +237,15 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     // timestep embedding (dit.py:176) + global embed (dit.py:179-182) -> prepend token rows X[b,0,:]
     SAT_TRY(glue_fourier(t_dev, t_const, p->ts_w, w.ff, bf, 128, s));
     SAT_TRY(glue_small_linear(w.ff, 256, p->te0_w, p->te0_b, nullptr, 0, w.h1, D, bf, D, 256, 1, false, s));
-    SAT_TRY(glue_small_linear(w.h1, D, p->te2_w, p->te2_b, p->has_global ? p->ge : nullptr, D, w.X, S * D, bf, D, D, 0, false, s));
+    if (!adaln) {
+        SAT_TRY(glue_small_linear(w.h1, D, p->te2_w, p->te2_b, p->has_global ? p->ge : nullptr, D, w.X, S * D, bf, D, D, 0, false, s));
+    } else {
+        // dit.py:205-206: the summed embedding conditions every block instead of being prepended; transformer.py:667:
+        // (scale, shift, gate) x (self, ff) = Linear(SiLU(global)) for all layers in one launch
+        SAT_TRY(glue_small_linear(w.h1, D, p->te2_w, p->te2_b, p->has_global ? p->ge : nullptr, D, w.gsum, D, bf, D, D, 2, false, s));
+        SAT_TRY(glue_small_linear(w.gsum, D, p->ssg_w, nullptr, nullptr, 0, w.ssg, ssg_ld, bf, ssg_ld, D, 0, false, s));
+        SAT_TRY(glue_adaln_finish(w.ssg, (int64_t)bf * ssg_ld, D, s));
+    }
     // preprocess_conv + residual + project_in (dit.py:197-199, transformer.py:778)
     SAT_TRY(glue_input_proj(x, p->win_eff, w.X, bf, xB, C, T, S, D, xscale, s));
 
@@ -233,7 +253,8 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     for (int l = 0; l < c.depth; ++l) {
         const LayerW& L = p->layers[l];
         // ---- self-attention branch (transformer.py:692)
-        SAT_TRY(sat_launch_layernorm(w.X, L.pre_g, L.pre_b, w.A, M, D, s));
+        const float* mod = adaln ? w.ssg + (size_t)l * 6 * D : nullptr;     // + {0..5} * D: scale1p/shift/gate self, then ff
+        SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_qkv; g.M = M; g.N = 3 * D; g.K = D;
         g.heads.out[0] = w.Q; g.heads.out[1] = w.K; g.heads.out[2] = w.Vt;
@@ -244,6 +265,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s));
         g = GemmArgs{};
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
+        if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
         // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
         // unconditional CFG half, dit.py:294-300) get k = v = 0 from the bias-free to_cond_embed / to_kv, hence an
@@ -267,7 +289,8 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             }
         }
         // ---- feed-forward branch (transformer.py:700)
-        SAT_TRY(sat_launch_layernorm(w.X, L.ff_g, L.ff_b, w.A, M, D, s));
+        SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
+                                         ssg_ld, s));
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
         const bool prof = p->prof_on && l == c.depth / 2 && p->prof_n < kProfMaxPairs;
@@ -289,6 +312,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         }
         g = GemmArgs{};
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
+        if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
     }
     // project_out + drop prepend + postprocess_conv + residual (transformer.py:807, dit.py:219-224)

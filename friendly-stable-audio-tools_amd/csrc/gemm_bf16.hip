@@ -48,8 +48,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                     const int r = rh * 8 + r8;
                     int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (m < M) {
+                        if (g.gate) {      // adaLN gated branch (transformer.py:674, 688): wave-uniform pointer test
+                            const float* gr = g.gate + (size_t)(m / g.gate_rows) * g.gate_ld + nw + l31;
 #pragma unroll
-                        for (int j = 0; j < NI; ++j) C[(size_t)m * ldc + nw + j * 32 + l31] = acc[i][j][r] + bia[j] + old[r8][j];
+                            for (int j = 0; j < NI; ++j)
+                                C[(size_t)m * ldc + nw + j * 32 + l31] = (acc[i][j][r] + bia[j]) * gr[j * 32] + old[r8][j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NI; ++j) C[(size_t)m * ldc + nw + j * 32 + l31] = acc[i][j][r] + bia[j] + old[r8][j];
+                        }
                     }
                 }
             }
@@ -406,7 +413,12 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
 
 // DBG (micro-benchmark ablations, wrong results): 0 production; 1 all tiles load tile (0,0); 2 no LDS-DMA in the loop;
 // 3 no ds_read/MFMA; 4 = 2 + no barrier; 5 = 4 + no ds_read (MFMA on register-resident fragments)
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>
+// GH ("ghost fold", B=1): M = 2*1025 leaves 2 rows beyond the last full 256-row tile; as a ninth row of tiles they cost a
+// full tile each (a tile is bound by staging its W panel, not by its MFMAs) and push FFN-in at 256x192 from exactly two
+// rounds of 256 workgroups into a third.  With GH the grid only has the full row tiles; the <= 8 leftover rows ride along
+// as one more 1-KiB wave-load per stage, and in the workgroups of tile rows 0..WN-1 the wave (wm = 0, wn = tile row)
+// multiplies them with the W fragments of its own 64 columns (2 extra MFMAs per k-step on one of NW waves).
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int GH = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
@@ -420,12 +432,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // 56 wave-loads) the first WL%NW waves carry one more than the rest, and the counted vmcnt wait is per wave.
     constexpr int NW = WM * WN;
     constexpr int WL_A = BM * CPR / 64;
-    constexpr int WL = (BM + BN) * CPR / 64;
+    constexpr int WL_AB = (BM + BN) * CPR / 64;
+    constexpr int WL = WL_AB + (GH ? 1 : 0);       // + the leftover rows (8 rows = one wave-load)
     constexpr int LPT = (WL + NW - 1) / NW;        // max LDS-DMA instructions per tile per wave
     constexpr int N_FULL = WL - (LPT - 1) * NW;    // waves [0, N_FULL) issue LPT, the others LPT-1
     constexpr bool UNIFORM = (WL % NW) == 0;
     constexpr int ROWB = BK * 2;
-    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB + (GH ? 32 * ROWB : 0);   // leftover rows: a 32-row MFMA block, 8 rows staged
+    static_assert(!GH || (BK == 64 && DBG == 0), "ghost fold: BK = 64 only");
     constexpr int D = NS - 1;                      // prefetch distance
     static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
 
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     const int l31 = lane & 31;
 
     const int M = g.M, N = g.N, K = g.K;
-    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_m = GH ? M / BM : (M + BM - 1) / BM;
     const int tiles_n = N / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -466,11 +480,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int L = i * NW + wave;               // wave-uniform
-        const bool is_a = L < WL_A;
-        int q = (is_a ? L : L - WL_A) * 64 + lane;
+        const bool is_g = GH && L == WL_AB;        // the leftover rows
+        const bool is_a = L < WL_A || is_g;
+        int q = (L < WL_A ? L : is_g ? 0 : L - WL_A) * 64 + lane;
         int row = q / CPR, pos = q % CPR;
         int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
-        int gm = (dbg_same ? 0 : m0) + row;
+        int gm = (is_g ? tiles_m * BM : dbg_same ? 0 : m0) + row;
         gm = gm < M ? gm : M - 1;
         int gn = (dbg_same ? 0 : n0) + row;
         gn = gn < N ? gn : N - 1;                  // only reachable by the unused slot of a short wave
@@ -485,6 +500,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // ghost fold: the wave that also multiplies the leftover rows with its own W columns
+    const bool ghost_wave = GH && wm == 0 && tm < WN && wn == tm;
+    f32x16 acc_g[1][NI];
+    if constexpr (GH != 0) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_g[0][j][r] = 0.f;
+    }
 
     auto stage_in = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE_BYTES;
@@ -540,6 +564,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                 __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
             }
         }
+        if constexpr (GH != 0) {
+            // outside the pinned region: a wave-uniform branch taken by one wave of WN workgroups per W panel
+            if (ghost_wave) {
+                const char* sg = sb + BN * ROWB;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 ag = *reinterpret_cast<const bf16x8*>(sg + lds_off_bk<BK>(l31, ks * 2 + half));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        bf16x8 bg = *reinterpret_cast<const bf16x8*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
+                        acc_g[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, bg, acc_g[0][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
     };
 
     const int nk = K / BK;
@@ -587,6 +626,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
 
     if (wave_rows_valid) gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+    if constexpr (GH != 0) {
+        if (ghost_wave) gemm_epilogue<EPI, 1, NI>(g, acc_g, tiles_m * BM, n0 + wn * TN, half, l31);
+    }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
@@ -776,12 +818,17 @@ int launch_pipe2(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int GH = 0>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
+    if constexpr (GH != 0) {
+        // the ghost fold covers 1..8 leftover rows and needs one full tile row per wave column; otherwise the plain grid
+        const int left = a.M % BM;
+        if (left == 0 || left > 8 || a.M / BM < WN) return launch_pipe<BM, BN, BK, WM, WN, NS, EPI, DBG, 0>(a, stream);
+    }
     constexpr int NT = WM * WN * 64;
-    constexpr int LDS = NS * (BM + BN) * BK * 2;
+    constexpr int LDS = NS * ((BM + BN) * BK * 2 + (GH ? 32 * BK * 2 : 0));
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
-    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG>;
+    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG, GH>;
     static bool attr_set = false;
     if (!attr_set) {
         SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -789,7 +836,7 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     }
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
     SAT_CHECK_ARG(a.K % BK == 0 && a.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
-    int tiles = cdiv(a.M, BM) * (a.N / BN);
+    int tiles = (GH ? a.M / BM : cdiv(a.M, BM)) * (a.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, a);
     SAT_LAUNCH_CHECK();
     return 0;
@@ -888,6 +935,8 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 28: return launch_pipe2<128, 128, 64, 4, 2, 4, EPI>(a, stream);
         case 29: return launch_pipe2<256, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
+        case 31: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 1>(a, stream);
+        case 32: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 1>(a, stream);
         default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
     }
 }

@@ -10,7 +10,8 @@ namespace {
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                        int m, int d) {
+                                                        int m, int d, const float* __restrict__ sc, const float* __restrict__ sh,
+                                                        int rps, int ld) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -33,15 +34,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float4* gr = reinterpret_cast<const float4*>(gamma);
     const float4* br = reinterpret_cast<const float4*>(beta);
     bf16x4* yr = reinterpret_cast<bf16x4*>(y + (size_t)row * d);
+    // adaLN modulation (wave-uniform branch): per-sequence (1 + scale) and shift vectors
+    const float4* scr = sc ? reinterpret_cast<const float4*>(sc + (size_t)(row / rps) * ld) : nullptr;
+    const float4* shr = sc ? reinterpret_cast<const float4*>(sh + (size_t)(row / rps) * ld) : nullptr;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         float4 g = gr[i * 64 + lane];
         float4 b = beta ? br[i * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r;
+        r.x = (v[i].x - mean) * rstd * g.x + b.x;
+        r.y = (v[i].y - mean) * rstd * g.y + b.y;
+        r.z = (v[i].z - mean) * rstd * g.z + b.z;
+        r.w = (v[i].w - mean) * rstd * g.w + b.w;
+        if (scr) {
+            float4 a = scr[i * 64 + lane], c = shr[i * 64 + lane];
+            r.x = r.x * a.x + c.x;
+            r.y = r.y * a.y + c.y;
+            r.z = r.z * a.z + c.z;
+            r.w = r.w * a.w + c.w;
+        }
         bf16x4 o;
-        o[0] = f32_to_bf16((v[i].x - mean) * rstd * g.x + b.x);
-        o[1] = f32_to_bf16((v[i].y - mean) * rstd * g.y + b.y);
-        o[2] = f32_to_bf16((v[i].z - mean) * rstd * g.z + b.z);
-        o[3] = f32_to_bf16((v[i].w - mean) * rstd * g.w + b.w);
+        o[0] = f32_to_bf16(r.x);
+        o[1] = f32_to_bf16(r.y);
+        o[2] = f32_to_bf16(r.z);
+        o[3] = f32_to_bf16(r.w);
         yr[i * 64 + lane] = o;
     }
 }
@@ -49,7 +65,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // generic fallback: any d % 4 == 0 (strided loop, row re-read from L2)
 __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                                int m, int d) {
+                                                                int m, int d, const float* __restrict__ sc,
+                                                                const float* __restrict__ sh, int rps, int ld) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -63,8 +80,13 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
         q += a * a;
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
-    for (int i = lane; i < d; i += 64)
-        y[(size_t)row * d + i] = f32_to_bf16((xr[i] - mean) * rstd * gamma[i] + (beta ? beta[i] : 0.f));
+    const float* scr = sc ? sc + (size_t)(row / rps) * ld : nullptr;
+    const float* shr = sc ? sh + (size_t)(row / rps) * ld : nullptr;
+    for (int i = lane; i < d; i += 64) {
+        float r = (xr[i] - mean) * rstd * gamma[i] + (beta ? beta[i] : 0.f);
+        if (scr) r = r * scr[i] + shr[i];
+        y[(size_t)row * d + i] = f32_to_bf16(r);
+    }
 }
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
@@ -130,24 +152,31 @@ __global__ void rope_table_kernel(const float* __restrict__ inv_freq, float* __r
 
 }  // namespace
 
-int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s) {
+int sat_launch_layernorm_mod(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, const float* sc,
+                             const float* sh, int rps, int ld, hipStream_t s) {
     SAT_CHECK_ARG(x && gamma && y && m > 0 && d > 0 && d % 4 == 0, SAT_E_INVALID, "layernorm: bad args m=%d d=%d", m, d);
+    SAT_CHECK_ARG((sc == nullptr) == (sh == nullptr) && (!sc || (rps > 0 && ld % 4 == 0)), SAT_E_INVALID,
+                  "layernorm: modulation needs both scale and shift, rows_per_seq > 0 and ld %% 4 == 0");
     dim3 grid(cdiv(m, 4)), block(256);
     if (d % 256 == 0 && d / 256 <= 8) {
         switch (d / 256) {
-            case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
-            case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
-            case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
-            case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
-            case 6: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
-            case 8: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y, m, d); break;
-            default: hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, gamma, beta, y, m, d); break;
+            case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
+            case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
+            case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
+            case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
+            case 6: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
+            case 8: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
+            default: hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
         }
     } else {
-        hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, gamma, beta, y, m, d);
+        hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld);
     }
     SAT_LAUNCH_CHECK();
     return 0;
+}
+
+int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s) {
+    return sat_launch_layernorm_mod(x, gamma, beta, y, m, d, nullptr, nullptr, 1, 0, s);
 }
 
 int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s) {

@@ -127,6 +127,8 @@ struct GemmArgs {
     float* C;            // [M,ldc]
     int ldc;
     int accumulate;
+    const float* gate;   // adaLN: (acc + bias) * gate[(row / gate_rows) * gate_ld + col] before the residual add; or nullptr
+    int gate_rows, gate_ld;
     // EPI_SWIGLU
     bf16_t* H;           // [M, N/2]
     // EPI_HEADS
@@ -135,6 +137,9 @@ struct GemmArgs {
 
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream);
 int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s);
+// adaLN: y = LN(x) * scale1p[b] + shift[b] with b = row / rows_per_seq and per-sequence vectors ld apart (transformer.py:671-672)
+int sat_launch_layernorm_mod(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, const float* scale1p,
+                             const float* shift, int rows_per_seq, int ld, hipStream_t s);
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
                          int sq, int sk, int sq_pad, int sk_pad, hipStream_t s);
 int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);

@@ -1,6 +1,7 @@
 """``generate_diffusion_cond`` (reference ``inference/generation.py:95-261``) -- same signature,
 same RNG order (manual_seed -> initial noise -> init-audio VAE noise -> sampler noise), same
 return values; the sampler loop and the decode run on the HIP C ABI."""
+import math
 import typing as tp
 
 import numpy as np
@@ -56,18 +57,45 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale: float = 6, condi
         init_noise_level = None
         mask_args = None
 
+    mask = None
     if init_audio is not None and mask_args is not None:
-        raise NotImplementedError("inpainting (mask_args) is outside the supported hot path")
-    if init_audio is not None:
+        # inpainting / outpainting (generation.py:195-213), in latent units: cut & paste the init latents, then the soft mask
+        cropfrom = math.floor(mask_args["cropfrom"] / 100.0 * sample_size)
+        pastefrom = math.floor(mask_args["pastefrom"] / 100.0 * sample_size)
+        pasteto = math.ceil(mask_args["pasteto"] / 100.0 * sample_size)
+        assert pastefrom < pasteto, "Paste From should be less than Paste To"
+        croplen = min(pasteto - pastefrom, sample_size - cropfrom)
+        cutpaste = init_audio.new_zeros(init_audio.shape)
+        cutpaste[:, :, pastefrom:pastefrom + croplen] = init_audio[:, :, cropfrom:cropfrom + croplen]
+        init_audio = cutpaste
+        mask = build_mask(sample_size, mask_args).to(device)
+    elif init_audio is not None:
         sampler_kwargs["sigma_max"] = init_noise_level                 # variations: generation.py:214-217
 
     conditioning_inputs = {k: (v.float() if v is not None else v) for k, v in conditioning_inputs.items()}
 
     if model.diffusion_objective != "v":
         raise NotImplementedError("only the v-objective / k-diffusion path is implemented (rectified flow is out of scope)")
-    sampled = sample_k(model.model, noise, init_audio, None, steps, **sampler_kwargs, **conditioning_inputs, cfg_scale=cfg_scale,
+    sampled = sample_k(model.model, noise, init_audio, mask, steps, **sampler_kwargs, **conditioning_inputs, cfg_scale=cfg_scale,
                        batch_cfg=True, rescale_cfg=True, device=device, disable_tqdm=disable_tqdm)
 
     if model.pretransform and not return_latents:
         sampled = model.pretransform.decode(sampled)
     return sampled
+
+
+def build_mask(sample_size, mask_args):
+    """Soft inpainting mask of length ``sample_size`` (reference generation.py:269-290): 1 = keep the input, 0 = generate,
+    Hann ramps of ``softnessL`` / ``softnessR`` percent at the edges of [maskstart, maskend) percent, everything scaled by
+    ``1 - marination`` so that the kept region is released before the last steps."""
+    start = math.floor(mask_args["maskstart"] / 100.0 * sample_size)
+    end = math.ceil(mask_args["maskend"] / 100.0 * sample_size)
+    soft_l = round(mask_args["softnessL"] / 100.0 * sample_size)
+    soft_r = round(mask_args["softnessR"] / 100.0 * sample_size)
+    mask = torch.zeros(sample_size)
+    mask[start:end] = 1
+    mask[start:start + soft_l] = torch.hann_window(soft_l * 2, periodic=False)[:soft_l]      # rising half
+    mask[end - soft_r:end] = torch.hann_window(soft_r * 2, periodic=False)[soft_r:]          # falling half
+    if mask_args["marination"] > 0:
+        mask = mask * (1 - mask_args["marination"])
+    return mask

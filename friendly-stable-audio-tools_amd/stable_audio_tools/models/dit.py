@@ -27,8 +27,8 @@ class DiffusionTransformer(nn.Module):
         super().__init__()
         if transformer_type != "continuous_transformer":
             raise NotImplementedError("only transformer_type='continuous_transformer' is implemented (the shipped DiT configs)")
-        if global_cond_type != "prepend":
-            raise NotImplementedError("only global_cond_type='prepend' is implemented (the shipped DiT configs)")
+        if global_cond_type not in ("prepend", "adaLN"):
+            raise ValueError(f"Unknown global_cond_type: {global_cond_type}")
         if patch_size != 1 or input_concat_dim != 0 or prepend_cond_dim != 0:
             raise NotImplementedError("patch_size>1 / input_concat / prepend_cond are outside the supported hot path")
         if not project_global_cond and global_cond_dim > 0:
@@ -59,7 +59,8 @@ class DiffusionTransformer(nn.Module):
                                                  _init.linear(embed_dim, embed_dim, bias=False))
         self.transformer = ContinuousTransformer(dim=embed_dim, depth=depth, dim_heads=embed_dim // num_heads,
                                                  dim_in=io_channels, dim_out=io_channels, cross_attend=cond_token_dim > 0,
-                                                 cond_token_dim=cond_embed_dim, global_cond_dim=None, **kwargs)
+                                                 cond_token_dim=cond_embed_dim,
+                                                 global_cond_dim=embed_dim if global_cond_type == "adaLN" else None, **kwargs)
         self.preprocess_conv = _init.conv1d(io_channels, io_channels, 1, bias=False, zero=True)
         self.postprocess_conv = _init.conv1d(io_channels, io_channels, 1, bias=False, zero=True)
 
@@ -88,7 +89,8 @@ class DiffusionTransformer(nn.Module):
             lib.sat_dit_plan_destroy(self._plan)
             self._plan = None
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
-                             self.cond_embed_dim, self.global_cond_dim, self.max_seq_len)
+                             self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
+                             1 if self.global_cond_type == "adaLN" else 0)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
         keep = []

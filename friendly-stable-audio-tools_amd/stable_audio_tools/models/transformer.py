@@ -73,8 +73,6 @@ class TransformerBlock(nn.Module):
                  zero_init_branch_outputs=True, conformer=False, layer_ix=-1, remove_norms=False, attn_kwargs={}, ff_kwargs={},
                  norm_kwargs={}):
         super().__init__()
-        if global_cond_dim:
-            raise NotImplementedError("adaLN global conditioning is not implemented by the HIP path (shipped configs use 'prepend')")
         if conformer or remove_norms:
             raise NotImplementedError("conformer / remove_norms are not supported by the HIP path")
         self.dim, self.dim_heads, self.cross_attend, self.dim_context = dim, dim_heads, cross_attend, dim_context
@@ -87,6 +85,13 @@ class TransformerBlock(nn.Module):
                                         zero_init_output=zero_init_branch_outputs, **attn_kwargs)
         self.ff_norm = LayerNorm(dim, **norm_kwargs)
         self.ff = FeedForward(dim, zero_init_output=zero_init_branch_outputs, **ff_kwargs)
+        self.global_cond_dim = global_cond_dim
+        if global_cond_dim:
+            # adaLN (reference transformer.py:650-656): SiLU -> Linear(global_cond_dim, 6*dim, no bias), zero-initialised;
+            # the HIP plan stacks the 24 weights and evaluates them in one launch per forward
+            if global_cond_dim != dim:
+                raise NotImplementedError("adaLN: the HIP plan expects global_cond_dim == dim (DiffusionTransformer always passes embed_dim)")
+            self.to_scale_shift_gate = nn.Sequential(nn.SiLU(), _init.linear(global_cond_dim, dim * 6, bias=False, zero=True))
 
 
 class ContinuousTransformer(nn.Module):

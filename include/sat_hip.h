@@ -63,6 +63,10 @@ typedef struct sat_dit_cfg {
     int32_t cond_embed_dim;    /* cond_token_dim if project_cond_tokens=false else embed_dim */
     int32_t global_cond_dim;   /* "global_cond_dim" (1536); 0 = timestep embedding only */
     int32_t max_seq_len;       /* largest latent length T the plan will see (+1 prepend) */
+    int32_t adaln;             /* 0: "global_cond_type": "prepend" (models/dit.py:186-197, the shipped configs);
+                                  1: "adaLN" (models/dit.py:205-206, models/transformer.py:665-689): no prepend token, the
+                                  global embedding drives per-layer scale/shift/gate of the self-attention and FF branches;
+                                  needs "transformer.layers.N.to_scale_shift_gate.1.weight" [6*embed_dim, embed_dim] */
 } sat_dit_cfg;
 
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
@@ -132,6 +136,13 @@ int sat_cfg_combine(const float* model_out_dev, float* out_dev, int32_t b, int32
 int sat_dpmpp3m_update(float* x_dev, const float* d_dev, const float* d1_dev, const float* d2_dev,
                        const float* noise_dev, float a, float b, float c1, float c2, float cn,
                        int64_t n, sat_stream_t stream);
+
+/* Inpainting re-injection (inference/sampling.py:98-103 get_bmask, :178-190 inpainting_callback, :168-172 initial mix):
+ *   x[r, i] <- init[r, i] + noise[r, i] * sigma     wherever mask[i] <= strength      (in place on x_dev)
+ * x/init/noise are [rows, t] (rows = batch * channels), mask is the [t] soft mask of generation.py:269-290 and
+ * strength = (step + 1) / steps.  Called right after the denoiser evaluation of every step, as the reference's callback. */
+int sat_inpaint_mix(float* x_dev, const float* init_dev, const float* noise_dev, const float* mask_dev,
+                    float sigma, float strength, int64_t rows, int32_t t, sat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Oobleck VAE.  Replaces models/autoencoders.py:45-194 (ResidualUnit, EncoderBlock,

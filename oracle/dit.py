@@ -117,8 +117,21 @@ def feed_forward(sd, pfx, x, rnd=None):
     return F.linear(h, _r(rnd, sd[pfx + "ff.2.weight"]), sd[pfx + "ff.2.bias"])
 
 
-# models/transformer.py:656-702 (TransformerBlock.forward, non-adaLN branch :691-700)
-def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None):
+# models/transformer.py:656-702 (TransformerBlock.forward: adaLN branch :665-689, plain branch :691-700)
+def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None, global_cond=None):
+    if global_cond is not None and (pfx + "to_scale_shift_gate.1.weight") in sd:
+        ssg = F.linear(F.silu(global_cond), sd[pfx + "to_scale_shift_gate.1.weight"]).unsqueeze(1)      # :667
+        scale_self, shift_self, gate_self, scale_ff, shift_ff, gate_ff = ssg.chunk(6, dim=-1)
+        h = layer_norm(x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"])
+        h = _r(rnd, h * (1 + scale_self) + shift_self)                                                    # :671-672
+        x = x + self_attention(sd, pfx + "self_attn.", h, freqs, num_heads, rnd) * torch.sigmoid(1 - gate_self)   # :673-675
+        if context is not None:                                                                          # :677-678 (un-modulated)
+            h = _r(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]))
+            x = x + cross_attention(sd, pfx + "cross_attn.", h, context, num_heads, dim_heads, rnd)
+        h = layer_norm(x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"])
+        h = _r(rnd, h * (1 + scale_ff) + shift_ff)                                                        # :685-686
+        x = x + feed_forward(sd, pfx + "ff.", h, rnd) * torch.sigmoid(1 - gate_ff)                        # :687-689
+        return x
     h = _r(rnd, layer_norm(x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"]))
     x = x + self_attention(sd, pfx + "self_attn.", h, freqs, num_heads, rnd)
     if context is not None:
@@ -130,15 +143,16 @@ def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None
 
 
 # models/transformer.py:764-809 (ContinuousTransformer.forward)
-def continuous_transformer(sd, x, prepend_embeds, context, depth, num_heads, rnd=None, return_hidden=False):
+def continuous_transformer(sd, x, prepend_embeds, context, depth, num_heads, rnd=None, return_hidden=False, global_cond=None):
     pfx = "transformer."
     x = F.linear(x, sd[pfx + "project_in.weight"])
-    x = torch.cat((prepend_embeds, x), dim=-2)
+    if prepend_embeds is not None:
+        x = torch.cat((prepend_embeds, x), dim=-2)
     dim_heads = x.shape[-1] // num_heads
     freqs = rotary_freqs(sd[pfx + "rotary_pos_emb.inv_freq"], x.shape[1])
     hidden = []
     for i in range(depth):
-        x = transformer_block(sd, f"{pfx}layers.{i}.", x, context, freqs, num_heads, dim_heads, rnd)
+        x = transformer_block(sd, f"{pfx}layers.{i}.", x, context, freqs, num_heads, dim_heads, rnd, global_cond)
         if return_hidden:
             hidden.append(x)
     out = F.linear(x, sd[pfx + "project_out.weight"])
@@ -157,8 +171,8 @@ def _mlp(sd, pfx, x, bias):
     return F.linear(x, sd[pfx + "2.weight"], sd[pfx + "2.bias"] if bias else None)
 
 
-# models/dit.py:135-226 (DiffusionTransformer._forward; global_cond_type == "prepend")
-def dit_inner_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, rnd=None, return_hidden=False):
+# models/dit.py:135-226 (DiffusionTransformer._forward; global_cond_type "prepend" :186-197 or "adaLN" :205-206)
+def dit_inner_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, rnd=None, return_hidden=False, adaln=False):
     """x [B,C,T] fp32, t [B], cross_attn_cond [B,Lc,Dc] or None, global_embed [B,Dg] or None."""
     context = None
     if cross_attn_cond is not None:
@@ -167,27 +181,28 @@ def dit_inner_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads,
         global_embed = _mlp(sd, "to_global_embed.", global_embed, bias=False)          # dit.py:154
     timestep_embed = _mlp(sd, "to_timestep_embed.", fourier_features(sd["timestep_features.weight"], t[:, None]), bias=True)
     global_embed = timestep_embed if global_embed is None else global_embed + timestep_embed  # dit.py:179-182
-    prepend = global_embed.unsqueeze(1)                                                  # dit.py:185-195
+    prepend = None if adaln else global_embed.unsqueeze(1)                               # dit.py:185-195
     x = F.conv1d(x, sd["preprocess_conv.weight"]) + x                                    # dit.py:197
     x = x.transpose(1, 2)                                                                # dit.py:199
-    out = continuous_transformer(sd, x, prepend, context, depth, num_heads, rnd, return_hidden)
+    out = continuous_transformer(sd, x, prepend, context, depth, num_heads, rnd, return_hidden,
+                                 global_cond=global_embed if adaln else None)
     if return_hidden:
         out, hidden = out
-    out = out.transpose(1, 2)[:, :, 1:]                                                  # dit.py:219
+    out = out.transpose(1, 2)[:, :, (0 if adaln else 1):]                                # dit.py:219
     out = F.conv1d(out, sd["postprocess_conv.weight"]) + out                             # dit.py:224
     return (out, hidden) if return_hidden else out
 
 
 # models/dit.py:228-364 (DiffusionTransformer.forward: batched CFG :270-349)
 def dit_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, cfg_scale=1.0, scale_phi=0.0,
-                negative_cross_attn_cond=None, rnd=None):
+                negative_cross_attn_cond=None, rnd=None, adaln=False):
     if cfg_scale != 1.0 and cross_attn_cond is not None:
         bx = torch.cat([x, x], dim=0)
         bt = torch.cat([t, t], dim=0)
         bg = None if global_embed is None else torch.cat([global_embed, global_embed], dim=0)
         null = torch.zeros_like(cross_attn_cond) if negative_cross_attn_cond is None else negative_cross_attn_cond
         bc = torch.cat([cross_attn_cond, null], dim=0)
-        out = dit_inner_forward(sd, bx, bt, bc, bg, depth, num_heads, rnd)
+        out = dit_inner_forward(sd, bx, bt, bc, bg, depth, num_heads, rnd, adaln=adaln)
         cond, uncond = torch.chunk(out, 2, dim=0)
         cfg = uncond + (cond - uncond) * cfg_scale                                       # dit.py:338-339
         if scale_phi != 0.0:                                                             # dit.py:342-345
@@ -195,4 +210,4 @@ def dit_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, cfg_s
             cfg_std = cfg.std(dim=1, keepdim=True)
             return scale_phi * (cfg * (cond_std / cfg_std)) + (1 - scale_phi) * cfg
         return cfg
-    return dit_inner_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, rnd)
+    return dit_inner_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, rnd, adaln=adaln)

@@ -80,3 +80,51 @@ def sample_dpmpp_3m_sde(denoiser, x, sigmas, noise_sampler, eta=1.0, s_noise=1.0
         denoised_1, denoised_2 = denoised, denoised_1
         h_1, h_2 = h, h_1
     return x
+
+
+# K.sampling.sample_dpmpp_2m_sde(model, x, sigmas, eta=1, s_noise=1, noise_sampler, solver_type='midpoint')
+# (sampling.py:226; the reference's DEFAULT sampler_type, sampling.py:150) -- restated from the published algorithm, unpinned
+def sample_dpmpp_2m_sde(denoiser, x, sigmas, noise_sampler, eta=1.0, s_noise=1.0, solver_type="midpoint", callback=None):
+    s_in = x.new_ones([x.shape[0]])
+    old_denoised = None
+    h_last = None
+    for i in range(len(sigmas) - 1):
+        denoised = denoiser(x, sigmas[i] * s_in)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        h = None
+        if sigmas[i + 1] == 0:
+            x = denoised
+        else:
+            t, s = -sigmas[i].log(), -sigmas[i + 1].log()
+            h = s - t
+            eta_h = eta * h
+            x = sigmas[i + 1] / sigmas[i] * (-eta_h).exp() * x + (-h - eta_h).expm1().neg() * denoised
+            if old_denoised is not None:
+                r = h_last / h
+                if solver_type == "heun":
+                    x = x + ((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / r) * (denoised - old_denoised)
+                else:
+                    x = x + 0.5 * (-h - eta_h).expm1().neg() * (1 / r) * (denoised - old_denoised)
+            if eta:
+                x = x + noise_sampler(i, sigmas[i], sigmas[i + 1]) * sigmas[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * s_noise
+        old_denoised = denoised
+        h_last = h
+    return x
+
+
+# inference/sampling.py:98-103 (get_bmask) and :166-201 (inpainting start + callback that mutates x)
+def get_bmask(i, steps, mask):
+    return torch.where(mask <= (i + 1) / steps, 1, 0)
+
+
+def inpainting_start_and_callback(init_data, noise_scaled, mask, steps, renoise):
+    """Returns (x0, callback).  ``renoise(i)`` supplies the unit Gaussian the reference draws with randn_like per step."""
+    b0 = get_bmask(0, steps, mask)
+    x0 = (init_data + noise_scaled) * b0 + noise_scaled * (1 - b0)
+
+    def callback(args):
+        i, x, sigma = args["i"], args["x"], args["sigma"]
+        bm = get_bmask(i, steps, mask)
+        x[:, :, :] = ((init_data + renoise(i) * sigma) * bm + x * (1 - bm))[:, :, :]
+    return x0, callback

@@ -26,6 +26,14 @@ SMALL_VAE = dict(channels=16, c_mults=[1, 2, 4, 8, 16], strides=[2, 4, 4, 8, 8])
 FULL_VAE = dict(channels=128, c_mults=[1, 2, 4, 8, 16], strides=[2, 4, 4, 8, 8])
 
 
+# generation.py:269-290 (build_mask): percent-valued inpainting arguments as the Gradio UI passes them
+MASK_ARGS = [
+    dict(cropfrom=0, pastefrom=0, pasteto=100, maskstart=25, maskend=75, softnessL=10, softnessR=5, marination=0),
+    dict(cropfrom=10, pastefrom=30, pasteto=90, maskstart=0, maskend=50.5, softnessL=0, softnessR=20, marination=0.3),
+    dict(cropfrom=50, pastefrom=0, pasteto=80, maskstart=33.3, maskend=100, softnessL=3.7, softnessR=0, marination=0),
+]
+
+
 def dit_inputs(b, t_len, cond_dim, global_dim, seed, lc=130):
     x = synthetic.synth_input("x", (b, 64, t_len), seed)
     c = synthetic.synth_input("c", (b, lc, cond_dim), seed + 1)

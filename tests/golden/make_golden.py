@@ -2,7 +2,7 @@
 placeholder modules of _ref_import.py) on seed-defined weights and inputs.
 
 Runs only in the build container (the reference does not travel).  Usage:
-    python tests/golden/make_golden.py [ops] [small] [vae] [full] [full_long] [host]
+    python tests/golden/make_golden.py [ops] [small] [adaln] [vae] [full] [full_long] [host]
 Stored: reference OUTPUTS only (fp32 .npz); weights/inputs are regenerated from seeds by
 ``stable_audio_tools.synthetic`` (see cases.py).
 """
@@ -172,7 +172,26 @@ def gen_host():
     a = synthetic.synth_input("pa", (1, 1000), 6)
     out["prepare_mono_to_stereo_pad"] = pa(a, 44100, 44100, 1500, 2, "cpu")
     out["prepare_crop"] = pa(synthetic.synth_input("pa3", (3, 1000), 7), 44100, 44100, 600, 2, "cpu")
+    for i, ma in enumerate(cases.MASK_ARGS):
+        out[f"mask_{i}"] = rgen.build_mask(1024, ma)
     save("host", **out)
+
+
+@torch.no_grad()
+def gen_adaln():
+    """Reduced DiT with global_cond_type='adaLN' (dit.py:205-206, transformer.py:665-689): no prepend token, per-layer
+    scale/shift/gate from the global embedding.  The reference zero-initialises to_scale_shift_gate; the synthetic state
+    dict re-draws it so that the modulation is exercised."""
+    m = load_synth(rdit.DiffusionTransformer(**cases.SMALL_DIT, global_cond_type="adaLN"), 0)
+    assert m.transformer.layers[1].to_scale_shift_gate[1].weight.abs().max() > 0
+    out = {}
+    for t_len in (64, 77):
+        x, t, c, g = cases.dit_inputs(2, t_len, 128, 96, 1)
+        out[f"cfg1_T{t_len}"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=1.0)
+    x, t, c, g = cases.dit_inputs(2, 77, 128, 96, 1)
+    out["cfg7_T77"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=7.0)
+    out["noglobal_T77"] = m(x, t, cross_attn_cond=c, cfg_scale=1.0)
+    save("dit_adaln_small", **out)
 
 
 def gen_keys():
@@ -207,6 +226,8 @@ if __name__ == "__main__":
         gen_vae()
     if "host" in which:
         gen_host()
+    if "adaln" in which:
+        gen_adaln()
     if "keys" in which:
         gen_keys()
     if "full" in which:

@@ -46,12 +46,12 @@ def test_cast_bf16(dev):
     assert torch.equal(y.cpu(), x.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32])
 @pytest.mark.parametrize("m,n,k", [(2050, 1536, 1536), (130, 256, 128), (1, 512, 64), (257, 768, 6144)])
 def test_gemm_f32(dev, variant, m, n, k):
     if variant in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26) and n % 256:
         pytest.skip("256-column tile needs n % 256 == 0")
-    if variant == 30 and n % 192:
+    if variant in (30, 31) and n % 192:
         pytest.skip("192-column tile needs n % 192 == 0")
     if variant >= 9 and k < 256:
         pytest.skip("the deep-prefetch variants need K >= stages * BK")
@@ -67,10 +67,11 @@ def test_gemm_f32(dev, variant, m, n, k):
     assert_close(f"gemm v{variant} {m}x{n}x{k}", cd, want, 1e-3)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 16, 22, 30])
-def test_gemm_swiglu(dev, variant):
+@pytest.mark.parametrize("m", [300, 770])          # 770 = 3*256 + 2 = 6*128 + 2: the leftover-row fold of variants 31 / 32
+@pytest.mark.parametrize("variant", [0, 1, 3, 16, 22, 30, 31, 32])
+def test_gemm_swiglu(dev, variant, m):
     _hip, lib = _lib()
-    m, k, inner = 300, 256, 768
+    k, inner = 256, 768
     a = _rand((m, k), 9).to(torch.bfloat16)
     w = _rand((2 * inner, k), 10) * 0.08
     bias = _rand((2 * inner,), 11) * 0.1
@@ -119,13 +120,13 @@ def test_attention(dev, b, h, kvh, sq, sk):
     assert rel_l2(out.view(b, sq, h * 64), exact) < 1e-2
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 16, 22, 30])
-def test_qkv_rope(dev, variant):
+@pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])      # 2*385 = 770 rows: leftover-row fold (variants 31 / 32)
+@pytest.mark.parametrize("variant", [0, 1, 3, 16, 22, 30, 31, 32])
+def test_qkv_rope(dev, variant, s, s_pad):
     from oracle import dit as odit
     _hip, lib = _lib()
-    b, s, d = 2, 197, 256
+    b, d = 2, 256
     h = d // 64
-    s_pad = 256
     a = _rand((b * s, d), 15).to(torch.bfloat16)
     w = (_rand((3 * d, d), 16) * 0.1).to(torch.bfloat16)
     inv_freq = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))

@@ -95,6 +95,45 @@ def test_dit_forward_cfg_and_denoise(dev, small_dit):
     assert_close("zero-context forward", got1, want1, 3e-3)
 
 
+def test_dit_adaln_vs_reference_golden(dev):
+    """global_cond_type='adaLN' (dit.py:205-206, transformer.py:665-689): no prepend token; LayerNorm modulated by
+    (1 + scale, shift) and the self-attention / FF branch outputs gated by sigmoid(1 - gate), all from one stacked
+    to_scale_shift_gate GEMV per forward.  Against the matched-rounding oracle (3e-3) and against the outputs of the
+    REFERENCE itself (tests/golden/dit_adaln_small.npz, fp32; 3e-2 / 1.5e-1 with CFG 7 as for the prepend model)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    from oracle import dit as odit
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.models import _init
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    gold = cases.load("dit_adaln_small")
+    with _init.skip_init():
+        dit = DiffusionTransformer(**cases.SMALL_DIT, global_cond_type="adaLN")
+    sd = synthetic.synth_state_dict(dit.state_dict(), 0)
+    dit.load_state_dict(sd)
+    dit = dit.to(dev).eval()
+    for t_len in (64, 77):
+        x, t, c, g = cases.dit_inputs(2, t_len, 128, 96, 1)
+        got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
+        want_m = odit.dit_forward(sd, x, t, c, g, 3, 4, rnd=bf16_round, adaln=True)
+        e_m = assert_close(f"adaLN T={t_len} vs matched oracle", got, want_m, 3e-3)
+        e_f = assert_close(f"adaLN T={t_len} vs reference", got, gold[f"cfg1_T{t_len}"], 3e-2)
+        print(f"\n[adaLN T={t_len}] rel-L2 vs matched {e_m:.2e}, vs the reference {e_f:.2e}")
+    x, t, c, g = cases.dit_inputs(2, 77, 128, 96, 1)
+    got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0)
+    assert_close("adaLN cfg7 vs matched oracle", got, odit.dit_forward(sd, x, t, c, g, 3, 4, cfg_scale=7.0, rnd=bf16_round, adaln=True), 1e-2)
+    assert_close("adaLN cfg7 vs reference", got, gold["cfg7_T77"], 1.5e-1)
+    got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), cfg_scale=1.0)
+    assert_close("adaLN without global cond vs reference", got, gold["noglobal_T77"], 3e-2)
+    # fused sampler-step entry point
+    dit.prepare_generation(c.to(dev), g.to(dev), 7.0)
+    sigma = 2.3
+    from oracle import sampler as osamp
+    fn = lambda xin, tt: odit.dit_forward(sd, xin, tt, c, g, 3, 4, cfg_scale=7.0, rnd=bf16_round, adaln=True)
+    assert_close("adaLN denoise_cfg", dit.denoise((x * sigma).to(dev), sigma, cfg_scale=7.0), osamp.vdenoise(fn, x * sigma, torch.full((2,), sigma)), 1e-2)
+
+
 @pytest.fixture(scope="module")
 def small_vae(dev):
     from stable_audio_tools import model_configs as MC
@@ -179,6 +218,41 @@ def test_generate_diffusion_cond_small(dev, small_dit):
     vsd = _sub(sd, "pretransform.model.decoder.")
     strides = cfg["model"]["pretransform"]["config"]["decoder"]["config"]["strides"]
     assert_close("pretransform.decode", model.pretransform.decode(lat), oob.oobleck_decoder(vsd, lat.cpu(), strides=strides, rnd=bf16_round), 1.5e-2)
+
+
+@pytest.mark.parametrize("sampler_type", ["dpmpp-2m-sde", "dpmpp-3m-sde"])
+def test_sample_k_inpainting_and_2m(dev, small_dit, sampler_type):
+    """sample_k with init data + soft mask (sampling.py:166-201: step-0 mix, then the per-step re-injection callback that
+    mutates x right after the denoiser call) under both multistep SDE samplers, against the oracle trajectory with every
+    Gaussian draw injected."""
+    from oracle import dit as odit, sampler as osamp
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.inference.generation import build_mask
+    from stable_audio_tools.inference.sampling import sample_k
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dsd = _sub(sd, "model.model.")
+    b, steps, t_len = 2, 5, 40
+    c = synthetic.synth_input("c", (b, 130, dc["cond_token_dim"]), 61)
+    g = synthetic.synth_input("g", (b, 2 * dc["cond_token_dim"]), 62)
+    noise = synthetic.synth_input("noise", (b, 64, t_len), 63)
+    init = synthetic.synth_input("init", (b, 64, t_len), 64)
+    step_noise = [synthetic.synth_input(f"sn{i}", (b, 64, t_len), 70 + i) for i in range(steps)]
+    renoise = [synthetic.synth_input(f"rn{i}", (b, 64, t_len), 80 + i) for i in range(steps)]
+    mask = build_mask(t_len, dict(maskstart=20, maskend=80, softnessL=15, softnessR=10, marination=0.1))
+    it = iter(step_noise)
+    got = sample_k(model.model, noise.to(dev), init.to(dev), mask.to(dev), steps, sampler_type=sampler_type, sigma_min=0.3,
+                   sigma_max=80.0, device=str(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=7.0,
+                   noise_sampler=lambda s_, sn_: next(it).to(dev), inpaint_noise=lambda i: renoise[i].to(dev))
+    sig = osamp.get_sigmas_polyexponential(steps, 0.3, 80.0, 1.0)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
+    x0, cb = osamp.inpainting_start_and_callback(init, noise * sig[0], mask, steps, lambda i: renoise[i])
+    solver = osamp.sample_dpmpp_2m_sde if sampler_type == "dpmpp-2m-sde" else osamp.sample_dpmpp_3m_sde
+    want = solver(lambda x, s_: osamp.vdenoise(fn, x, s_), x0.clone(), sig, lambda i, a_, b_: step_noise[i], callback=cb)
+    e = assert_close(f"inpainting trajectory ({sampler_type}) vs matched oracle", got, want, 2e-2)
+    print(f"\n[inpaint {sampler_type}] rel-L2 {e:.2e}")
+    with pytest.raises(NotImplementedError):
+        sample_k(model.model, noise.to(dev), None, None, steps, sampler_type="k-heun", cross_attn_cond=c.to(dev), global_cond=g.to(dev))
 
 
 @pytest.mark.parametrize("t_len", [1024, 6144])

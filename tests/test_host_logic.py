@@ -61,11 +61,21 @@ def test_reference_init_conventions():
 
 def test_unsupported_configs_fail_loudly():
     cfg = MC.reduced(MC.stable_audio_open_1_0())
-    for key, val in (("transformer_type", "x-transformers"), ("global_cond_type", "adaLN"), ("patch_size", 2)):
+    for key, val in (("transformer_type", "x-transformers"), ("patch_size", 2)):
         bad = json.loads(json.dumps(cfg))
         bad["model"]["diffusion"]["config"][key] = val
         with pytest.raises(NotImplementedError):
             S.create_model_from_config(bad)
+    bad = json.loads(json.dumps(cfg))
+    bad["model"]["diffusion"]["config"]["global_cond_type"] = "film"
+    with pytest.raises(ValueError):
+        S.create_model_from_config(bad)
+    # adaLN is supported: same keys as the reference (transformer.py:651-655)
+    ada = json.loads(json.dumps(cfg))
+    ada["model"]["diffusion"]["config"]["global_cond_type"] = "adaLN"
+    m = S.create_model_from_config(ada)
+    d = ada["model"]["diffusion"]["config"]["embed_dim"]
+    assert tuple(m.state_dict()["model.model.transformer.layers.0.to_scale_shift_gate.1.weight"].shape) == (6 * d, d)
     bad = json.loads(json.dumps(cfg))
     bad["model"]["diffusion"]["type"] = "adp_cfg_1d"
     with pytest.raises(NotImplementedError):

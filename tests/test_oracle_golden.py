@@ -70,6 +70,20 @@ def test_dit_small_forward(small_dit_sd):
     assert rel_l2(r1, g["cfg7_T64"]) < 3e-2
 
 
+def test_dit_adaln_forward():
+    """global_cond_type='adaLN' (transformer.py:665-689): oracle vs the reference's outputs."""
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    g = cases.load("dit_adaln_small")
+    sd = synthetic.synth_state_dict(_template_sd(lambda: DiffusionTransformer(**cases.SMALL_DIT, global_cond_type="adaLN")), 0)
+    assert "transformer.layers.2.to_scale_shift_gate.1.weight" in sd
+    for t_len in (64, 77):
+        x, t, c, gl = cases.dit_inputs(2, t_len, 128, 96, 1)
+        assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=1.0, adaln=True), g[f"cfg1_T{t_len}"]) < TOL
+    x, t, c, gl = cases.dit_inputs(2, 77, 128, 96, 1)
+    assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=7.0, adaln=True), g["cfg7_T77"]) < TOL
+    assert rel_l2(odit.dit_forward(sd, x, t, c, None, 3, 4, adaln=True), g["noglobal_T77"]) < TOL
+
+
 def test_ops_codec_and_quantisation():
     g = cases.load("ops")
     from stable_audio_tools.models.blocks import SnakeBeta

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import sampler as osamp
-from stable_audio_tools.inference.sampling import dpmpp3m_coefficients, get_sigmas_polyexponential
+from stable_audio_tools.inference.sampling import dpmpp2m_coefficients, dpmpp3m_coefficients, get_sigmas_polyexponential
 
 
 def test_polyexponential_schedule():
@@ -113,3 +113,53 @@ def test_fused_coefficient_form_equals_multistep_form(eta):
         x, d1, d2 = new, d, d1
     assert ((x - want).norm() / want.norm()).item() < 1e-12
     assert coeffs[-1] == (0.0, 1.0, 0.0, 0.0, 0.0)
+
+
+@pytest.mark.parametrize("eta", [0.0, 1.0])
+@pytest.mark.parametrize("solver_type", ["midpoint", "heun"])
+def test_dpmpp2m_fused_form_equals_multistep_form(eta, solver_type):
+    """dpmpp-2m-sde (the reference's default sampler_type): the product's host scalars (a, b, c1, 0, cn) reproduce the
+    restated multistep recursion on an arbitrary smooth denoiser with injected noise."""
+    steps = 17
+    sig = osamp.get_sigmas_polyexponential(steps, 0.4, 120.0, 1.0).double()
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(2, 3, 11, generator=g, dtype=torch.float64) * sig[0]
+    target = torch.randn(2, 3, 11, generator=g, dtype=torch.float64)
+    noises = [torch.randn(2, 3, 11, generator=g, dtype=torch.float64) for _ in range(steps)]
+    den = lambda x, s: target + (x - target) / (1 + s.view(-1, 1, 1) ** 2) + 0.1 * torch.tanh(x / (1 + s.view(-1, 1, 1)))
+    want = osamp.sample_dpmpp_2m_sde(den, x0.clone(), sig, lambda i, a, b: noises[i], eta=eta, solver_type=solver_type)
+    coeffs = dpmpp2m_coefficients([float(v) for v in sig], eta=eta, solver_type=solver_type)
+    x, d1 = x0.clone(), None
+    for i in range(steps):
+        d = den(x, sig[i].expand(2))
+        a, b, c1, c2, cn = coeffs[i]
+        assert c2 == 0.0
+        x = a * x + b * d + (c1 * (d - d1) if d1 is not None else 0) + cn * noises[i]
+        d1 = d
+    assert ((x - want).norm() / want.norm()).item() < 1e-12
+
+
+def test_dpmpp2m_deterministic_limit_matches_probability_flow():
+    s_data = 0.7
+    sig = osamp.get_sigmas_polyexponential(300, 0.05, 80.0, 1.0)
+    x0 = torch.randn(2, 3, 50, dtype=torch.float64) * 80.0
+    out = osamp.sample_dpmpp_2m_sde(_gaussian_denoiser(s_data), x0.clone(), sig[:-1].double(), lambda i, a, b: torch.zeros_like(x0), eta=0.0)
+    exact = x0 * math.sqrt((s_data ** 2 + sig[-2].item() ** 2) / (s_data ** 2 + sig[0].item() ** 2))
+    assert ((out - exact).norm() / exact.norm()).item() < 1e-3
+
+
+def test_inpainting_mask_schedule_and_build_mask():
+    """build_mask against the reference's own outputs (tests/golden/host.npz) and the shrinking binary mask."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    from stable_audio_tools.inference.generation import build_mask
+    from stable_audio_tools.inference.sampling import get_bmask_strength
+    g = cases.load("host")
+    for i, ma in enumerate(cases.MASK_ARGS):
+        assert torch.equal(build_mask(1024, ma), g[f"mask_{i}"]), f"mask_args case {i}"
+    m = build_mask(1024, cases.MASK_ARGS[0])
+    steps = 10
+    kept = [int(osamp.get_bmask(i, steps, m).sum()) for i in range(steps)]
+    assert kept == sorted(kept) and kept[-1] == 1024          # the keep-region only grows; the last step keeps everything
+    assert all(torch.equal(osamp.get_bmask(i, steps, m), (m <= get_bmask_strength(i, steps)).long()) for i in range(steps))

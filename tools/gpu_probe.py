@@ -57,10 +57,10 @@ def gemm_bench():
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
-        for v in (22, 15, 30, 17, 16, 20):
+        for v in (22, 15, 30, 31, 32, 16):
             if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26) and n % 256:
                 continue
-            if v == 30 and n % 192:
+            if v in (30, 31) and n % 192:
                 continue
             f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
             ms = timeit(f)
