@@ -40,6 +40,30 @@ def section(name, fn):
 
 
 def gemm_bench():
+    if os.environ.get("PROBE_DATA"):
+        # how much of the MFMA "peak" is a function of operand data (power): zeros vs N(0,1) operands, production kernel (22)
+        # and its MFMA-only ablation (522: fragments stay in registers, no LDS traffic, no barriers)
+        m, n, k = 16400, 12288, 1536
+        c = torch.zeros(m, n, device=dev)
+        for label, mk in (("zeros", lambda *sh: torch.zeros(*sh, device=dev)), ("randn", lambda *sh: torch.randn(*sh, device=dev)),
+                          ("randn*1e-3", lambda *sh: torch.randn(*sh, device=dev) * 1e-3)):
+            a = mk(m, k).to(torch.bfloat16)
+            w = mk(n, k).to(torch.bfloat16)
+            for v in (22, 522, 622):
+                f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
+                ms = timeit(f)
+                print(f"data {label:10s} v{v} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
+        return
+    if os.environ.get("PROBE_PP"):
+        for name, m, n, k in [("proj", 2050, 1536, 1536), ("ff_in B8", 16400, 12288, 1536)]:
+            a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+            c = torch.zeros(m, n, device=dev)
+            for v in (22, 33, 133, 233, 333, 433, 533):
+                f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
+                ms = timeit(f)
+                print(f"pp-ablate {name:9s} v{v} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
+        return
     if os.environ.get("PROBE_QUANT"):
         shapes = [("256 tiles", 2048, 8192, 1536), ("384 tiles", 2048, 12288, 1536), ("432 tiles", 2050, 12288, 1536), ("512 tiles", 2048, 16384, 1536),
                   ("128 tiles", 2048, 4096, 1536), ("162 tiles", 2050, 4608, 1536)]
@@ -57,10 +81,10 @@ def gemm_bench():
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
-        for v in (22, 15, 30, 31, 32, 16):
-            if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26) and n % 256:
+        for v in (22, 34, 35, 30):
+            if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26, 33, 34) and n % 256:
                 continue
-            if v in (30, 31) and n % 192:
+            if v in (30, 31, 35) and n % 192:
                 continue
             f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
             ms = timeit(f)
