@@ -377,6 +377,34 @@ int glue_cfg_denoise(const float* mo, const float* x, float* den, int B, int C, 
     return 0;
 }
 
+// out <- sum_i c_i * t_i over up to five terms (NULL terms are skipped; any t_i may alias out): the state update of the
+// single-step k-diffusion samplers (Euler / Heun / DPM-2 / LMS / DPM++ 2S ancestral / DPM-Solver fast) and of the
+// rectified-flow Euler loop, which are all linear combinations of the state, denoiser outputs and noise
+__global__ __launch_bounds__(256) void lincomb_kernel(float* __restrict__ out, const float* t0, const float* t1, const float* t2,
+                                                      const float* t3, const float* t4, float c0, float c1, float c2, float c3,
+                                                      float c4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        if (t0) v += c0 * t0[i];
+        if (t1) v += c1 * t1[i];
+        if (t2) v += c2 * t2[i];
+        if (t3) v += c3 * t3[i];
+        if (t4) v += c4 * t4[i];
+        out[i] = v;
+    }
+}
+
+extern "C" int sat_lincomb(float* out_dev, const float* t0, float c0, const float* t1, float c1, const float* t2, float c2,
+                           const float* t3, float c3, const float* t4, float c4, int64_t n, sat_stream_t stream) {
+    SAT_CHECK_ARG(out_dev && n > 0, SAT_E_INVALID, "lincomb: null output or n <= 0");
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out_dev, t0, t1, t2, t3, t4, c0, c1, c2, c3,
+                       c4, n);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 // inference/sampling.py:178-190 (inpainting_callback): keep-region of the current step's binary mask is re-noised init data
 __global__ __launch_bounds__(256) void inpaint_mix_kernel(float* __restrict__ x, const float* __restrict__ init,
                                                           const float* __restrict__ noise, const float* __restrict__ mask,

@@ -414,12 +414,7 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
 // DBG (micro-benchmark ablations, wrong results): 0 production; 1 all tiles load tile (0,0); 2 no LDS-DMA in the loop;
 // 3 no ds_read/MFMA; 4 = 2 + no barrier; 5 = 4 + no ds_read (MFMA on register-resident fragments); 6 = 5 + no epilogue
 // (the stores are kept behind a never-true data-dependent test so that the MFMAs stay)
-// GH ("ghost fold", B=1): M = 2*1025 leaves 2 rows beyond the last full 256-row tile; as a ninth row of tiles they cost a
-// full tile each (a tile is bound by staging its W panel, not by its MFMAs) and push FFN-in at 256x192 from exactly two
-// rounds of 256 workgroups into a third.  With GH the grid only has the full row tiles; the <= 8 leftover rows ride along
-// as one more 1-KiB wave-load per stage, and in the workgroups of tile rows 0..WN-1 the wave (wm = 0, wn = tile row)
-// multiplies them with the W fragments of its own 64 columns (2 extra MFMAs per k-step on one of NW waves).
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int GH = 0>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
@@ -433,14 +428,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // 56 wave-loads) the first WL%NW waves carry one more than the rest, and the counted vmcnt wait is per wave.
     constexpr int NW = WM * WN;
     constexpr int WL_A = BM * CPR / 64;
-    constexpr int WL_AB = (BM + BN) * CPR / 64;
-    constexpr int WL = WL_AB + (GH ? 1 : 0);       // + the leftover rows (8 rows = one wave-load)
+    constexpr int WL = (BM + BN) * CPR / 64;
     constexpr int LPT = (WL + NW - 1) / NW;        // max LDS-DMA instructions per tile per wave
     constexpr int N_FULL = WL - (LPT - 1) * NW;    // waves [0, N_FULL) issue LPT, the others LPT-1
     constexpr bool UNIFORM = (WL % NW) == 0;
     constexpr int ROWB = BK * 2;
-    constexpr int STAGE_BYTES = (BM + BN) * ROWB + (GH ? 32 * ROWB : 0);   // leftover rows: a 32-row MFMA block, 8 rows staged
-    static_assert(!GH || (BK == 64 && DBG == 0), "ghost fold: BK = 64 only");
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int D = NS - 1;                      // prefetch distance
     static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
 
@@ -455,7 +448,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     const int l31 = lane & 31;
 
     const int M = g.M, N = g.N, K = g.K;
-    const int tiles_m = GH ? M / BM : (M + BM - 1) / BM;
+    const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = N / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -482,12 +475,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int L = i * NW + wave;               // wave-uniform
-        const bool is_g = GH && L == WL_AB;        // the leftover rows
-        const bool is_a = L < WL_A || is_g;
-        int q = (L < WL_A ? L : is_g ? 0 : L - WL_A) * 64 + lane;
+        const bool is_a = L < WL_A;
+        int q = (is_a ? L : L - WL_A) * 64 + lane;
         int row = q / CPR, pos = q % CPR;
         int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
-        int gm = (is_g ? tiles_m * BM : dbg_same ? 0 : m0) + row;
+        int gm = (dbg_same ? 0 : m0) + row;
         gm = gm < M ? gm : M - 1;
         int gn = (dbg_same ? 0 : n0) + row;
         gn = gn < N ? gn : N - 1;                  // only reachable by the unused slot of a short wave
@@ -502,16 +494,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // ghost fold: the wave that also multiplies the leftover rows with its own W columns
-    const bool ghost_wave = GH && wm == 0 && tm < WN && wn == tm;
-    f32x16 acc_g[1][NI];
-    if constexpr (GH != 0) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_g[0][j][r] = 0.f;
-    }
-
     auto stage_in = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE_BYTES;
 #pragma unroll
@@ -566,21 +548,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                 __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
             }
         }
-        if constexpr (GH != 0) {
-            // outside the pinned region: a wave-uniform branch taken by one wave of WN workgroups per W panel
-            if (ghost_wave) {
-                const char* sg = sb + BN * ROWB;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    bf16x8 ag = *reinterpret_cast<const bf16x8*>(sg + lds_off_bk<BK>(l31, ks * 2 + half));
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        bf16x8 bg = *reinterpret_cast<const bf16x8*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
-                        acc_g[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, bg, acc_g[0][j], 0, 0, 0);
-                    }
-                }
-            }
-        }
     };
 
     const int nk = K / BK;
@@ -631,9 +598,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         if (acc[0][0][0] != 12345.678f) return;
     }
     if (wave_rows_valid) gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
-    if constexpr (GH != 0) {
-        if (ghost_wave) gemm_epilogue<EPI, 1, NI>(g, acc_g, tiles_m * BM, n0 + wn * TN, half, l31);
-    }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
@@ -823,17 +787,12 @@ int launch_pipe2(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int GH = 0>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
-    if constexpr (GH != 0) {
-        // the ghost fold covers 1..8 leftover rows and needs one full tile row per wave column; otherwise the plain grid
-        const int left = a.M % BM;
-        if (left == 0 || left > 8 || a.M / BM < WN) return launch_pipe<BM, BN, BK, WM, WN, NS, EPI, DBG, 0>(a, stream);
-    }
     constexpr int NT = WM * WN * 64;
-    constexpr int LDS = NS * ((BM + BN) * BK * 2 + (GH ? 32 * BK * 2 : 0));
+    constexpr int LDS = NS * (BM + BN) * BK * 2;
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
-    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG, GH>;
+    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -841,7 +800,7 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     }
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
     SAT_CHECK_ARG(a.K % BK == 0 && a.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
-    int tiles = (GH ? a.M / BM : cdiv(a.M, BM)) * (a.N / BN);
+    int tiles = cdiv(a.M, BM) * (a.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, a);
     SAT_LAUNCH_CHECK();
     return 0;
@@ -864,226 +823,6 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Ping-pong ("8-phase") 256x256 tile: 8 waves (2 x 4), 128x64 per wave, BK = 64, LDS = two K-tiles of 64 KiB.
-// The pipe kernels above run all waves of a workgroup in lockstep: everybody stages, everybody reads fragments, everybody
-// issues MFMAs, so the matrix pipe idles during every fragment-read burst.  Here the two wave rows are staggered by one
-// barrier (guide section 5, "256^2 8-phase template"): a K-tile is four phases, one 64x32 quadrant of the wave tile per
-// phase (8 MFMAs of 32x32x16); in every barrier interval one wave row is inside its MFMA block while the other reads
-// the fragments of ITS next quadrant from LDS and issues one eighth of the next-but-one K-tile as LDS-DMA.  Each SIMD
-// hosts one wave of each row (wave w -> SIMD w % 4), so its matrix pipe always has work.
-//
-// Phase p of K-tile k (q = 4k + p), quadrant = (rows half p>>1, column block p&1) of the wave tile:
-//   R(q): issue the ds_reads of the operand that the quadrant needs and is not in registers yet
-//           p0: A rows lo(k)   p1: W cols 1(k)   p2: A rows hi(k)   p3: W cols 0(k+1)
-//         issue the 16-KiB slot (2 LDS-DMA per thread) that overwrites what R(q-2) read:
-//           p0: A-hi(k+1)      p1: W0(k+2)       p2: A-lo(k+2)      p3: W1(k+2)
-//         s_waitcnt vmcnt(10): the slot issued five phases ago (the one R(q+1) reads) has landed; barrier
-//   M(q): lgkmcnt(0) (the fragment reads flew while the OTHER wave row was in its MFMA block); 8 MFMAs; barrier
-// RAW: a slot is read one phase after every wave waited for its share and passed a barrier.  WAR: a slot is restaged
-// two phases after its last read, i.e. a full barrier interval after the readers' lgkmcnt(0).
-// Five slots (1.25 K-tiles) are in flight in steady state; prologue and tail count only the slots that exist.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {      // n is wave-uniform and even, 0..10
-    switch (n) {
-        case 10: wait_vmcnt<10>(); break;
-        case 8: wait_vmcnt<8>(); break;
-        case 6: wait_vmcnt<6>(); break;
-        case 4: wait_vmcnt<4>(); break;
-        case 2: wait_vmcnt<2>(); break;
-        default: wait_vmcnt<0>(); break;
-    }
-}
-
-// DBG (timing ablations, wrong results): 1 no fragment ds_reads in the loop; 2 no LDS-DMA in the loop; 3 no MFMAs; 4 = 1 + 2;
-// 5 = 4 + no barriers (MFMA-only loop)
-template <int EPI, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
-    constexpr bool dbg_nords = DBG == 1 || DBG >= 4, dbg_nodma = DBG == 2 || DBG >= 4, dbg_nomfma = DBG == 3, dbg_nobar = DBG == 5;
-    constexpr int BM = 256, BN = 256, BK = 64;
-    constexpr int SLOT = 128 * 128;              // bytes: 128 rows x 64 bf16
-    constexpr int TILE = 4 * SLOT;               // [A-lo][A-hi][W0][W1]
-    constexpr int O_ALO = 0, O_AHI = SLOT, O_W0 = 2 * SLOT, O_W1 = 3 * SLOT;
-    constexpr int MI = 4, NI = 2;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2;                    // wave row 0..1 (128 rows each) == stagger group
-    const int wc = wave & 3;                     // wave column 0..3 (64 columns each)
-    const int half = lane >> 5;
-    const int l31 = lane & 31;
-
-    const int M = g.M, N = g.N, K = g.K;
-    const int tiles_m = (M + BM - 1) / BM;
-    const int tiles_n = N / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    if (tiles_m <= tiles_n) {
-        tn = bid / tiles_m;
-        tm = bid - tn * tiles_m;
-    } else {
-        tm = bid / tiles_n;
-        tn = bid - tm * tiles_n;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = K / BK;
-    const bool rows_valid = (m0 + wr * 128) < M;       // M-tail tile: the lower wave row may have nothing to compute
-
-    // ---- staging: slot-local row lr (0..127), 16-B chunk pos; element offsets from A / W (32-bit)
-    //   A-lo: lr -> tile row (lr>>6)*128 + (lr&63)        A-hi: + 64
-    //   W0  : lr -> tile col (lr>>5)*64  + (lr&31)        W1  : + 32
-    unsigned off_a[2][2], off_w[2][2];               // [lo/hi or 0/1][load u]
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int q = u * 512 + tid;
-        const int lr = q >> 3, pos = q & 7;
-        const int c = pos ^ ((lr >> 1) & 7);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int ar = m0 + (lr >> 6) * 128 + (lr & 63) + h * 64;
-            ar = ar < M ? ar : M - 1;
-            off_a[h][u] = (unsigned)ar * (unsigned)K + c * 8;
-            const int wrow = n0 + (lr >> 5) * 64 + (lr & 31) + h * 32;
-            off_w[h][u] = (unsigned)wrow * (unsigned)K + c * 8;
-        }
-    }
-    auto issue = [&](const bf16_t* base, const unsigned (&off)[2], int kt, int lds_off) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[u] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(smem + lds_off + (u * 512 + wave * 64) * 16), 16, 0, 0);
-    };
-
-    // ---- fragment reads (same XOR swizzle as the pipe kernels, keyed by the slot-local row; row blocks are multiples of 32
-    //      so the swizzle term only depends on l31)
-    const int swz = (l31 >> 1) & 7;
-    const int a_row = (wr * 64 + l31) * 128;         // + ii*32*128 for the second 32-row block of the half
-    const int w_row = (wc * 32 + l31) * 128;
-    bf16x8 afr[2][4], w0fr[4], w1fr[4];
-    auto read_a = [&](int buf_off) {                 // buf_off: byte offset of the A-lo or A-hi slot
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                afr[ii][ks] = *reinterpret_cast<const bf16x8*>(smem + buf_off + a_row + ii * 32 * 128 + (((ks * 2 + half) ^ swz) << 4));
-    };
-    auto read_w = [&](bf16x8 (&dst)[4], int buf_off) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            dst[ks] = *reinterpret_cast<const bf16x8*>(smem + buf_off + w_row + (((ks * 2 + half) ^ swz) << 4));
-    };
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    auto mfma_block = [&](int ih, const bf16x8 (&wf)[4], int j) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-                acc[ih * 2 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ii][ks], wf[ks], acc[ih * 2 + ii][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // slot issued at (virtual) phase q: q%4 == 0 -> A-hi of K-tile q/4 + 1, else -> K-tile q/4 + 2 (W0, A-lo, W1); it exists
-    // if that K-tile does.  allowed(q) = LDS-DMA instructions of this thread that may stay in flight after phase q's wait
-    auto allowed = [&](int q) {
-        int cnt = 0;
-#pragma unroll
-        for (int d = 0; d < 5; ++d) {
-            const int qq = q - d;
-            const int t = (qq >> 2) + ((qq & 3) == 0 ? 1 : 2);
-            cnt += (qq >= -7 && t < nk) ? 1 : 0;
-        }
-        return 2 * cnt;
-    };
-    // ---- prologue: virtual phases -7..-1
-    issue(g.W, off_w[0], 0, O_W0);
-    issue(g.A, off_a[0], 0, O_ALO);
-    issue(g.W, off_w[1], 0, O_W1);
-    issue(g.A, off_a[1], 0, O_AHI);
-    if (nk > 1) {
-        issue(g.W, off_w[0], 1, TILE + O_W0);
-        issue(g.A, off_a[0], 1, TILE + O_ALO);
-        issue(g.W, off_w[1], 1, TILE + O_W1);
-    }
-    wait_vmcnt_dyn(allowed(-1));                     // W0(0) and A-lo(0) have landed
-    __builtin_amdgcn_s_barrier();
-    read_w(w0fr, O_W0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();       // the stagger: wave row 1 runs one barrier interval behind row 0
-
-    for (int k = 0; k < nk; ++k) {
-        const int cur = (k & 1) * TILE, nxt = TILE - cur;
-        const bool steady = k >= 1 && k + 3 < nk;    // every slot in the 5-phase window exists
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            // ---------------- R(q)
-            __builtin_amdgcn_sched_barrier(0);
-            if (p == 0) {
-                if (rows_valid && !dbg_nords) read_a(cur + O_ALO);
-                if (k + 1 < nk && !dbg_nodma) issue(g.A, off_a[1], k + 1, nxt + O_AHI);
-            } else if (p == 1) {
-                if (rows_valid && !dbg_nords) read_w(w1fr, cur + O_W1);
-                if (k + 2 < nk && !dbg_nodma) issue(g.W, off_w[0], k + 2, cur + O_W0);
-            } else if (p == 2) {
-                if (rows_valid && !dbg_nords) read_a(cur + O_AHI);
-                if (k + 2 < nk && !dbg_nodma) issue(g.A, off_a[0], k + 2, cur + O_ALO);
-            } else {
-                if (rows_valid && k + 1 < nk && !dbg_nords) read_w(w0fr, nxt + O_W0);
-                if (k + 2 < nk && !dbg_nodma) issue(g.W, off_w[1], k + 2, cur + O_W1);
-            }
-            if (dbg_nodma) wait_vmcnt<0>();
-            else if (steady) wait_vmcnt<10>();
-            else wait_vmcnt_dyn(allowed(4 * k + p));
-            __builtin_amdgcn_sched_barrier(0);
-            if (!dbg_nobar) __builtin_amdgcn_s_barrier();
-            // ---------------- M(q)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (rows_valid && !dbg_nomfma) {
-                if (p == 0) mfma_block(0, w0fr, 0);
-                else if (p == 1) mfma_block(0, w1fr, 1);
-                else if (p == 2) mfma_block(1, w0fr, 0);
-                else mfma_block(1, w1fr, 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (!dbg_nobar) __builtin_amdgcn_s_barrier();
-        }
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();       // balance the stagger
-
-    if (rows_valid) gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wr * 128, n0 + wc * 64, half, l31);
-}
-
-template <int EPI, int DBG = 0>
-int launch_pp(const GemmArgs& a, hipStream_t stream) {
-    constexpr int LDS = 2 * 4 * 128 * 128;           // 128 KiB
-    auto kern = gemm_pp_kernel<EPI, DBG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
-    SAT_CHECK_ARG(a.N % 256 == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the 256-column tile", a.N);
-    SAT_CHECK_ARG(a.K % 64 == 0, SAT_E_UNSUPPORTED, "gemm: K=%d not a multiple of 64", a.K);
-    SAT_CHECK_ARG((long long)a.M * a.K < (1ll << 32) && (long long)a.N * a.K < (1ll << 32), SAT_E_UNSUPPORTED,
-                  "gemm(ping-pong): operand larger than 2^32 elements");
-    int tiles = cdiv(a.M, 256) * (a.N / 256);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, a);
-    SAT_LAUNCH_CHECK();
-    return 0;
-}
-
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
     if (a.variant >= 100) {   // micro-benchmark ablations (tools/gpu_probe.py), EPI_F32 only
@@ -1095,11 +834,6 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
                 case 422: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 4>(a, stream);
                 case 522: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 5>(a, stream);
                 case 622: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 6>(a, stream);
-                case 133: return launch_pp<EPI, 1>(a, stream);
-                case 233: return launch_pp<EPI, 2>(a, stream);
-                case 333: return launch_pp<EPI, 3>(a, stream);
-                case 433: return launch_pp<EPI, 4>(a, stream);
-                case 533: return launch_pp<EPI, 5>(a, stream);
                 case 213: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 2>(a, stream);
                 case 413: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 4>(a, stream);
                 case 513: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 5>(a, stream);
@@ -1166,11 +900,6 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 28: return launch_pipe2<128, 128, 64, 4, 2, 4, EPI>(a, stream);
         case 29: return launch_pipe2<256, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
-        case 31: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 1>(a, stream);
-        case 32: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 1>(a, stream);
-        case 33: return launch_pp<EPI>(a, stream);
-        case 34: return launch_pipe<256, 256, 64, 2, 4, 2, EPI>(a, stream);
-        case 35: return launch_pipe<256, 192, 64, 2, 3, 2, EPI>(a, stream);
         default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
     }
 }

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "sat_dit_profile_read": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64),
                                        POINTER(c_int64)]),
     "sat_cfg_combine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
+    "sat_lincomb": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float,
+                              c_int64, c_void_p]),
     "sat_inpaint_mix": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64, c_int32, c_void_p]),
     "sat_dpmpp3m_update": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                      c_float, c_int64, c_void_p]),

@@ -7,7 +7,7 @@ import typing as tp
 import numpy as np
 import torch
 
-from .sampling import sample_k
+from .sampling import sample_k, sample_rf
 from .utils import prepare_audio
 
 
@@ -74,10 +74,16 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale: float = 6, condi
 
     conditioning_inputs = {k: (v.float() if v is not None else v) for k, v in conditioning_inputs.items()}
 
-    if model.diffusion_objective != "v":
-        raise NotImplementedError("only the v-objective / k-diffusion path is implemented (rectified flow is out of scope)")
-    sampled = sample_k(model.model, noise, init_audio, mask, steps, **sampler_kwargs, **conditioning_inputs, cfg_scale=cfg_scale,
-                       batch_cfg=True, rescale_cfg=True, device=device, disable_tqdm=disable_tqdm)
+    if model.diffusion_objective == "v":
+        sampled = sample_k(model.model, noise, init_audio, mask, steps, **sampler_kwargs, **conditioning_inputs, cfg_scale=cfg_scale,
+                           batch_cfg=True, rescale_cfg=True, device=device, disable_tqdm=disable_tqdm)
+    elif model.diffusion_objective == "rectified_flow":                # generation.py:235-244
+        sampler_kwargs.pop("sigma_min", None)
+        sampler_kwargs.pop("sampler_type", None)
+        sampled = sample_rf(model.model, noise, init_data=init_audio, steps=steps, **sampler_kwargs, **conditioning_inputs,
+                            cfg_scale=cfg_scale, batch_cfg=True, rescale_cfg=True, device=device, disable_tqdm=disable_tqdm)
+    else:
+        raise ValueError(f"unknown diffusion objective {model.diffusion_objective}")
 
     if model.pretransform and not return_latents:
         sampled = model.pretransform.decode(sampled)

@@ -1,5 +1,8 @@
-"""``sample_k`` with the ``dpmpp-3m-sde`` / ``dpmpp-2m-sde`` samplers (reference ``inference/sampling.py:144-228``),
-plain sampling, variations (``init_data``) and inpainting (``init_data`` + soft ``mask``).
+"""``sample_k`` (reference ``inference/sampling.py:144-228``): the multistep SDE samplers ``dpmpp-3m-sde`` /
+``dpmpp-2m-sde`` (fused per-step update), the single-step k-diffusion samplers ``k-heun``, ``k-lms``,
+``k-dpmpp-2s-ancestral``, ``k-dpm-2``, ``k-dpm-fast`` (generic linear-combination update), plain sampling, variations
+(``init_data``) and inpainting (``init_data`` + soft ``mask``); ``sample_rf`` / ``sample_discrete_euler`` for
+rectified-flow models (:28-60, :236-270).
 
 The reference delegates to the un-vendored ``k-diffusion==0.1.1``: ``VDenoiser`` (:159),
 ``get_sigmas_polyexponential`` (:165), ``sample_dpmpp_3m_sde`` (:228).  Here the host computes
@@ -19,7 +22,7 @@ import torch
 from .. import _hip
 from ..models.diffusion import DiTWrapper
 
-SUPPORTED_SAMPLERS = ("dpmpp-3m-sde", "dpmpp-2m-sde")
+SUPPORTED_SAMPLERS = ("dpmpp-3m-sde", "dpmpp-2m-sde", "k-heun", "k-lms", "k-dpmpp-2s-ancestral", "k-dpm-2", "k-dpm-fast")
 
 
 def get_sigmas_polyexponential(n, sigma_min, sigma_max, rho=1.0):
@@ -99,6 +102,151 @@ def get_bmask_strength(i, steps):
     return (i + 1) / steps
 
 
+def _lin(out, terms):
+    """out <- sum c_i * t_i (``sat_lincomb``; up to five terms, terms may alias ``out``)."""
+    assert 1 <= len(terms) <= 5
+    args = []
+    for c, t in terms:
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == out.numel()
+        args += [_hip.ptr(t), float(c)]
+    args += [None, 0.0] * (5 - len(terms))
+    _hip.check(_hip.lib().sat_lincomb(_hip.ptr(out), *args, out.numel(), _hip.stream()))
+    return out
+
+
+def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
+    """k_diffusion.sampling.get_ancestral_step: (sigma_down, sigma_up)."""
+    if not eta:
+        return sigma_to, 0.0
+    sigma_up = min(sigma_to, eta * math.sqrt(sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2))
+    return math.sqrt(sigma_to ** 2 - sigma_up ** 2), sigma_up
+
+
+def lms_coefficient(order, t, i, j):
+    """k_diffusion.sampling.linear_multistep_coeff: integral over [t_i, t_{i+1}] of the j-th Lagrange basis polynomial through
+    t_i, t_{i-1}, ..., t_{i-order+1}.  k-diffusion integrates numerically (scipy quad, epsrel 1e-4); the polynomial is
+    integrated exactly here."""
+    import numpy as np
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+    poly = np.polynomial.Polynomial([1.0])
+    for k in range(order):
+        if k != j:
+            poly = poly * np.polynomial.Polynomial([-t[i - k], 1.0]) / (t[i - j] - t[i - k])
+    integ = poly.integ()
+    return float(integ(t[i + 1]) - integ(t[i]))
+
+
+def _single_step_sampler(sampler_type, denoise, after_denoise, x, sigmas, sigma_min, sigma_max, steps, noise_sampler, eta, s_noise,
+                         order=4):
+    """The k-diffusion samplers that evaluate the denoiser more than once per step or keep a derivative history
+    (sampling.py:212-225).  ``denoise(x, sigma, out)`` is the fused CFG + VDenoiser DiT evaluation; ``after_denoise(i, x,
+    sigma, denoised)`` runs the inpainting re-injection and the user callback exactly where k-diffusion calls ``callback``.
+    Every state update is one ``sat_lincomb`` launch with scalars computed here in float64."""
+    den = torch.empty_like(x)
+    den2 = torch.empty_like(x)
+    x2 = torch.empty_like(x)
+
+    def draw(s_from, s_to):
+        nz = noise_sampler(s_from, s_to) if noise_sampler is not None else torch.randn_like(x)
+        return nz.float().contiguous()
+
+    if sampler_type == "k-dpm-fast":
+        # k_diffusion.sampling.sample_dpm_fast -> DPMSolver.dpm_solver_fast(x, t_start, t_end, nfe=steps, eta=0): orders 3/2/1 in
+        # log-sigma time t = -log(sigma); eps(x, t) = (x - D(x, sigma(t))) / sigma(t); no final step to sigma = 0
+        if sigma_min <= 0 or sigma_max <= 0:
+            raise ValueError("sigma_min and sigma_max must not be 0")
+        nfe = steps
+        t_start, t_end = -math.log(sigma_max), -math.log(sigma_min)
+        m = nfe // 3 + 1
+        ts = [t_start + (t_end - t_start) * i / m for i in range(m + 1)]
+        orders = [3] * (m - 2) + [2, 1] if nfe % 3 == 0 else [3] * (m - 1) + [nfe % 3]
+        sig = lambda t: math.exp(-t)
+        eps1 = torch.empty_like(x)
+        u = torch.empty_like(x)
+        for i, order_i in enumerate(orders):
+            t, t_next = ts[i], ts[i + 1]
+            h = t_next - t
+            denoise(x, sig(t), den)
+            after_denoise(i, x, sig(t), den)
+            st = sig(t)
+            # eps = (x - den)/st is never materialised: every combination below is written in (x, den, u, den_u)
+            if order_i == 1:
+                c = -sig(t_next) * math.expm1(h) / st
+                _lin(x, [(1 + c, x), (-c, den)])
+            elif order_i == 2:
+                r1 = 0.5
+                s1 = t + r1 * h
+                c = -sig(s1) * math.expm1(r1 * h) / st
+                _lin(u, [(1 + c, x), (-c, den)])                       # u1 = x - sigma(s1) expm1(r1 h) eps
+                denoise(u, sig(s1), den2)                              # eps_r1 = (u1 - den2) / sigma(s1)
+                a = -sig(t_next) * math.expm1(h)
+                b = -sig(t_next) / (2 * r1) * math.expm1(h)
+                # x_2 = x + a eps + b (eps_r1 - eps)
+                _lin(x, [(1 + (a - b) / st, x), (-(a - b) / st, den), (b / sig(s1), u), (-b / sig(s1), den2)])
+            else:
+                r1, r2 = 1 / 3, 2 / 3
+                s1, s2 = t + r1 * h, t + r2 * h
+                c = -sig(s1) * math.expm1(r1 * h) / st
+                _lin(u, [(1 + c, x), (-c, den)])                       # u1
+                denoise(u, sig(s1), den2)                              # eps_r1 = (u - den2)/sigma(s1)
+                _lin(eps1, [(1 / sig(s1), u), (-1 / sig(s1), den2)])
+                a2 = -sig(s2) * math.expm1(r2 * h)
+                b2 = -sig(s2) * (r2 / r1) * (math.expm1(r2 * h) / (r2 * h) - 1)
+                # u2 = x + a2 eps + b2 (eps_r1 - eps)
+                _lin(u, [(1 + (a2 - b2) / st, x), (-(a2 - b2) / st, den), (b2, eps1)])
+                denoise(u, sig(s2), den2)                              # eps_r2 = (u2 - den2)/sigma(s2)
+                a3 = -sig(t_next) * math.expm1(h)
+                b3 = -sig(t_next) / r2 * (math.expm1(h) / h - 1)
+                _lin(x, [(1 + (a3 - b3) / st, x), (-(a3 - b3) / st, den), (b3 / sig(s2), u), (-b3 / sig(s2), den2)])
+        return x
+
+    hist = []                                                          # k-lms: derivative history, newest last
+    for i in range(len(sigmas) - 1):
+        s_i, s_n = sigmas[i], sigmas[i + 1]
+        denoise(x, s_i, den)
+        after_denoise(i, x, s_i, den)
+        if sampler_type == "k-lms":
+            d = hist.pop(0) if len(hist) == order else torch.empty_like(x)
+            _lin(d, [(1 / s_i, x), (-1 / s_i, den)])                    # to_d
+            hist.append(d)
+            cur = min(i + 1, order)
+            cs = [lms_coefficient(cur, sigmas, i, j) for j in range(cur)]
+            _lin(x, [(1.0, x)] + [(c, dd) for c, dd in zip(cs, reversed(hist))])
+        elif sampler_type in ("k-heun", "k-dpm-2"):
+            dt = s_n - s_i
+            if s_n == 0:
+                _lin(x, [(1 + dt / s_i, x), (-dt / s_i, den)])          # Euler: x + (x - D)/sigma * dt
+            elif sampler_type == "k-heun":
+                _lin(x2, [(1 + dt / s_i, x), (-dt / s_i, den)])
+                denoise(x2, s_n, den2)
+                # x + dt/2 * [(x - D)/s_i + (x2 - D2)/s_n]
+                _lin(x, [(1 + dt / (2 * s_i), x), (-dt / (2 * s_i), den), (dt / (2 * s_n), x2), (-dt / (2 * s_n), den2)])
+            else:
+                s_mid = math.exp(0.5 * (math.log(s_i) + math.log(s_n)))
+                dt1, dt2 = s_mid - s_i, s_n - s_i
+                _lin(x2, [(1 + dt1 / s_i, x), (-dt1 / s_i, den)])
+                denoise(x2, s_mid, den2)
+                _lin(x, [(1.0, x), (dt2 / s_mid, x2), (-dt2 / s_mid, den2)])
+        elif sampler_type == "k-dpmpp-2s-ancestral":
+            s_down, s_up = get_ancestral_step(s_i, s_n, eta)
+            if s_down == 0:
+                dt = s_down - s_i
+                _lin(x, [(1 + dt / s_i, x), (-dt / s_i, den)])
+            else:
+                t, t_next = -math.log(s_i), -math.log(s_down)
+                h = t_next - t
+                s = t + 0.5 * h
+                _lin(x2, [(math.exp(-s) / math.exp(-t), x), (-math.expm1(-h * 0.5), den)])
+                denoise(x2, math.exp(-s), den2)
+                _lin(x, [(math.exp(-t_next) / math.exp(-t), x), (-math.expm1(-h), den2)])
+            if s_n > 0:
+                _lin(x, [(1.0, x), (s_noise * s_up, draw(s_i, s_n))])
+        else:
+            raise NotImplementedError(sampler_type)
+    return x
+
+
 @torch.no_grad()
 def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type="dpmpp-2m-sde", sigma_min=0.5, sigma_max=50,
              rho=1.0, device="cuda", callback=None, cond_fn=None, disable_tqdm: bool = False, noise_sampler=None,
@@ -108,7 +256,8 @@ def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type
              input_concat_cond=None, prepend_cond=None, prepend_cond_mask=None, negative_global_cond=None,
              negative_input_concat_cond=None, **extra_args):
     if sampler_type not in SUPPORTED_SAMPLERS:
-        raise NotImplementedError(f"sampler_type '{sampler_type}' is not implemented by the HIP path; supported: {SUPPORTED_SAMPLERS}")
+        raise NotImplementedError(f"sampler_type '{sampler_type}' is not implemented by the HIP path; supported: {SUPPORTED_SAMPLERS}"
+                                  " (k-dpm-adaptive needs a host-synchronised error controller and is not offered)")
     if cond_fn is not None:
         raise NotImplementedError("cond_fn (gradient guidance through the denoiser) is outside the supported hot path")
     if mask is not None and init_data is None:
@@ -121,20 +270,16 @@ def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type
     dit = model_fn.model
 
     sigmas = get_sigmas_polyexponential(steps, sigma_min, sigma_max, rho)
-    if sampler_type == "dpmpp-3m-sde":
-        coeffs = dpmpp3m_coefficients(sigmas, eta=eta, s_noise=s_noise)
-    else:
-        coeffs = dpmpp2m_coefficients(sigmas, eta=eta, s_noise=s_noise, solver_type=extra_args.pop("solver_type", "midpoint"))
     lib = _hip.lib()
     unit_noise = noise.float().contiguous()
     noise = unit_noise * sigmas[0]
+    rows = noise.numel() // noise.shape[-1]
     if init_data is not None and mask is not None:
         # INPAINTING (sampling.py:166-172): x = (init + noise) where the step-0 binary mask keeps the input, noise elsewhere
         init_data = init_data.float().contiguous()
         mask = mask.to(noise.device, torch.float32).contiguous()
         assert mask.ndim == 1 and mask.numel() == noise.shape[-1], "mask must be [latent_length]"
         x = noise.clone()
-        rows = x.numel() // x.shape[-1]
         _hip.check(lib.sat_inpaint_mix(_hip.ptr(x), _hip.ptr(init_data), _hip.ptr(unit_noise), _hip.ptr(mask), sigmas[0],
                                        get_bmask_strength(0, steps), rows, x.shape[-1], _hip.stream()))
     elif init_data is not None:
@@ -143,6 +288,26 @@ def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type
         x = noise                                                       # SAMPLING
 
     dit.prepare_generation(cross_attn_cond, global_cond, cfg_scale, negative_cross_attn_cond, negative_cross_attn_mask)
+
+    def after_denoise(i, x, sigma, denoised):
+        if mask is not None:
+            # sampling.py:178-190: right after the denoiser evaluation, x is overwritten in the keep-region of this step's
+            # (shrinking) binary mask with the init data re-noised to the current sigma (fresh Gaussian draw per step)
+            rn = inpaint_noise(i) if inpaint_noise is not None else torch.randn_like(x)
+            _hip.check(lib.sat_inpaint_mix(_hip.ptr(x), _hip.ptr(init_data), _hip.ptr(rn.float().contiguous()), _hip.ptr(mask),
+                                           sigma, get_bmask_strength(i, steps), rows, x.shape[-1], _hip.stream()))
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigma, "sigma_hat": sigma, "denoised": denoised})
+
+    if sampler_type not in ("dpmpp-3m-sde", "dpmpp-2m-sde"):
+        denoise = lambda xin, sigma, out: dit.denoise(xin, sigma, cfg_scale=cfg_scale, scale_phi=scale_phi, out=out)
+        return _single_step_sampler(sampler_type, denoise, after_denoise, x, sigmas, sigma_min, sigma_max, steps, noise_sampler,
+                                    eta, s_noise, order=extra_args.pop("order", 4))
+
+    if sampler_type == "dpmpp-3m-sde":
+        coeffs = dpmpp3m_coefficients(sigmas, eta=eta, s_noise=s_noise)
+    else:
+        coeffs = dpmpp2m_coefficients(sigmas, eta=eta, s_noise=s_noise, solver_type=extra_args.pop("solver_type", "midpoint"))
     n = x.numel()
     d = torch.empty_like(x)
     d1 = torch.empty_like(x)
@@ -150,14 +315,7 @@ def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type
     have = 0
     for i in range(steps):
         dit.denoise(x, sigmas[i], cfg_scale=cfg_scale, scale_phi=scale_phi, out=d)
-        if mask is not None:
-            # sampling.py:178-190: right after the denoiser evaluation, x is overwritten in the keep-region of this step's
-            # (shrinking) binary mask with the init data re-noised to the current sigma (fresh Gaussian draw per step)
-            rn = inpaint_noise(i) if inpaint_noise is not None else torch.randn_like(x)
-            _hip.check(lib.sat_inpaint_mix(_hip.ptr(x), _hip.ptr(init_data), _hip.ptr(rn.float().contiguous()), _hip.ptr(mask),
-                                           sigmas[i], get_bmask_strength(i, steps), rows, x.shape[-1], _hip.stream()))
-        if callback is not None:
-            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": d})
+        after_denoise(i, x, sigmas[i], d)
         a, b, c1, c2, cn = coeffs[i]
         nz = None
         if cn != 0.0:
@@ -168,3 +326,29 @@ def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type
         d, d1, d2 = d2, d, d1      # D2 <- D1, D1 <- D; the old D2 buffer is recycled for the next D
         have = min(have + 1, 2)
     return x
+
+
+@torch.no_grad()
+def sample_discrete_euler(model, x, steps, sigma_max=1, verbose=False, callback=None, **extra_args):
+    """Rectified-flow Euler integration (reference sampling.py:28-60): t from sigma_max down to 0, x <- x + dt * model(x, t)."""
+    x = x.float().contiguous()
+    t = torch.linspace(sigma_max, 0, steps + 1)
+    for i in range(steps):
+        t_curr, t_prev = float(t[i]), float(t[i + 1])
+        v = model(x, torch.full((x.shape[0],), t_curr, dtype=torch.float32, device=x.device), **extra_args).float().contiguous()
+        _lin(x, [(1.0, x), (t_prev - t_curr, v)])
+        if callback is not None:
+            callback({"x": x, "i": i, "t": t_curr})
+    return x
+
+
+@torch.no_grad()
+def sample_rf(model_fn, noise, init_data=None, steps=100, sigma_max=1, device="cuda", callback=None, cond_fn=None,
+              disable_tqdm: bool = False, **extra_args):
+    """reference sampling.py:236-270: rectified-flow sampling / variations through the discrete Euler loop."""
+    if cond_fn is not None:
+        raise NotImplementedError("cond_fn (gradient guidance through the denoiser) is outside the supported hot path")
+    sigma_max = min(sigma_max, 1)
+    noise = noise.float()
+    x = init_data.float() * (1 - sigma_max) + noise * sigma_max if init_data is not None else noise
+    return sample_discrete_euler(model_fn, x, steps, sigma_max, verbose=not disable_tqdm, callback=callback, **extra_args)

@@ -137,6 +137,13 @@ int sat_dpmpp3m_update(float* x_dev, const float* d_dev, const float* d1_dev, co
                        const float* noise_dev, float a, float b, float c1, float c2, float cn,
                        int64_t n, sat_stream_t stream);
 
+/* out <- c0*t0 + c1*t1 + c2*t2 + c3*t3 + c4*t4 over n floats; NULL terms are skipped, terms may alias out_dev.
+ * State update of the single-step k-diffusion samplers selected at inference/sampling.py:212-225 (sample_heun, sample_lms,
+ * sample_dpmpp_2s_ancestral, sample_dpm_2, sample_dpm_fast) and of sample_discrete_euler (:28-60): each is a linear
+ * combination of the state, denoiser outputs and noise with host-computed scalars. */
+int sat_lincomb(float* out_dev, const float* t0, float c0, const float* t1, float c1, const float* t2, float c2,
+                const float* t3, float c3, const float* t4, float c4, int64_t n, sat_stream_t stream);
+
 /* Inpainting re-injection (inference/sampling.py:98-103 get_bmask, :178-190 inpainting_callback, :168-172 initial mix):
  *   x[r, i] <- init[r, i] + noise[r, i] * sigma     wherever mask[i] <= strength      (in place on x_dev)
  * x/init/noise are [rows, t] (rows = batch * channels), mask is the [t] soft mask of generation.py:269-290 and

@@ -128,3 +128,145 @@ def inpainting_start_and_callback(init_data, noise_scaled, mask, steps, renoise)
         bm = get_bmask(i, steps, mask)
         x[:, :, :] = ((init_data + renoise(i) * sigma) * bm + x * (1 - bm))[:, :, :]
     return x0, callback
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The single-step k-diffusion samplers selectable at inference/sampling.py:212-225 (k-diffusion 0.1.1, restated, unpinned)
+# ---------------------------------------------------------------------------------------------------------------------
+def to_d(x, sigma, denoised):
+    return (x - denoised) / sigma
+
+
+def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
+    if not eta:
+        return sigma_to, 0.0
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def sample_heun(denoiser, x, sigmas, callback=None):                      # K.sampling.sample_heun, s_churn = 0
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = denoiser(x, sigmas[i] * s_in)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        d = to_d(x, sigmas[i], denoised)
+        dt = sigmas[i + 1] - sigmas[i]
+        if sigmas[i + 1] == 0:
+            x = x + d * dt
+        else:
+            x_2 = x + d * dt
+            d_2 = to_d(x_2, sigmas[i + 1], denoiser(x_2, sigmas[i + 1] * s_in))
+            x = x + (d + d_2) / 2 * dt
+    return x
+
+
+def sample_dpm_2(denoiser, x, sigmas, callback=None):                     # K.sampling.sample_dpm_2, s_churn = 0
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = denoiser(x, sigmas[i] * s_in)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        d = to_d(x, sigmas[i], denoised)
+        if sigmas[i + 1] == 0:
+            x = x + d * (sigmas[i + 1] - sigmas[i])
+        else:
+            sigma_mid = sigmas[i].log().lerp(sigmas[i + 1].log(), 0.5).exp()
+            x_2 = x + d * (sigma_mid - sigmas[i])
+            d_2 = to_d(x_2, sigma_mid, denoiser(x_2, sigma_mid * s_in))
+            x = x + d_2 * (sigmas[i + 1] - sigmas[i])
+    return x
+
+
+def linear_multistep_coeff(order, t, i, j):
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def fn(tau):
+        prod = 1.0
+        for k in range(order):
+            if j != k:
+                prod *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return prod
+    return integrate.quad(fn, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+def sample_lms(denoiser, x, sigmas, order=4, callback=None):               # K.sampling.sample_lms
+    s_in = x.new_ones([x.shape[0]])
+    sig = [float(v) for v in sigmas]
+    ds = []
+    for i in range(len(sigmas) - 1):
+        denoised = denoiser(x, sigmas[i] * s_in)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        ds.append(to_d(x, sigmas[i], denoised))
+        if len(ds) > order:
+            ds.pop(0)
+        cur_order = min(i + 1, order)
+        coeffs = [linear_multistep_coeff(cur_order, sig, i, j) for j in range(cur_order)]
+        x = x + sum(c * d for c, d in zip(coeffs, reversed(ds)))
+    return x
+
+
+def sample_dpmpp_2s_ancestral(denoiser, x, sigmas, noise_sampler, eta=1.0, s_noise=1.0, callback=None):
+    s_in = x.new_ones([x.shape[0]])
+    for i in range(len(sigmas) - 1):
+        denoised = denoiser(x, sigmas[i] * s_in)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
+        sigma_down, sigma_up = get_ancestral_step(float(sigmas[i]), float(sigmas[i + 1]), eta)
+        if sigma_down == 0:
+            x = x + to_d(x, sigmas[i], denoised) * (sigma_down - sigmas[i])
+        else:
+            t, t_next = -math.log(float(sigmas[i])), -math.log(sigma_down)
+            h = t_next - t
+            s = t + 0.5 * h
+            x_2 = (math.exp(-s) / math.exp(-t)) * x - math.expm1(-h * 0.5) * denoised
+            denoised_2 = denoiser(x_2, math.exp(-s) * s_in)
+            x = (math.exp(-t_next) / math.exp(-t)) * x - math.expm1(-h) * denoised_2
+        if sigmas[i + 1] > 0:
+            x = x + noise_sampler(i, sigmas[i], sigmas[i + 1]) * s_noise * sigma_up
+    return x
+
+
+def sample_dpm_fast(denoiser, x, sigma_min, sigma_max, n, callback=None):  # K.sampling.sample_dpm_fast, eta = 0 (DPMSolver)
+    s_in = x.new_ones([x.shape[0]])
+    sigma = lambda t: math.exp(-t)
+    eps = lambda xx, t: (xx - denoiser(xx, sigma(t) * s_in)) / sigma(t)
+    t_start, t_end = -math.log(sigma_max), -math.log(sigma_min)
+    m = n // 3 + 1
+    ts = [t_start + (t_end - t_start) * i / m for i in range(m + 1)]
+    orders = [3] * (m - 2) + [2, 1] if n % 3 == 0 else [3] * (m - 1) + [n % 3]
+    for i, order in enumerate(orders):
+        t, t_next = ts[i], ts[i + 1]
+        h = t_next - t
+        e = eps(x, t)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigma(t), "sigma_hat": sigma(t), "denoised": x - sigma(t) * e})
+        if order == 1:
+            x = x - sigma(t_next) * math.expm1(h) * e
+        elif order == 2:
+            r1 = 0.5
+            s1 = t + r1 * h
+            u1 = x - sigma(s1) * math.expm1(r1 * h) * e
+            e1 = eps(u1, s1)
+            x = x - sigma(t_next) * math.expm1(h) * e - sigma(t_next) / (2 * r1) * math.expm1(h) * (e1 - e)
+        else:
+            r1, r2 = 1 / 3, 2 / 3
+            s1, s2 = t + r1 * h, t + r2 * h
+            u1 = x - sigma(s1) * math.expm1(r1 * h) * e
+            e1 = eps(u1, s1)
+            u2 = x - sigma(s2) * math.expm1(r2 * h) * e - sigma(s2) * (r2 / r1) * (math.expm1(r2 * h) / (r2 * h) - 1) * (e1 - e)
+            e2 = eps(u2, s2)
+            x = x - sigma(t_next) * math.expm1(h) * e - sigma(t_next) / r2 * (math.expm1(h) / h - 1) * (e2 - e)
+    return x
+
+
+# inference/sampling.py:28-60 (sample_discrete_euler): rectified flow
+def sample_discrete_euler(model, x, steps, sigma_max=1.0):
+    t = torch.linspace(sigma_max, 0, steps + 1)
+    for t_curr, t_prev in zip(t[:-1], t[1:]):
+        x = x + (t_prev - t_curr) * model(x, t_curr * torch.ones((x.shape[0],), dtype=x.dtype))
+    return x

@@ -252,7 +252,68 @@ def test_sample_k_inpainting_and_2m(dev, small_dit, sampler_type):
     e = assert_close(f"inpainting trajectory ({sampler_type}) vs matched oracle", got, want, 2e-2)
     print(f"\n[inpaint {sampler_type}] rel-L2 {e:.2e}")
     with pytest.raises(NotImplementedError):
-        sample_k(model.model, noise.to(dev), None, None, steps, sampler_type="k-heun", cross_attn_cond=c.to(dev), global_cond=g.to(dev))
+        sample_k(model.model, noise.to(dev), None, None, steps, sampler_type="k-dpm-adaptive", cross_attn_cond=c.to(dev),
+                 global_cond=g.to(dev))
+
+
+@pytest.mark.parametrize("sampler_type", ["k-heun", "k-lms", "k-dpmpp-2s-ancestral", "k-dpm-2", "k-dpm-fast"])
+def test_sample_k_single_step_samplers(dev, small_dit, sampler_type):
+    """The other sampler_type values of sample_k (sampling.py:212-225): product trajectory (fused CFG/VDenoiser DiT call + one
+    sat_lincomb per state update) vs the oracle restatement driving the oracle DiT, ancestral noise injected."""
+    from oracle import dit as odit, sampler as osamp
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.inference.sampling import sample_k
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dsd = _sub(sd, "model.model.")
+    b, steps, t_len = 2, 6, 24
+    c = synthetic.synth_input("c", (b, 130, dc["cond_token_dim"]), 91)
+    g = synthetic.synth_input("g", (b, 2 * dc["cond_token_dim"]), 92)
+    noise = synthetic.synth_input("noise", (b, 64, t_len), 93)
+    step_noise = [synthetic.synth_input(f"sn{i}", (b, 64, t_len), 95 + i) for i in range(steps)]
+    it = iter(step_noise)
+    seen = []
+    got = sample_k(model.model, noise.to(dev), None, None, steps, sampler_type=sampler_type, sigma_min=0.3, sigma_max=80.0,
+                   device=str(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=7.0,
+                   noise_sampler=lambda s_, sn_: next(it).to(dev), callback=lambda a: seen.append(a["i"]))
+    sig = osamp.get_sigmas_polyexponential(steps, 0.3, 80.0, 1.0)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
+    den = lambda x, s_: osamp.vdenoise(fn, x, s_)
+    x0 = noise * sig[0]
+    if sampler_type == "k-heun":
+        want = osamp.sample_heun(den, x0, sig)
+    elif sampler_type == "k-lms":
+        want = osamp.sample_lms(den, x0, sig)
+    elif sampler_type == "k-dpm-2":
+        want = osamp.sample_dpm_2(den, x0, sig)
+    elif sampler_type == "k-dpmpp-2s-ancestral":
+        want = osamp.sample_dpmpp_2s_ancestral(den, x0, sig, lambda i, a_, b_: step_noise[i])
+    else:
+        want = osamp.sample_dpm_fast(den, x0, 0.3, 80.0, steps)
+    e = assert_close(f"{sampler_type} trajectory vs matched oracle", got, want, 2e-2)
+    assert seen == list(range(len(seen))) and len(seen) >= 2
+    print(f"\n[{sampler_type}] rel-L2 {e:.2e}")
+
+
+def test_rectified_flow_euler(dev, small_dit):
+    """diffusion_objective 'rectified_flow' (generation.py:235-244 -> sampling.py:236-270, :28-60): x <- x + dt * model(x, t)
+    with the CFG-batched raw DiT output."""
+    from oracle import dit as odit, sampler as osamp
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.inference.sampling import sample_rf
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dsd = _sub(sd, "model.model.")
+    b, steps, t_len = 2, 5, 24
+    c = synthetic.synth_input("c", (b, 130, dc["cond_token_dim"]), 111)
+    g = synthetic.synth_input("g", (b, 2 * dc["cond_token_dim"]), 112)
+    noise = synthetic.synth_input("noise", (b, 64, t_len), 113)
+    init = synthetic.synth_input("init", (b, 64, t_len), 114)
+    got = sample_rf(model.model, noise.to(dev), init_data=init.to(dev), steps=steps, sigma_max=0.8, device=str(dev),
+                    cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=3.0, batch_cfg=True, rescale_cfg=True)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=3.0, rnd=bf16_round)
+    want = osamp.sample_discrete_euler(fn, init * (1 - 0.8) + noise * 0.8, steps, 0.8)
+    assert_close("rectified-flow Euler trajectory", got, want, 1e-2)
 
 
 @pytest.mark.parametrize("t_len", [1024, 6144])

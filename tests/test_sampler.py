@@ -163,3 +163,51 @@ def test_inpainting_mask_schedule_and_build_mask():
     kept = [int(osamp.get_bmask(i, steps, m).sum()) for i in range(steps)]
     assert kept == sorted(kept) and kept[-1] == 1024          # the keep-region only grows; the last step keeps everything
     assert all(torch.equal(osamp.get_bmask(i, steps, m), (m <= get_bmask_strength(i, steps)).long()) for i in range(steps))
+
+
+def test_single_step_samplers_converge_to_the_probability_flow_solution():
+    """k-heun / k-dpm-2 / k-lms / k-dpmpp-2s-ancestral(eta=0) / k-dpm-fast restatements (k-diffusion is un-vendored): on the
+    Gaussian toy problem every one must converge to the exact ODE solution at its order (2, 2, 4, 2, ~3)."""
+    s_data = 0.7
+    den = _gaussian_denoiser(s_data)
+    errs = {}
+    for steps in (50, 100):
+        sig = osamp.get_sigmas_polyexponential(steps, 0.05, 80.0, 1.0).double()
+        x0 = torch.randn(2, 3, 20, dtype=torch.float64, generator=torch.Generator().manual_seed(1)) * 80.0
+        exact = x0 * math.sqrt((s_data ** 2 + sig[-2].item() ** 2) / (s_data ** 2 + sig[0].item() ** 2))
+        exact_f = x0 * math.sqrt((s_data ** 2 + 0.05 ** 2) / (s_data ** 2 + 80.0 ** 2))
+        zero = lambda i, a, b: torch.zeros_like(x0)
+        out = {"heun": osamp.sample_heun(den, x0.clone(), sig[:-1]), "dpm2": osamp.sample_dpm_2(den, x0.clone(), sig[:-1]),
+               "lms": osamp.sample_lms(den, x0.clone(), sig[:-1]),
+               "2s": osamp.sample_dpmpp_2s_ancestral(den, x0.clone(), sig[:-1], zero, eta=0.0)}
+        errs[steps] = {k: ((v - exact).norm() / exact.norm()).item() for k, v in out.items()}
+        errs[steps]["fast"] = ((osamp.sample_dpm_fast(den, x0.clone(), 0.05, 80.0, steps) - exact_f).norm() / exact_f.norm()).item()
+    for k, order in (("heun", 2), ("dpm2", 2), ("2s", 2), ("lms", 3.5)):
+        assert errs[100][k] < 1e-3 and errs[50][k] / errs[100][k] > 2 ** order * 0.8, (k, errs)
+    assert errs[100]["fast"] < 5e-4
+
+
+def test_ancestral_sampler_keeps_the_marginal_variance():
+    """k-dpmpp-2s-ancestral with eta = 1 on the Gaussian toy problem: std at the last positive sigma = sqrt(s^2 + sigma^2)."""
+    s_data, steps = 1.3, 80
+    sig = osamp.get_sigmas_polyexponential(steps, 0.3, 100.0, 1.0).double()
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(64, 8, 256, generator=g, dtype=torch.float64) * math.sqrt(s_data ** 2 + 100.0 ** 2)
+    out = osamp.sample_dpmpp_2s_ancestral(_gaussian_denoiser(s_data), x0, sig[:-1], lambda i, a, b: torch.randn(x0.shape, generator=g, dtype=torch.float64))
+    want = math.sqrt(s_data ** 2 + sig[-2].item() ** 2)
+    assert abs(out.std().item() / want - 1) < 2e-2
+    sd, su = osamp.get_ancestral_step(2.0, 1.0)
+    assert abs(sd ** 2 + su ** 2 - 1.0) < 1e-12
+
+
+def test_lms_coefficients_exact_vs_quadrature():
+    """The product integrates the Lagrange basis exactly; k-diffusion (and the oracle) use scipy quad with epsrel 1e-4."""
+    from stable_audio_tools.inference.sampling import get_ancestral_step, lms_coefficient
+    sig = [float(v) for v in osamp.get_sigmas_polyexponential(12, 0.3, 80.0, 1.0)]
+    for i in range(12):
+        cur = min(i + 1, 4)
+        for j in range(cur):
+            a, b = lms_coefficient(cur, sig, i, j), osamp.linear_multistep_coeff(cur, sig, i, j)
+            assert abs(a - b) <= 2e-4 * max(abs(a), abs(b), 1e-9), (i, j, a, b)
+    assert get_ancestral_step(2.0, 1.0) == pytest.approx(osamp.get_ancestral_step(2.0, 1.0))
+    assert get_ancestral_step(2.0, 0.0)[0] == 0.0

@@ -54,16 +54,6 @@ def gemm_bench():
                 ms = timeit(f)
                 print(f"data {label:10s} v{v} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
         return
-    if os.environ.get("PROBE_PP"):
-        for name, m, n, k in [("proj", 2050, 1536, 1536), ("ff_in B8", 16400, 12288, 1536)]:
-            a = torch.randn(m, k, device=dev).to(torch.bfloat16)
-            w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
-            c = torch.zeros(m, n, device=dev)
-            for v in (22, 33, 133, 233, 333, 433, 533):
-                f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
-                ms = timeit(f)
-                print(f"pp-ablate {name:9s} v{v} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
-        return
     if os.environ.get("PROBE_QUANT"):
         shapes = [("256 tiles", 2048, 8192, 1536), ("384 tiles", 2048, 12288, 1536), ("432 tiles", 2050, 12288, 1536), ("512 tiles", 2048, 16384, 1536),
                   ("128 tiles", 2048, 4096, 1536), ("162 tiles", 2050, 4608, 1536)]
@@ -81,10 +71,10 @@ def gemm_bench():
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
-        for v in (22, 34, 35, 30):
-            if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26, 33, 34) and n % 256:
+        for v in (22, 26, 30, 15, 16):
+            if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26) and n % 256:
                 continue
-            if v in (30, 31, 35) and n % 192:
+            if v == 30 and n % 192:
                 continue
             f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, v, _hip.stream()))
             ms = timeit(f)
