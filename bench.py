@@ -30,6 +30,9 @@ SAMPLE_RATE = 44100
 SAMPLER = dict(sampler_type="dpmpp-3m-sde", sigma_min=0.3, sigma_max=500)
 CFG_SCALE = 7.0
 DIT_STEPS = 100
+# developer smoke test of the RCCL path on a 1-GPU box: run under torch.distributed.run --nproc-per-node 1 with this set, and the
+# process group, barrier, all-reduce and the final all-gather are exercised with world_size 1
+FORCE_DIST = os.environ.get("SAT_BENCH_FORCE_DIST") == "1"
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -64,7 +67,7 @@ def one_generation(model, cond, seed, dev, world):
     scratch = torch.empty(1, dtype=torch.int32, device=dev)
     for i in range(b):
         _hip.check(_hip.lib().sat_float_to_int16(_hip.ptr(audio[i]), _hip.ptr(out[i]), c * n, 0, _hip.ptr(scratch), _hip.stream()))
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         from stable_audio_tools.inference.distributed import gather_sharded
         return gather_sharded(out, world * b)          # the single RCCL collective (xGMI)
     return out
@@ -119,9 +122,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or FORCE_DIST
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     model, sd = build_model(dev)
     if rank != 0 or args.no_cpu_baseline:
@@ -136,17 +141,17 @@ def main():
     for i in range(args.warmup):
         one_generation(model, cond, 1000 + i, dev, world)
     _hip.check(lib.sat_dit_profile(dit._plan, 1))
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_generation(model, cond, 2000 + i, dev, world)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -190,7 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
