@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1, help="prompts per GPU (BASELINE config 2: 1; config 3: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
+                    help="GEMM operand type: bf16 (headline) or fp8 = BASELINE config 5 (e4m3 to_qkv / cross to_q / FF-in, rest bf16)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,6 +137,7 @@ def main():
     prompt_ids = list(range(world * args.batch))[rank::world]
     cond = conditioning(model, prompt_ids, dev)
     dit = model.model.model
+    dit.set_gemm_dtype(args.dtype)
 
     from stable_audio_tools import _hip
     lib = _hip.lib()
@@ -183,12 +186,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 (to_qkv, cross to_q, FF-in; per-token x per-channel scales) + bf16, fp32 accumulate",
             "data": "synthetic (random-init weights of the SA-Open-1.0 architecture, random T5 embeddings)",
             "config": {"workload": "Stable-Audio-Open-1.0 DiT shape (24 layers, D=1536, S=1025, CFG 7 -> 2 sequences/prompt) + Oobleck decode, "
                                    f"{args.batch} prompt(s)/GPU x 47.55 s, 100 DPM-Solver++(3M) SDE steps", "prompts_per_gpu": args.batch,
                        "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
-            "roofline": {"bound": "mfma", "kernel": f"FFN-in SwiGLU GEMM M={m.value} N={n.value} K={k.value} (bf16 MFMA, fp32 acc)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": f"FFN-in SwiGLU GEMM M={m.value} N={n.value} K={k.value} ({args.dtype} MFMA, fp32 acc)", "achieved": achieved,
                          "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_us": avg_ms * 1e3, "launches_timed": cnt.value},
         }

@@ -23,7 +23,7 @@ void sat_set_error(const char* fmt, ...) {
     g_last_error = buf;
 }
 extern "C" const char* sat_last_error(void) { return g_last_error.c_str(); }
-extern "C" int sat_version(void) { return 2; }
+extern "C" int sat_version(void) { return 3; }
 
 // ------------------------------------------------------------------------------ plan
 namespace {
@@ -43,6 +43,7 @@ struct LayerW {
     float *pre_g, *pre_b, *cross_g, *cross_b, *ff_g, *ff_b;
     bf16_t *w_qkv, *w_o, *w_cq, *w_ckv, *w_co, *w_ff1, *w_ff2;
     float *b_ff1, *b_ff2;
+    float *s_qkv, *s_cq, *s_ff1;      // fp8_gemm: per-output-channel scales (the weights above then hold e4m3 bytes)
 };
 
 }  // namespace
@@ -59,6 +60,7 @@ struct sat_dit_plan {
     float *ce0_w, *ce2_w, *ge0_w, *ge2_w;
     float *win_eff, *wout_eff;
     float *rope_cos, *rope_sin, *inv_freq;
+    int fp8_mode = 2;               // 2: v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, 2x rate); 1: v_mfma_f32_32x32x16_fp8_fp8
     float* ssg_w = nullptr;         // adaLN: [depth * 6D, D] stacked to_scale_shift_gate weights
     // per-generation context (sat_dit_prepare_context)
     char* ctx_buf = nullptr;
@@ -103,6 +105,17 @@ int pack_w(sat_dit_plan* p, Arena& ar, const std::string& name, int n, int k, in
     const float* src;
     SAT_TRY(get_tensor(p, name, (int64_t)n * k, &src));
     return sat_launch_pack_rows_bf16(src, *dst, n, k, interleave, s);
+}
+
+// fp8_gemm: e4m3 bytes + one scale per output channel instead of bf16
+int pack_w8(sat_dit_plan* p, Arena& ar, const std::string& name, int n, int k, int interleave, bf16_t** dst, float** scale,
+            hipStream_t s) {
+    *dst = (bf16_t*)ar.take((size_t)n * k);
+    *scale = (float*)ar.take((size_t)n * 4);
+    if (ar.dry) return 0;
+    const float* src;
+    SAT_TRY(get_tensor(p, name, (int64_t)n * k, &src));
+    return sat_launch_quant_rows_fp8(src, *dst, *scale, n, k, interleave, s);
 }
 
 int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
@@ -152,16 +165,20 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
         SAT_TRY(copy_f32(p, ar, pf + "pre_norm.beta", D, &L.pre_b, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.gamma", D, &L.ff_g, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.beta", D, &L.ff_b, s));
-        SAT_TRY(pack_w(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, s));
+        const bool f8 = c.fp8_gemm != 0;
+        if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, &L.s_qkv, s));
+        else SAT_TRY(pack_w(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, s));
         SAT_TRY(pack_w(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, s));
         if (Dct > 0) {
             SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.gamma", D, &L.cross_g, s));
             SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.beta", D, &L.cross_b, s));
-            SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, s));
+            if (f8) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, &L.s_cq, s));
+            else SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, s));
             SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_kv.weight", 2 * Dc, Dc, 0, &L.w_ckv, s));
             SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, s));
         }
-        SAT_TRY(pack_w(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, s));
+        if (f8) SAT_TRY(pack_w8(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, &L.s_ff1, s));
+        else SAT_TRY(pack_w(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, s));
         L.b_ff1 = (float*)ar.take((size_t)2 * inner * 4);
         if (!ar.dry) {
             const float* b1;
@@ -178,6 +195,7 @@ struct Workspace {
     float* X;
     bf16_t *A, *AO, *Q, *K, *Vt, *Hh;
     float *ff, *h1, *mo;
+    float* As;              // fp8_gemm: per-row scale of the quantised LayerNorm output in A
     float *gsum, *ssg;      // adaLN: silu(global + timestep embed) [bf, D]; per-layer modulation [bf, depth, 6, D]
     size_t qkv_bytes;
     size_t total;
@@ -208,6 +226,7 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     w.ff = (float*)take((size_t)bf * 256 * 4);
     w.h1 = (float*)take((size_t)bf * D * 4);
     w.mo = (float*)take((size_t)bf * c.io_channels * T * 4);
+    w.As = c.fp8_gemm ? (float*)take(M * 4) : nullptr;
     w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
     w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
     w.total = off;
@@ -227,7 +246,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     Workspace w = carve(p, bf, T, (char*)ws);
     SAT_CHECK_ARG(ws_bytes >= w.total, SAT_E_WORKSPACE, "dit forward: workspace %zu < required %zu", ws_bytes, w.total);
     const int D = c.embed_dim, H = c.num_heads, C = c.io_channels;
-    const bool adaln = c.adaln != 0;
+    const bool adaln = c.adaln != 0, f8 = c.fp8_gemm != 0;
     const int S = T + (adaln ? 0 : 1), M = bf * S, Spad = (int)round_up(S + 3, 128);
     const int ssg_ld = c.depth * 6 * D;      // per-sequence stride of the adaLN modulation vectors
 
@@ -254,9 +273,11 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         const LayerW& L = p->layers[l];
         // ---- self-attention branch (transformer.py:692)
         const float* mod = adaln ? w.ssg + (size_t)l * 6 * D : nullptr;     // + {0..5} * D: scale1p/shift/gate self, then ff
-        SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
+        if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.pre_g, L.pre_b, w.A, w.As, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
+        else SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_qkv; g.M = M; g.N = 3 * D; g.K = D;
+        if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_qkv; }
         g.heads.out[0] = w.Q; g.heads.out[1] = w.K; g.heads.out[2] = w.Vt;
         g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
         g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
@@ -275,9 +296,11 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             const int bc = (p->ctx_null_from >= 0 && p->ctx_null_from < bf) ? p->ctx_null_from : bf;
             const int Mc = bc * S;
             if (bc > 0) {
-                SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s));
+                if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.cross_g, L.cross_b, w.A, w.As, Mc, D, nullptr, nullptr, 1, 0, s));
+                else SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s));
                 g = GemmArgs{};
                 g.A = w.A; g.W = L.w_cq; g.M = Mc; g.N = D; g.K = D;
+                if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_cq; }
                 g.heads.out[0] = w.Q; g.heads.kind[0] = 0; g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
                 SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
                 const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lcpad * 64;
@@ -289,10 +312,13 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             }
         }
         // ---- feed-forward branch (transformer.py:700)
-        SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
-                                         ssg_ld, s));
+        if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.ff_g, L.ff_b, w.A, w.As, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr,
+                                                 S, ssg_ld, s));
+        else SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
+                                              ssg_ld, s));
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
+        if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_ff1; }
         const bool prof = p->prof_on && l == c.depth / 2 && p->prof_n < kProfMaxPairs;
         if (prof) {
             if ((int)p->prof_ev.size() < 2 * (p->prof_n + 1)) {
@@ -340,6 +366,7 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
                       cfg->num_heads, kvh);
     }
     SAT_CHECK_ARG(cfg->global_cond_dim % 4 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: global_cond_dim must be a multiple of 4");
+    SAT_CHECK_ARG(!cfg->fp8_gemm || cfg->embed_dim % 256 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: fp8_gemm needs embed_dim %% 256 == 0");
     sat_dit_plan* p = new (std::nothrow) sat_dit_plan();
     SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_plan_create: out of host memory");
     p->cfg = *cfg;
@@ -589,4 +616,23 @@ extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_
     g.heads.parts = 3; g.heads.heads = H; g.heads.S = s_len; g.heads.Spad = s_pad;
     g.heads.rope_cos = cs; g.heads.rope_sin = sn;
     return sat_launch_gemm(EPI_HEADS, g, s);
+}
+
+extern "C" int sat_quant_rows_fp8(const float* x, void* out8, float* row_scale, int32_t rows, int32_t k, sat_stream_t stream) {
+    return sat_launch_quant_rows_fp8(x, out8, row_scale, rows, k, 0, (hipStream_t)stream);
+}
+
+extern "C" int sat_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* y8, float* row_scale, int32_t m,
+                                 int32_t d, sat_stream_t stream) {
+    return sat_launch_layernorm_fp8(x, gamma, beta, y8, row_scale, m, d, nullptr, nullptr, 1, 0, (hipStream_t)stream);
+}
+
+extern "C" int sat_gemm_fp8_f32(const void* a8, const float* a_scale, const void* w8, const float* w_scale, const float* bias,
+                                float* c, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream) {
+    SAT_CHECK_ARG(a8 && w8 && a_scale && w_scale && c, SAT_E_INVALID, "gemm_fp8: null pointer");
+    GemmArgs g{};
+    g.A = (const bf16_t*)a8; g.W = (const bf16_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & 0xff;
+    g.C = c; g.ldc = n; g.accumulate = accumulate; g.a_scale = a_scale; g.w_scale = w_scale;
+    g.fp8 = (variant & 256) ? 1 : 2;      // bit 8 of variant: the plain 32x32x16 fp8 MFMA instead of the 2x-rate scaled 32x32x64
+    return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);
 }

@@ -414,7 +414,10 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
 // DBG (micro-benchmark ablations, wrong results): 0 production; 1 all tiles load tile (0,0); 2 no LDS-DMA in the loop;
 // 3 no ds_read/MFMA; 4 = 2 + no barrier; 5 = 4 + no ds_read (MFMA on register-resident fragments); 6 = 5 + no epilogue
 // (the stores are kept behind a never-true data-dependent test so that the MFMAs stay)
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>
+// FP8: A and W are e4m3 bytes.  The launcher hands the kernel K/2 "bf16 columns", so staging, LDS layout and swizzle are
+// byte-for-byte those of the bf16 kernel (128-B rows now hold 128 k); a 16-B fragment is two 8-byte MFMA operands:
+// v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16 rate, but every LDS / L2 / HBM byte carries twice the k.
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int FP8 = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int D = NS - 1;                      // prefetch distance
     static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
+    static_assert(!FP8 || (BK == 64 && DBG == 0), "fp8: 128-byte rows only");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -513,10 +517,112 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     };
     // fragments are double-buffered across the k-steps: the ds_reads of step ks+1 are issued BEFORE the MFMAs of
     // step ks, so the wave waits with a counted lgkmcnt and LDS latency hides behind the matrix pipe
+    typedef long i64x2 __attribute__((ext_vector_type(2)));
     auto compute = [&](int stage) {
         const char* sa = smem + stage * STAGE_BYTES;
         const char* sb = sa + BM * ROWB;
         constexpr int KS = BK / 16;
+        if constexpr (FP8 == 2) {
+            // v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 127): twice the MFMA rate of bf16 / plain fp8.  One
+            // instruction consumes 64 k: lane (row, half) supplies 32 bytes = bytes half*32 .. +31 of the 64-byte step.  Which k
+            // the hardware assigns to a (half, byte) slot is irrelevant as long as A and W are loaded identically (they are).
+            typedef int i32x8 __attribute__((ext_vector_type(8)));
+            constexpr int KS2 = BK / 32;               // 64-byte steps per 128-byte row
+            i32x8 af[2][MI], bfr[2][NI];
+            auto frag = [&](int ks, int buf) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int row = wm * TM + i * 32 + l31;
+                    u32x4 lo = *reinterpret_cast<const u32x4*>(sa + lds_off_bk<BK>(row, ks * 4 + half * 2));
+                    u32x4 hi = *reinterpret_cast<const u32x4*>(sa + lds_off_bk<BK>(row, ks * 4 + half * 2 + 1));
+                    af[buf][i] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int row = wn * TN + j * 32 + l31;
+                    u32x4 lo = *reinterpret_cast<const u32x4*>(sb + lds_off_bk<BK>(row, ks * 4 + half * 2));
+                    u32x4 hi = *reinterpret_cast<const u32x4*>(sb + lds_off_bk<BK>(row, ks * 4 + half * 2 + 1));
+                    bfr[buf][j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                }
+            };
+            // 16-wave workgroups have 128 VGPRs per lane: 64 accumulators + one set of 32-byte fragments (32) fit, two sets do not;
+            // four waves per SIMD cover the fragment-read latency instead
+            constexpr bool DBUF = NT < 1024;
+            if constexpr (!DBUF) {
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks) {
+                    frag(ks, 0);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
+                                                                                        0x7F7F7F7F);
+                }
+                return;
+            }
+            frag(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                if (ks + 1 < KS2) frag(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0,
+                                                                                    0x7F7F7F7F, 0, 0x7F7F7F7F);
+                if (ks + 1 < KS2) {
+                    constexpr int NR = 2 * (MI + NI), NM = MI * NI;
+#pragma unroll
+                    for (int r = 0; r < NM; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, NR / NM, 0);
+                    }
+                    if (NR % NM) __builtin_amdgcn_sched_group_barrier(0x100, NR % NM, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
+                }
+            }
+            return;
+        }
+        if constexpr (FP8 == 1) {
+            // fragment step ks = 32 k (two MFMAs): lane (row, half) holds bytes half*16 .. +15 of it, the first 8 feed one MFMA and
+            // the last 8 the next -- A and W use the same k permutation, so the dot product is unchanged
+            i64x2 af[2][MI], bfr[2][NI];
+            auto frag = [&](int ks, int buf) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[buf][i] = *reinterpret_cast<const i64x2*>(sa + lds_off_bk<BK>(wm * TM + i * 32 + l31, ks * 2 + half));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    bfr[buf][j] = *reinterpret_cast<const i64x2*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
+            };
+            frag(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) frag(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(af[ks & 1][i][h2], bfr[ks & 1][j][h2], acc[i][j], 0, 0, 0);
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int r = 0; r < MI + NI; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x8, 2 * MI * NI - (MI + NI), 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 2 * MI * NI, 0);
+                }
+            }
+            return;
+        }
         bf16x8 af[2][MI], bfr[2][NI];
         auto frag = [&](int ks, int buf) {
 #pragma unroll
@@ -596,6 +702,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 
     if constexpr (dbg_noepi) {
         if (acc[0][0][0] != 12345.678f) return;
+    }
+    if constexpr (FP8 != 0) {
+        // dequantise: per-token scale of A x per-output-channel scale of W (kept out of the last K-tile's MFMA schedule)
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave_rows_valid) {
+            float sw[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) sw[j] = g.w_scale[n0 + wn * TN + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    row = row < M ? row : M - 1;
+                    const float sa_r = g.a_scale[row];
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j][r] *= sa_r * sw[j];
+                }
+        }
     }
     if (wave_rows_valid) gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
 }
@@ -787,21 +912,26 @@ int launch_pipe2(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int FP8 = 0>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
     constexpr int LDS = NS * (BM + BN) * BK * 2;
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
-    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG>;
+    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG, FP8>;
     static bool attr_set = false;
     if (!attr_set) {
         SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
-    SAT_CHECK_ARG(a.K % BK == 0 && a.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
-    int tiles = cdiv(a.M, BM) * (a.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, a);
+    GemmArgs b = a;
+    if (FP8) {
+        SAT_CHECK_ARG(a.K % 128 == 0 && a.a_scale && a.w_scale, SAT_E_UNSUPPORTED, "gemm(fp8): K=%d must be a multiple of 128 and both scale vectors given", a.K);
+        b.K = a.K / 2;       // the kernel counts 16-bit columns: 128-byte LDS rows = 128 e4m3
+    }
+    SAT_CHECK_ARG(b.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", b.N, BN);
+    SAT_CHECK_ARG(b.K % BK == 0 && b.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
+    int tiles = cdiv(b.M, BM) * (b.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, b);
     SAT_LAUNCH_CHECK();
     return 0;
 }
@@ -844,7 +974,38 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         sat_set_error("gemm: unknown ablation variant %d", a.variant);
         return SAT_E_INVALID;
     }
-    int v = a.variant;
+    int v = a.variant & 0xff;
+    if (a.fp8) {
+        // e4m3 operands: the LDS-DMA tiles only (22 / 30 / 15 / 16); the same fill x rate choice, K counted in bytes
+        auto score = [&](int bm, int bn, double rate) {
+            if (a.N % bn) return 0.0;
+            long t = (long)cdiv(a.M, bm) * (a.N / bn);
+            return rate * (double)t / (double)(((t + 255) / 256) * 256);
+        };
+        if (v == 0) {
+            const double s256 = score(256, 256, 1.0), s192 = score(256, 192, 0.95), s128 = score(128, 128, 0.7), s64 = score(128, 64, 0.6);
+            const double best = s256 > s192 ? (s256 > s128 ? s256 : s128) : (s192 > s128 ? s192 : s128);
+            v = (s64 > best) ? 16 : (best == s256) ? 22 : (best == s192) ? 30 : 15;
+            if (a.K < 384 && (v == 15 || v == 16)) v = 22;     // the 3-stage tiles need K >= 384 bytes
+        }
+        if (a.fp8 == 2) {      // block-scaled MFMA with unit scales: 2x the MFMA rate
+            switch (v) {
+                case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 2>(a, stream);
+                case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 0, 2>(a, stream);
+                case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 0, 2>(a, stream);
+                case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 2>(a, stream);
+            }
+        } else {
+            switch (v) {
+                case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 1>(a, stream);
+                case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 0, 1>(a, stream);
+                case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 0, 1>(a, stream);
+                case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 1>(a, stream);
+            }
+        }
+        sat_set_error("gemm(fp8): variant %d has no e4m3 build (15, 16, 22, 30)", v);
+        return SAT_E_INVALID;
+    }
     if (v == 0) {
         // Pick the tile whose (fill of the last round of 256 CUs) x (measured in-kernel rate relative to the 256x256
         // tile) is best.  Rates from profiles/r01_gemm_variants.txt: 256x256 (16 waves) 1.0, 256x192 (12 waves) 0.95,
@@ -909,7 +1070,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG(a.A && a.W, SAT_E_INVALID, "gemm: null operand");
     SAT_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, SAT_E_INVALID, "gemm: bad shape %d %d %d", a.M, a.N, a.K);
-    SAT_CHECK_ARG(a.K % 64 == 0, SAT_E_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", a.K);
+    SAT_CHECK_ARG(a.K % (a.fp8 ? 128 : 64) == 0, SAT_E_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", a.K, a.fp8 ? 128 : 64);
     SAT_CHECK_ARG(a.N % 128 == 0, SAT_E_UNSUPPORTED, "gemm: N=%d must be a multiple of 128", a.N);
     switch (epi) {
         case EPI_F32:

@@ -7,11 +7,12 @@
 namespace {
 
 // D = 64 * 4 * NV  (NV float4 per lane)
-template <int NV>
+// FP8: the row is quantised to e4m3 with its own scale (amax / 448) -- the A operand of the fp8 GEMMs; y then points to bytes
+template <int NV, bool FP8 = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                         int m, int d, const float* __restrict__ sc, const float* __restrict__ sh,
-                                                        int rps, int ld) {
+                                                        int rps, int ld, float* __restrict__ row_scale = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
     const float4* gr = reinterpret_cast<const float4*>(gamma);
     const float4* br = reinterpret_cast<const float4*>(beta);
-    bf16x4* yr = reinterpret_cast<bf16x4*>(y + (size_t)row * d);
+    [[maybe_unused]] bf16x4* yr = reinterpret_cast<bf16x4*>(y + (size_t)row * d);
     // adaLN modulation (wave-uniform branch): per-sequence (1 + scale) and shift vectors
     const float4* scr = sc ? reinterpret_cast<const float4*>(sc + (size_t)(row / rps) * ld) : nullptr;
     const float4* shr = sc ? reinterpret_cast<const float4*>(sh + (size_t)(row / rps) * ld) : nullptr;
@@ -53,12 +54,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             r.z = r.z * a.z + c.z;
             r.w = r.w * a.w + c.w;
         }
-        bf16x4 o;
-        o[0] = f32_to_bf16(r.x);
-        o[1] = f32_to_bf16(r.y);
-        o[2] = f32_to_bf16(r.z);
-        o[3] = f32_to_bf16(r.w);
-        yr[i * 64 + lane] = o;
+        if constexpr (FP8) {
+            v[i] = r;             // keep the normalised row in registers for the amax pass
+        } else {
+            bf16x4 o;
+            o[0] = f32_to_bf16(r.x);
+            o[1] = f32_to_bf16(r.y);
+            o[2] = f32_to_bf16(r.z);
+            o[3] = f32_to_bf16(r.w);
+            yr[i * 64 + lane] = o;
+        }
+    }
+    if constexpr (FP8) {
+        float am = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) am = fmaxf(am, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+        am = wave_max(am);
+        const float scale = am > 0.f ? am * (1.0f / 448.0f) : 1.0f;
+        const float inv = 1.0f / scale;
+        unsigned* y8 = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(y) + (size_t)row * d);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            unsigned p = 0;
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, p, false);
+            p = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, p, true);
+            y8[i * 64 + lane] = p;
+        }
+        if (lane == 0) row_scale[row] = scale;
     }
 }
 
@@ -128,6 +150,40 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     }
 }
 
+// one workgroup per output row: amax -> scale = amax / 448 -> e4m3 bytes (4 per thread per pass); same row permutation as
+// pack_rows_kernel for the SwiGLU weight
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
+                                                             float* __restrict__ row_scale, int n, int k, int interleave) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    int src = row;
+    if (interleave) {
+        int g = row >> 6, c = row & 63;
+        src = (c < 32) ? (g * 32 + c) : (n / 2 + g * 32 + (c - 32));
+    }
+    const float* wr = w + (size_t)src * k;
+    float am = 0.f;
+    for (int i = threadIdx.x * 4; i < k; i += 256 * 4) {
+        float4 v = *reinterpret_cast<const float4*>(wr + i);
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = am > 0.f ? am * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / scale;
+    unsigned* o = reinterpret_cast<unsigned*>(out + (size_t)row * k);
+    for (int i = threadIdx.x * 4; i < k; i += 256 * 4) {
+        float4 v = *reinterpret_cast<const float4*>(wr + i);
+        unsigned p = 0;
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * inv, v.y * inv, p, false);
+        p = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * inv, v.w * inv, p, true);
+        o[i >> 2] = p;
+    }
+    if (threadIdx.x == 0) row_scale[row] = scale;
+}
+
 __global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int n, int interleave) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
@@ -175,6 +231,27 @@ int sat_launch_layernorm_mod(const float* x, const float* gamma, const float* be
     return 0;
 }
 
+int sat_launch_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* y8, float* row_scale, int m, int d,
+                             const float* sc, const float* sh, int rps, int ld, hipStream_t s) {
+    SAT_CHECK_ARG(x && gamma && y8 && row_scale && m > 0 && d > 0, SAT_E_INVALID, "layernorm_fp8: bad args m=%d d=%d", m, d);
+    SAT_CHECK_ARG((sc == nullptr) == (sh == nullptr) && (!sc || (rps > 0 && ld % 4 == 0)), SAT_E_INVALID, "layernorm_fp8: bad modulation");
+    dim3 grid(cdiv(m, 4)), block(256);
+    bf16_t* y = reinterpret_cast<bf16_t*>(y8);
+    switch (d % 256 == 0 ? d / 256 : 0) {
+        case 1: hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld, row_scale); break;
+        case 2: hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld, row_scale); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<3, true>), grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld, row_scale); break;
+        case 4: hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld, row_scale); break;
+        case 6: hipLaunchKernelGGL((layernorm_kernel<6, true>), grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld, row_scale); break;
+        case 8: hipLaunchKernelGGL((layernorm_kernel<8, true>), grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld, row_scale); break;
+        default:
+            sat_set_error("layernorm_fp8: d=%d must be 256 * {1,2,3,4,6,8}", d);
+            return SAT_E_UNSUPPORTED;
+    }
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s) {
     return sat_launch_layernorm_mod(x, gamma, beta, y, m, d, nullptr, nullptr, 1, 0, s);
 }
@@ -194,6 +271,15 @@ int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swi
     SAT_CHECK_ARG(w && out && n > 0 && k > 0 && k % 4 == 0, SAT_E_INVALID, "pack_rows: bad args");
     SAT_CHECK_ARG(!swiglu_interleave || n % 128 == 0, SAT_E_UNSUPPORTED, "pack_rows: swiglu needs n %% 128 == 0");
     hipLaunchKernelGGL(pack_rows_kernel, dim3(n), dim3(256), 0, s, w, out, n, k, swiglu_interleave);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int sat_launch_quant_rows_fp8(const float* w, void* out8, float* row_scale, int n, int k, int swiglu_interleave, hipStream_t s) {
+    SAT_CHECK_ARG(w && out8 && row_scale && n > 0 && k > 0 && k % 4 == 0, SAT_E_INVALID, "quant_rows_fp8: bad args");
+    SAT_CHECK_ARG(!swiglu_interleave || n % 128 == 0, SAT_E_UNSUPPORTED, "quant_rows_fp8: swiglu needs n %% 128 == 0");
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3(n), dim3(256), 0, s, w, reinterpret_cast<unsigned char*>(out8), row_scale, n, k,
+                       swiglu_interleave);
     SAT_LAUNCH_CHECK();
     return 0;
 }

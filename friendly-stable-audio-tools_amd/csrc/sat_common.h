@@ -127,6 +127,11 @@ struct GemmArgs {
     float* C;            // [M,ldc]
     int ldc;
     int accumulate;
+    // fp8 (e4m3) operands: A and W hold one byte per element (row-major, K contiguous), the fp32 accumulator is multiplied by
+    // a_scale[row] * w_scale[col] (per-token x per-output-channel scales) before the epilogue; K % 128 == 0
+    int fp8;
+    const float* a_scale;   // [M]
+    const float* w_scale;   // [N]
     const float* gate;   // adaLN: (acc + bias) * gate[(row / gate_rows) * gate_ld + col] before the residual add; or nullptr
     int gate_rows, gate_ld;
     // EPI_SWIGLU
@@ -140,6 +145,11 @@ int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, 
 // adaLN: y = LN(x) * scale1p[b] + shift[b] with b = row / rows_per_seq and per-sequence vectors ld apart (transformer.py:671-672)
 int sat_launch_layernorm_mod(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, const float* scale1p,
                              const float* shift, int rows_per_seq, int ld, hipStream_t s);
+// LayerNorm (+ optional adaLN modulation) quantised per row to fp8 e4m3: y8 = rne(r / s), s = amax(r) / 448 -> row_scale[m]
+int sat_launch_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* y8, float* row_scale, int m, int d,
+                             const float* scale1p, const float* shift, int rows_per_seq, int ld, hipStream_t s);
+// rows of an fp32 matrix -> fp8 e4m3 with one scale per row (weights: per output channel; optional SwiGLU interleave)
+int sat_launch_quant_rows_fp8(const float* w, void* out8, float* row_scale, int n, int k, int swiglu_interleave, hipStream_t s);
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
                          int sq, int sk, int sq_pad, int sk_pad, hipStream_t s);
 int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);

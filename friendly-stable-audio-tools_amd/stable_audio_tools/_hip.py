@@ -21,7 +21,7 @@ class SatError(RuntimeError):
 class SatDitCfg(Structure):
     _fields_ = [("io_channels", c_int32), ("embed_dim", c_int32), ("depth", c_int32), ("num_heads", c_int32),
                 ("cond_token_dim", c_int32), ("cond_embed_dim", c_int32), ("global_cond_dim", c_int32),
-                ("max_seq_len", c_int32), ("adaln", c_int32)]
+                ("max_seq_len", c_int32), ("adaln", c_int32), ("fp8_gemm", c_int32)]
 
 
 class SatOobleckCfg(Structure):
@@ -46,6 +46,10 @@ _SIGNATURES = {
     "sat_dit_profile_read": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64),
                                        POINTER(c_int64)]),
     "sat_cfg_combine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
+    "sat_quant_rows_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "sat_layernorm_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "sat_gemm_fp8_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                   c_int32, c_void_p]),
     "sat_lincomb": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float,
                               c_int64, c_void_p]),
     "sat_inpaint_mix": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64, c_int32, c_void_p]),

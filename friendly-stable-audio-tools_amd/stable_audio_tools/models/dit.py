@@ -68,6 +68,17 @@ class DiffusionTransformer(nn.Module):
         self._plan_version = None
         self._ws = None
         self._ctx_key = None
+        self.gemm_dtype = "bf16"
+
+    def set_gemm_dtype(self, dtype: str):
+        """Build extension (BASELINE config 5): "bf16" (default) or "fp8" -- OCP e4m3 operands with per-token / per-output-
+        channel scales for the GEMMs fed by a LayerNorm (to_qkv, cross to_q, FF-in).  Rebuilds the plan on next use."""
+        if dtype not in ("bf16", "fp8"):
+            raise ValueError("gemm_dtype must be 'bf16' or 'fp8'")
+        if dtype != self.gemm_dtype:
+            self.gemm_dtype = dtype
+            self._plan_version = None
+        return self
 
     # ------------------------------------------------------------------ plan management
     def __del__(self):
@@ -90,7 +101,7 @@ class DiffusionTransformer(nn.Module):
             self._plan = None
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
                              self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
-                             1 if self.global_cond_type == "adaLN" else 0)
+                             1 if self.global_cond_type == "adaLN" else 0, 1 if self.gemm_dtype == "fp8" else 0)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
         keep = []

@@ -67,6 +67,10 @@ typedef struct sat_dit_cfg {
                                   1: "adaLN" (models/dit.py:205-206, models/transformer.py:665-689): no prepend token, the
                                   global embedding drives per-layer scale/shift/gate of the self-attention and FF branches;
                                   needs "transformer.layers.N.to_scale_shift_gate.1.weight" [6*embed_dim, embed_dim] */
+    int32_t fp8_gemm;          /* 0: bf16 GEMM operands everywhere (default, the headline path);
+                                  1: BASELINE config 5 -- the GEMMs fed by a LayerNorm (self-attention to_qkv, cross-attention
+                                  to_q, FF-in; transformer.py:314, 311, 222) take OCP e4m3 operands with one scale per token
+                                  (activations) and per output channel (weights), fp32 accumulation; everything else as 0 */
 } sat_dit_cfg;
 
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
@@ -143,6 +147,17 @@ int sat_dpmpp3m_update(float* x_dev, const float* d_dev, const float* d1_dev, co
  * combination of the state, denoiser outputs and noise with host-computed scalars. */
 int sat_lincomb(float* out_dev, const float* t0, float c0, const float* t1, float c1, const float* t2, float c2,
                 const float* t3, float c3, const float* t4, float c4, int64_t n, sat_stream_t stream);
+
+/* fp8 building blocks of fp8_gemm = 1, exported for the kernel-level parity tests:
+ *   sat_quant_rows_fp8: x [rows, k] fp32 -> out8 [rows, k] OCP e4m3 bytes, row_scale[rows] = amax(row) / 448 (1 if the row is 0)
+ *   sat_layernorm_fp8 : LayerNorm (eps 1e-5, transformer.py:205-206) fused with that row quantisation
+ *   sat_gemm_fp8_f32  : c [m, n] (+)= (a8 . w8^T) * a_scale[m] * w_scale[n] (+ bias), k % 128 == 0, n % 128 == 0 */
+int sat_quant_rows_fp8(const float* x_dev, void* out8_dev, float* row_scale_dev, int32_t rows, int32_t k, sat_stream_t stream);
+int sat_layernorm_fp8(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y8_dev, float* row_scale_dev,
+                      int32_t m, int32_t d, sat_stream_t stream);
+int sat_gemm_fp8_f32(const void* a8_dev, const float* a_scale_dev, const void* w8_dev, const float* w_scale_dev,
+                     const float* bias_dev, float* c_dev, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant,
+                     sat_stream_t stream);
 
 /* Inpainting re-injection (inference/sampling.py:98-103 get_bmask, :178-190 inpainting_callback, :168-172 initial mix):
  *   x[r, i] <- init[r, i] + noise[r, i] * sigma     wherever mask[i] <= strength      (in place on x_dev)

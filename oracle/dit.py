@@ -28,6 +28,33 @@ def _r(rnd, x):
     return x if rnd is None else rnd(x)
 
 
+def fp8_rows(x):
+    """Per-row (last dim) OCP e4m3 quantisation as the fp8_gemm kernels do it: scale = amax / 448, value * (1 / scale) rounded
+    to nearest even -- returned de-quantised.  (Activations: one scale per token; weights: one per output channel.)"""
+    amax = x.abs().amax(dim=-1, keepdim=True)
+    scale = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    return (x * (1.0 / scale)).to(torch.float8_e4m3fn).to(torch.float32) * scale
+
+
+class Fp8Rounding:
+    """Matched-rounding hook of BASELINE config 5 (sat_dit_cfg.fp8_gemm): bf16 everywhere, except that the LayerNorm outputs
+    and the weights of the three GEMMs they feed (to_qkv, cross to_q, FF-in) are e4m3 with per-row scales."""
+
+    def __call__(self, x):
+        return bf16_round(x)
+
+    act = staticmethod(fp8_rows)
+    weight = staticmethod(fp8_rows)
+
+
+def _ra(rnd, x):      # a LayerNorm output that feeds a GEMM
+    return rnd.act(x) if hasattr(rnd, "act") else _r(rnd, x)
+
+
+def _rw(rnd, w):      # the weight of a GEMM fed by a LayerNorm output
+    return rnd.weight(w) if hasattr(rnd, "weight") else _r(rnd, w)
+
+
 # models/transformer.py:188-206 (LayerNorm: F.layer_norm with gamma, beta buffer, eps 1e-5)
 def layer_norm(x, gamma, beta):
     return F.layer_norm(x, x.shape[-1:], weight=gamma, bias=beta)
@@ -85,7 +112,7 @@ def _merge(t):
 
 # models/transformer.py:407-554 (Attention.forward), self-attention branch (to_qkv)
 def self_attention(sd, pfx, x, freqs, num_heads, rnd=None):
-    w_qkv = _r(rnd, sd[pfx + "to_qkv.weight"])
+    w_qkv = _rw(rnd, sd[pfx + "to_qkv.weight"])
     q, k, v = F.linear(x, w_qkv).chunk(3, dim=-1)
     q, k, v = (_heads(t, num_heads) for t in (q, k, v))
     q = apply_rotary(q.float(), freqs)      # transformer.py:438-452
@@ -98,7 +125,7 @@ def self_attention(sd, pfx, x, freqs, num_heads, rnd=None):
 
 # models/transformer.py:407-554, cross-attention branch (to_q / to_kv; no RoPE: :438)
 def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
-    q = _heads(F.linear(x, _r(rnd, sd[pfx + "to_q.weight"])), num_heads)
+    q = _heads(F.linear(x, _rw(rnd, sd[pfx + "to_q.weight"])), num_heads)
     kv = F.linear(context, _r(rnd, sd[pfx + "to_kv.weight"]))
     k, v = kv.chunk(2, dim=-1)
     kv_heads = k.shape[-1] // dim_heads
@@ -111,7 +138,7 @@ def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
 
 # models/transformer.py:211-287 (GLU + FeedForward; value = first half, gate = second half)
 def feed_forward(sd, pfx, x, rnd=None):
-    h = F.linear(x, _r(rnd, sd[pfx + "ff.0.proj.weight"]), sd[pfx + "ff.0.proj.bias"])
+    h = F.linear(x, _rw(rnd, sd[pfx + "ff.0.proj.weight"]), sd[pfx + "ff.0.proj.bias"])
     val, gate = h.chunk(2, dim=-1)
     h = _r(rnd, val * F.silu(gate))
     return F.linear(h, _r(rnd, sd[pfx + "ff.2.weight"]), sd[pfx + "ff.2.bias"])
@@ -123,21 +150,21 @@ def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None
         ssg = F.linear(F.silu(global_cond), sd[pfx + "to_scale_shift_gate.1.weight"]).unsqueeze(1)      # :667
         scale_self, shift_self, gate_self, scale_ff, shift_ff, gate_ff = ssg.chunk(6, dim=-1)
         h = layer_norm(x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"])
-        h = _r(rnd, h * (1 + scale_self) + shift_self)                                                    # :671-672
+        h = _ra(rnd, h * (1 + scale_self) + shift_self)                                                   # :671-672
         x = x + self_attention(sd, pfx + "self_attn.", h, freqs, num_heads, rnd) * torch.sigmoid(1 - gate_self)   # :673-675
         if context is not None:                                                                          # :677-678 (un-modulated)
-            h = _r(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]))
+            h = _ra(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]))
             x = x + cross_attention(sd, pfx + "cross_attn.", h, context, num_heads, dim_heads, rnd)
         h = layer_norm(x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"])
-        h = _r(rnd, h * (1 + scale_ff) + shift_ff)                                                        # :685-686
+        h = _ra(rnd, h * (1 + scale_ff) + shift_ff)                                                        # :685-686
         x = x + feed_forward(sd, pfx + "ff.", h, rnd) * torch.sigmoid(1 - gate_ff)                        # :687-689
         return x
-    h = _r(rnd, layer_norm(x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"]))
+    h = _ra(rnd, layer_norm(x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"]))
     x = x + self_attention(sd, pfx + "self_attn.", h, freqs, num_heads, rnd)
     if context is not None:
-        h = _r(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]))
+        h = _ra(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]))
         x = x + cross_attention(sd, pfx + "cross_attn.", h, context, num_heads, dim_heads, rnd)
-    h = _r(rnd, layer_norm(x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"]))
+    h = _ra(rnd, layer_norm(x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"]))
     x = x + feed_forward(sd, pfx + "ff.", h, rnd)
     return x
 

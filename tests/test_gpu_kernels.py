@@ -227,3 +227,74 @@ def test_cfg_combine_and_sampler_update(dev):
         d, d1, d2 = d2, d, d1
         have = min(have + 1, 2)
     assert_close("dpmpp3m trajectory", x, want, 2e-5)
+
+
+def _deq8(q_bytes, scale):
+    return q_bytes.view(torch.float8_e4m3fn).to(torch.float32) * scale[:, None]
+
+
+def test_fp8_quant_and_layernorm(dev):
+    """sat_quant_rows_fp8 / sat_layernorm_fp8 (BASELINE config 5 building blocks) against torch's e4m3 conversion: the bytes must
+    be identical except where x / scale sits on a rounding boundary (kernel multiplies by 1/scale), and never off by more than
+    one code."""
+    from oracle import dit as odit
+    _hip, lib = _lib()
+    for rows, k in ((37, 256), (300, 1536)):
+        x = _rand((rows, k), 200, 3.0)
+        x[1] = 0
+        xd = x.to(dev)
+        q = torch.empty((rows, k), dtype=torch.uint8, device=dev)
+        sc = torch.empty((rows,), dtype=torch.float32, device=dev)
+        _hip.check(lib.sat_quant_rows_fp8(_hip.ptr(xd), _hip.ptr(q), _hip.ptr(sc), rows, k, _hip.stream()))
+        amax = x.abs().amax(dim=1)
+        want_sc = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+        assert torch.allclose(sc.cpu(), want_sc, rtol=1e-6)
+        got = _deq8(q.cpu(), sc.cpu())
+        assert_close("fp8 rows", got, odit.fp8_rows(x), 2e-3)
+        assert (got - x).norm() / x.norm() < 4e-2                      # e4m3: 3 mantissa bits
+        assert (q.cpu()[1] == 0).all() and sc.cpu()[1] == 1.0
+    m, d = 130, 1536
+    x = _rand((m, d), 201, 2.0)
+    gm, bt = 1 + 0.1 * _rand((d,), 202), 0.1 * _rand((d,), 203)
+    xd, gd, bd = x.to(dev), gm.to(dev), bt.to(dev)
+    q = torch.empty((m, d), dtype=torch.uint8, device=dev)
+    sc = torch.empty((m,), dtype=torch.float32, device=dev)
+    _hip.check(lib.sat_layernorm_fp8(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(q), _hip.ptr(sc), m, d, _hip.stream()))
+    want = odit.fp8_rows(F.layer_norm(x, (d,), gm, bt))
+    assert_close("layernorm fp8", _deq8(q.cpu(), sc.cpu()), want, 3e-3)
+
+
+@pytest.mark.parametrize("plain", [0, 256])
+@pytest.mark.parametrize("variant", [0, 15, 16, 22, 30])
+@pytest.mark.parametrize("m,n,k", [(2050, 1536, 1536), (257, 768, 6144), (130, 256, 384), (1, 768, 256)])
+def test_gemm_fp8(dev, variant, m, n, k, plain):
+    """e4m3 x e4m3 -> fp32 GEMM with per-row scales on both operands against an fp32 matmul of the de-quantised operands
+    (exact products, fp32 accumulation): only the accumulation order differs.  plain=0: v_mfma_scale_f32_32x32x64_f8f6f4 with
+    unit block scales (2x MFMA rate, the default); plain=256: v_mfma_f32_32x32x16_fp8_fp8."""
+    if variant in (22,) and n % 256:
+        pytest.skip("256-column tile")
+    if variant == 30 and n % 192:
+        pytest.skip("192-column tile")
+    if variant in (15, 16) and k < 384:
+        pytest.skip("3-stage tiles need K >= 384")
+    if variant in (22, 30) and k < 256:
+        pytest.skip("2-stage tiles need K >= 256")
+    _hip, lib = _lib()
+    a = _rand((m, k), 210, 2.0)
+    w = _rand((n, k), 211) * 0.05 + torch.linspace(-0.02, 0.03, n)[:, None]
+    bias = _rand((n,), 212)
+    c0 = _rand((m, n), 213)
+    ad, wd = a.to(dev), w.to(dev)
+    a8 = torch.empty((m, k), dtype=torch.uint8, device=dev)
+    w8 = torch.empty((n, k), dtype=torch.uint8, device=dev)
+    sa = torch.empty((m,), dtype=torch.float32, device=dev)
+    sw = torch.empty((n,), dtype=torch.float32, device=dev)
+    _hip.check(lib.sat_quant_rows_fp8(_hip.ptr(ad), _hip.ptr(a8), _hip.ptr(sa), m, k, _hip.stream()))
+    _hip.check(lib.sat_quant_rows_fp8(_hip.ptr(wd), _hip.ptr(w8), _hip.ptr(sw), n, k, _hip.stream()))
+    want = _deq8(a8.cpu(), sa.cpu()) @ _deq8(w8.cpu(), sw.cpu()).T + bias + c0
+    cd, bd = c0.to(dev), bias.to(dev)
+    _hip.check(lib.sat_gemm_fp8_f32(_hip.ptr(a8), _hip.ptr(sa), _hip.ptr(w8), _hip.ptr(sw), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1,
+                                    variant | plain, _hip.stream()))
+    assert_close(f"gemm fp8 v{variant} {m}x{n}x{k}", cd, want, 1e-4)
+    full = a @ w.T + bias + c0
+    assert rel_l2(cd, full) < 5e-2, "e4m3 operands: a few percent from the fp32 product"

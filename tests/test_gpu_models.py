@@ -134,6 +134,38 @@ def test_dit_adaln_vs_reference_golden(dev):
     assert_close("adaLN denoise_cfg", dit.denoise((x * sigma).to(dev), sigma, cfg_scale=7.0), osamp.vdenoise(fn, x * sigma, torch.full((2,), sigma)), 1e-2)
 
 
+def test_dit_fp8_gemm_mode(dev, small_dit):
+    """BASELINE config 5: e4m3 operands (per-token / per-output-channel scales) for to_qkv, cross to_q and FF-in.  Against
+    the matched-rounding oracle that quantises at the same points (gate 5e-3: accumulation order + the rare code flipped by
+    x * (1/s) vs the kernel's own rounding), and against the fp32 oracle at the stated looser tolerance (1e-1 without
+    CFG: e4m3 carries 3 mantissa bits; the bf16 path sits at ~5e-3 on the same case)."""
+    from oracle import dit as odit
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dsd = _sub(sd, "model.model.")
+    dit = model.model.model
+    x, c, g = _inputs(2, 77, dc["cond_token_dim"])
+    t = torch.tensor([0.31, 0.87])
+    bf = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0)
+    dit.set_gemm_dtype("fp8")
+    try:
+        got = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0)
+        want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=odit.Fp8Rounding())
+        want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"])
+        e_m = assert_close("fp8 dit vs matched fp8 oracle", got, want_m, 5e-3)
+        e_f = assert_close("fp8 dit vs fp32 oracle", got, want_f, 1e-1)
+        e_b = rel_l2(got, bf)
+        print(f"\n[dit fp8] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}, vs the bf16 path {e_b:.2e}")
+        assert e_b > 1e-4, "fp8 mode must actually change the arithmetic"
+        got7 = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=7.0)
+        want7 = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=odit.Fp8Rounding())
+        assert_close("fp8 dit cfg7 vs matched fp8 oracle", got7, want7, 2e-2)
+    finally:
+        dit.set_gemm_dtype("bf16")
+    again = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0)
+    assert torch.equal(again, bf), "switching back to bf16 must restore the default path bit for bit"
+
+
 @pytest.fixture(scope="module")
 def small_vae(dev):
     from stable_audio_tools import model_configs as MC
