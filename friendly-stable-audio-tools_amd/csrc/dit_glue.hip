@@ -405,6 +405,36 @@ extern "C" int sat_lincomb(float* out_dev, const float* t0, float c0, const floa
     return 0;
 }
 
+// DPM-Solver adaptive (k-diffusion dpm_solver_adaptive, selected at sampling.py:222-224): per-block partial sums of
+// ((x_low - x_high) / max(atol, rtol * max(|x_low|, |x_prev|)))^2; the host adds the (fixed number of) partials in float64, so the
+// accept / reject decision is reproducible
+__global__ __launch_bounds__(256) void dpm_error_kernel(const float* __restrict__ x_low, const float* __restrict__ x_high,
+                                                        const float* __restrict__ x_prev, float atol, float rtol, int64_t n,
+                                                        float* __restrict__ partial) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float lo = x_low[i];
+        const float delta = fmaxf(atol, rtol * fmaxf(fabsf(lo), fabsf(x_prev[i])));
+        const float e = (lo - x_high[i]) / delta;
+        acc += e * e;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int sat_dpm_error_partials(const float* x_low, const float* x_high, const float* x_prev, float atol, float rtol,
+                                      int64_t n, float* partial_dev, int32_t n_partials, sat_stream_t stream) {
+    SAT_CHECK_ARG(x_low && x_high && x_prev && partial_dev && n > 0 && n_partials > 0 && n_partials <= 4096, SAT_E_INVALID,
+                  "dpm_error_partials: bad argument");
+    hipLaunchKernelGGL(dpm_error_kernel, dim3(n_partials), dim3(256), 0, (hipStream_t)stream, x_low, x_high, x_prev, atol, rtol, n,
+                       partial_dev);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 // inference/sampling.py:178-190 (inpainting_callback): keep-region of the current step's binary mask is re-noised init data
 __global__ __launch_bounds__(256) void inpaint_mix_kernel(float* __restrict__ x, const float* __restrict__ init,
                                                           const float* __restrict__ noise, const float* __restrict__ mask,

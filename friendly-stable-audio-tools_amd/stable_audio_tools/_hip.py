@@ -52,6 +52,7 @@ _SIGNATURES = {
                                    c_int32, c_void_p]),
     "sat_lincomb": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float,
                               c_int64, c_void_p]),
+    "sat_dpm_error_partials": (c_int32, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64, c_void_p, c_int32, c_void_p]),
     "sat_inpaint_mix": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64, c_int32, c_void_p]),
     "sat_dpmpp3m_update": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                      c_float, c_int64, c_void_p]),

@@ -1,6 +1,6 @@
 """``sample_k`` (reference ``inference/sampling.py:144-228``): the multistep SDE samplers ``dpmpp-3m-sde`` /
 ``dpmpp-2m-sde`` (fused per-step update), the single-step k-diffusion samplers ``k-heun``, ``k-lms``,
-``k-dpmpp-2s-ancestral``, ``k-dpm-2``, ``k-dpm-fast`` (generic linear-combination update), plain sampling, variations
+``k-dpmpp-2s-ancestral``, ``k-dpm-2``, ``k-dpm-fast``, ``k-dpm-adaptive`` (generic linear-combination update), plain sampling, variations
 (``init_data``) and inpainting (``init_data`` + soft ``mask``); ``sample_rf`` / ``sample_discrete_euler`` for
 rectified-flow models (:28-60, :236-270).
 
@@ -22,7 +22,8 @@ import torch
 from .. import _hip
 from ..models.diffusion import DiTWrapper
 
-SUPPORTED_SAMPLERS = ("dpmpp-3m-sde", "dpmpp-2m-sde", "k-heun", "k-lms", "k-dpmpp-2s-ancestral", "k-dpm-2", "k-dpm-fast")
+SUPPORTED_SAMPLERS = ("dpmpp-3m-sde", "dpmpp-2m-sde", "k-heun", "k-lms", "k-dpmpp-2s-ancestral", "k-dpm-2", "k-dpm-fast",
+                      "k-dpm-adaptive")
 
 
 def get_sigmas_polyexponential(n, sigma_min, sigma_max, rho=1.0):
@@ -135,6 +136,89 @@ def lms_coefficient(order, t, i, j):
             poly = poly * np.polynomial.Polynomial([-t[i - k], 1.0]) / (t[i - j] - t[i - k])
     integ = poly.integ()
     return float(integ(t[i + 1]) - integ(t[i]))
+
+
+class PIDStepSizeController:
+    """k_diffusion.sampling.PIDStepSizeController (host scalars only)."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        self.h = h
+        self.b1 = (pcoeff + icoeff + dcoeff) / order
+        self.b2 = -(pcoeff + 2 * dcoeff) / order
+        self.b3 = dcoeff / order
+        self.accept_safety = accept_safety
+        self.eps = eps
+        self.errs = []
+
+    def propose_step(self, error):
+        inv_error = 1 / (float(error) + self.eps)
+        if not self.errs:
+            self.errs = [inv_error, inv_error, inv_error]
+        self.errs[0] = inv_error
+        factor = self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3
+        factor = 1 + math.atan(factor - 1)
+        accept = factor >= self.accept_safety
+        if accept:
+            self.errs[2] = self.errs[1]
+            self.errs[1] = self.errs[0]
+        self.h *= factor
+        return accept
+
+
+def _dpm_adaptive(denoise, after_denoise, x, sigma_min, sigma_max, rtol=0.01, atol=0.01, h_init=0.05, pcoeff=0.0, icoeff=1.0,
+                  dcoeff=0.0, accept_safety=0.81, info=None):
+    """k_diffusion.sampling.sample_dpm_adaptive -> DPMSolver.dpm_solver_adaptive(order=3, eta=0) with the reference's rtol = atol =
+    0.01 (sampling.py:223-224): embedded 2nd/3rd-order pair in t = -log(sigma), PID step-size control on the host.  Three denoiser
+    evaluations per attempted step; ONE host synchronisation per step (the error norm decides accept / reject)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError("sigma_min and sigma_max must not be 0")
+    lib = _hip.lib()
+    t_end = -math.log(sigma_min)
+    s = -math.log(sigma_max)
+    sig = lambda t: math.exp(-t)
+    pid = PIDStepSizeController(abs(h_init), pcoeff, icoeff, dcoeff, 3, accept_safety)
+    den, den1, den2 = (torch.empty_like(x) for _ in range(3))
+    u1, u2, eps1, x_low, x_high = (torch.empty_like(x) for _ in range(5))
+    x_prev = x.clone()
+    n_part = 1024
+    partial = torch.empty(n_part, dtype=torch.float32, device=x.device)
+    stats = {"steps": 0, "nfe": 0, "n_accept": 0, "n_reject": 0}
+    r1, r2 = 1 / 3, 2 / 3
+    while s < t_end - 1e-5:
+        t = min(t_end, s + pid.h)
+        h = t - s
+        ss = sig(s)
+        denoise(x, ss, den)                                              # eps = (x - den) / sigma(s)
+        after_denoise(stats["steps"], x, ss, den)
+        s1, s2 = s + r1 * h, s + r2 * h
+        c = -sig(s1) * math.expm1(r1 * h) / ss
+        _lin(u1, [(1 + c, x), (-c, den)])
+        denoise(u1, sig(s1), den1)                                       # eps_r1 = (u1 - den1) / sigma(s1)
+        _lin(eps1, [(1 / sig(s1), u1), (-1 / sig(s1), den1)])
+        a = -sig(t) * math.expm1(h)
+        b_low = -sig(t) / (2 * r1) * math.expm1(h)                       # dpm_solver_2_step(r1 = 1/3)
+        _lin(x_low, [(1 + (a - b_low) / ss, x), (-(a - b_low) / ss, den), (b_low, eps1)])
+        a2 = -sig(s2) * math.expm1(r2 * h)
+        b2 = -sig(s2) * (r2 / r1) * (math.expm1(r2 * h) / (r2 * h) - 1)
+        _lin(u2, [(1 + (a2 - b2) / ss, x), (-(a2 - b2) / ss, den), (b2, eps1)])
+        denoise(u2, sig(s2), den2)                                       # eps_r2 = (u2 - den2) / sigma(s2)
+        b3 = -sig(t) / r2 * (math.expm1(h) / h - 1)
+        _lin(x_high, [(1 + (a - b3) / ss, x), (-(a - b3) / ss, den), (b3 / sig(s2), u2), (-b3 / sig(s2), den2)])
+        _hip.check(lib.sat_dpm_error_partials(_hip.ptr(x_low), _hip.ptr(x_high), _hip.ptr(x_prev), atol, rtol, x.numel(),
+                                              _hip.ptr(partial), n_part, _hip.stream()))
+        error = math.sqrt(float(partial.double().sum().item()) / x.numel())     # the one host sync of the step
+        if pid.propose_step(error):
+            x_prev, x_low = x_low, x_prev
+            x, x_high = x_high, x
+            s = t
+            stats["n_accept"] += 1
+        else:
+            stats["n_reject"] += 1
+        stats["nfe"] += 3
+        stats["steps"] += 1
+    if info is not None:
+        info.update(stats)
+    return x
 
 
 def _single_step_sampler(sampler_type, denoise, after_denoise, x, sigmas, sigma_min, sigma_max, steps, noise_sampler, eta, s_noise,
@@ -256,8 +340,7 @@ def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type
              input_concat_cond=None, prepend_cond=None, prepend_cond_mask=None, negative_global_cond=None,
              negative_input_concat_cond=None, **extra_args):
     if sampler_type not in SUPPORTED_SAMPLERS:
-        raise NotImplementedError(f"sampler_type '{sampler_type}' is not implemented by the HIP path; supported: {SUPPORTED_SAMPLERS}"
-                                  " (k-dpm-adaptive needs a host-synchronised error controller and is not offered)")
+        raise NotImplementedError(f"sampler_type '{sampler_type}' is not implemented by the HIP path; supported: {SUPPORTED_SAMPLERS}")
     if cond_fn is not None:
         raise NotImplementedError("cond_fn (gradient guidance through the denoiser) is outside the supported hot path")
     if mask is not None and init_data is None:
@@ -299,8 +382,11 @@ def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type
         if callback is not None:
             callback({"x": x, "i": i, "sigma": sigma, "sigma_hat": sigma, "denoised": denoised})
 
+    denoise = lambda xin, sigma, out: dit.denoise(xin, sigma, cfg_scale=cfg_scale, scale_phi=scale_phi, out=out)
+    if sampler_type == "k-dpm-adaptive":
+        return _dpm_adaptive(denoise, after_denoise, x.clone() if x is noise else x, sigma_min, sigma_max, rtol=extra_args.pop("rtol", 0.01),
+                             atol=extra_args.pop("atol", 0.01), info=extra_args.pop("info", None))
     if sampler_type not in ("dpmpp-3m-sde", "dpmpp-2m-sde"):
-        denoise = lambda xin, sigma, out: dit.denoise(xin, sigma, cfg_scale=cfg_scale, scale_phi=scale_phi, out=out)
         return _single_step_sampler(sampler_type, denoise, after_denoise, x, sigmas, sigma_min, sigma_max, steps, noise_sampler,
                                     eta, s_noise, order=extra_args.pop("order", 4))
 

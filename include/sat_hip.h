@@ -159,6 +159,12 @@ int sat_gemm_fp8_f32(const void* a8_dev, const float* a_scale_dev, const void* w
                      const float* bias_dev, float* c_dev, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant,
                      sat_stream_t stream);
 
+/* Error estimate of one DPM-Solver adaptive step (k-diffusion sample_dpm_adaptive, inference/sampling.py:222-224):
+ * partial_dev[j], j < n_partials, receive block-wise partial sums of ((x_low - x_high) / delta)^2 with
+ * delta = max(atol, rtol * max(|x_low|, |x_prev|)); error = sqrt(sum(partials) / n), summed by the caller (fixed order). */
+int sat_dpm_error_partials(const float* x_low_dev, const float* x_high_dev, const float* x_prev_dev, float atol, float rtol,
+                           int64_t n, float* partial_dev, int32_t n_partials, sat_stream_t stream);
+
 /* Inpainting re-injection (inference/sampling.py:98-103 get_bmask, :178-190 inpainting_callback, :168-172 initial mix):
  *   x[r, i] <- init[r, i] + noise[r, i] * sigma     wherever mask[i] <= strength      (in place on x_dev)
  * x/init/noise are [rows, t] (rows = batch * channels), mask is the [t] soft mask of generation.py:269-290 and

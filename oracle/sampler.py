@@ -264,6 +264,62 @@ def sample_dpm_fast(denoiser, x, sigma_min, sigma_max, n, callback=None):  # K.s
     return x
 
 
+class PIDStepSizeController:                                               # K.sampling.PIDStepSizeController
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order=1, accept_safety=0.81, eps=1e-8):
+        self.h, self.accept_safety, self.eps, self.errs = h, accept_safety, eps, []
+        self.b1 = (pcoeff + icoeff + dcoeff) / order
+        self.b2 = -(pcoeff + 2 * dcoeff) / order
+        self.b3 = dcoeff / order
+
+    def propose_step(self, error):
+        inv_error = 1 / (float(error) + self.eps)
+        if not self.errs:
+            self.errs = [inv_error, inv_error, inv_error]
+        self.errs[0] = inv_error
+        factor = 1 + math.atan(self.errs[0] ** self.b1 * self.errs[1] ** self.b2 * self.errs[2] ** self.b3 - 1)
+        accept = factor >= self.accept_safety
+        if accept:
+            self.errs[2], self.errs[1] = self.errs[1], self.errs[0]
+        self.h *= factor
+        return accept
+
+
+# K.sampling.sample_dpm_adaptive(model, x, sigma_min, sigma_max, rtol=0.01, atol=0.01) as called at sampling.py:222-224
+# -> DPMSolver.dpm_solver_adaptive(order=3, eta=0): embedded DPM-Solver-2 (r1 = 1/3) / DPM-Solver-3 pair, PID step control
+def sample_dpm_adaptive(denoiser, x, sigma_min, sigma_max, rtol=0.01, atol=0.01, h_init=0.05, accept_safety=0.81, info=None):
+    s_in = x.new_ones([x.shape[0]])
+    sigma = lambda t: math.exp(-t)
+    eps = lambda xx, t: (xx - denoiser(xx, sigma(t) * s_in)) / sigma(t)
+    s, t_end = -math.log(sigma_max), -math.log(sigma_min)
+    pid = PIDStepSizeController(h_init, 0.0, 1.0, 0.0, 3, accept_safety)
+    x_prev = x
+    stats = {"steps": 0, "nfe": 0, "n_accept": 0, "n_reject": 0}
+    r1, r2 = 1 / 3, 2 / 3
+    while s < t_end - 1e-5:
+        t = min(t_end, s + pid.h)
+        h = t - s
+        e = eps(x, s)
+        s1, s2 = s + r1 * h, s + r2 * h
+        u1 = x - sigma(s1) * math.expm1(r1 * h) * e
+        e1 = eps(u1, s1)
+        x_low = x - sigma(t) * math.expm1(h) * e - sigma(t) / (2 * r1) * math.expm1(h) * (e1 - e)
+        u2 = x - sigma(s2) * math.expm1(r2 * h) * e - sigma(s2) * (r2 / r1) * (math.expm1(r2 * h) / (r2 * h) - 1) * (e1 - e)
+        e2 = eps(u2, s2)
+        x_high = x - sigma(t) * math.expm1(h) * e - sigma(t) / r2 * (math.expm1(h) / h - 1) * (e2 - e)
+        delta = torch.maximum(torch.tensor(atol, dtype=x.dtype), rtol * torch.maximum(x_low.abs(), x_prev.abs()))
+        error = torch.linalg.norm((x_low - x_high) / delta) / x.numel() ** 0.5
+        if pid.propose_step(error):
+            x_prev, x, s = x_low, x_high, t
+            stats["n_accept"] += 1
+        else:
+            stats["n_reject"] += 1
+        stats["nfe"] += 3
+        stats["steps"] += 1
+    if info is not None:
+        info.update(stats)
+    return x
+
+
 # inference/sampling.py:28-60 (sample_discrete_euler): rectified flow
 def sample_discrete_euler(model, x, steps, sigma_max=1.0):
     t = torch.linspace(sigma_max, 0, steps + 1)

@@ -284,7 +284,7 @@ def test_sample_k_inpainting_and_2m(dev, small_dit, sampler_type):
     e = assert_close(f"inpainting trajectory ({sampler_type}) vs matched oracle", got, want, 2e-2)
     print(f"\n[inpaint {sampler_type}] rel-L2 {e:.2e}")
     with pytest.raises(NotImplementedError):
-        sample_k(model.model, noise.to(dev), None, None, steps, sampler_type="k-dpm-adaptive", cross_attn_cond=c.to(dev),
+        sample_k(model.model, noise.to(dev), None, None, steps, sampler_type="k-euler-nonexistent", cross_attn_cond=c.to(dev),
                  global_cond=g.to(dev))
 
 
@@ -325,6 +325,33 @@ def test_sample_k_single_step_samplers(dev, small_dit, sampler_type):
     e = assert_close(f"{sampler_type} trajectory vs matched oracle", got, want, 2e-2)
     assert seen == list(range(len(seen))) and len(seen) >= 2
     print(f"\n[{sampler_type}] rel-L2 {e:.2e}")
+
+
+def test_sample_k_dpm_adaptive(dev, small_dit):
+    """k-dpm-adaptive (sampling.py:222-224): the product's PID-controlled embedded pair (3 fused DiT evaluations + one
+    sat_dpm_error_partials reduction and ONE host sync per step) against the oracle restatement driving the oracle DiT: same
+    accept/reject history and the same latents."""
+    from oracle import dit as odit, sampler as osamp
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.inference.sampling import sample_k
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dsd = _sub(sd, "model.model.")
+    b, t_len = 2, 24
+    c = synthetic.synth_input("c", (b, 130, dc["cond_token_dim"]), 121)
+    g = synthetic.synth_input("g", (b, 2 * dc["cond_token_dim"]), 122)
+    noise = synthetic.synth_input("noise", (b, 64, t_len), 123)
+    info = {}
+    got = sample_k(model.model, noise.to(dev), None, None, 10, sampler_type="k-dpm-adaptive", sigma_min=2.0, sigma_max=20.0,
+                   device=str(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=3.0, info=info)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=3.0, rnd=bf16_round)
+    winfo = {}
+    sig0 = float(osamp.get_sigmas_polyexponential(10, 2.0, 20.0, 1.0)[0])
+    want = osamp.sample_dpm_adaptive(lambda x, s_: osamp.vdenoise(fn, x, s_), noise * sig0, 2.0, 20.0, info=winfo)
+    print(f"\n[k-dpm-adaptive] product {info}  oracle {winfo}")
+    assert info["steps"] >= 3 and info["nfe"] == 3 * info["steps"]
+    assert (info["n_accept"], info["n_reject"]) == (winfo["n_accept"], winfo["n_reject"])
+    assert_close("k-dpm-adaptive latents vs matched oracle", got, want, 2e-2)
 
 
 def test_rectified_flow_euler(dev, small_dit):

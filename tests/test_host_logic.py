@@ -151,7 +151,7 @@ def test_generate_rejects_what_the_reference_api_cannot_do():
     with pytest.raises(NotImplementedError, match="negative"):
         generate_diffusion_cond(model, steps=2, conditioning_tensors=cond, negative_conditioning=[{"prompt": "x"}], device="cpu")
     with pytest.raises(NotImplementedError, match="sampler_type"):
-        sample_k(model.model, torch.zeros(1, 64, 8), sampler_type="k-dpm-adaptive")
+        sample_k(model.model, torch.zeros(1, 64, 8), sampler_type="k-euler-nonexistent")
     with pytest.raises(NotImplementedError):
         sample_k(lambda x, s: x, torch.zeros(1, 64, 8), sampler_type="dpmpp-3m-sde")
 

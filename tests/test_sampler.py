@@ -211,3 +211,21 @@ def test_lms_coefficients_exact_vs_quadrature():
             assert abs(a - b) <= 2e-4 * max(abs(a), abs(b), 1e-9), (i, j, a, b)
     assert get_ancestral_step(2.0, 1.0) == pytest.approx(osamp.get_ancestral_step(2.0, 1.0))
     assert get_ancestral_step(2.0, 0.0)[0] == 0.0
+
+
+def test_dpm_adaptive_controls_the_error():
+    """k-dpm-adaptive restatement: on the Gaussian toy problem it must land on the exact probability-flow solution at
+    sigma_min within a few rtol, take fewer steps at a looser tolerance, and reject steps when started with a huge h."""
+    s_data = 0.7
+    den = _gaussian_denoiser(s_data)
+    x0 = torch.randn(2, 3, 40, dtype=torch.float64, generator=torch.Generator().manual_seed(5)) * 80.0
+    exact = x0 * math.sqrt((s_data ** 2 + 0.05 ** 2) / (s_data ** 2 + 80.0 ** 2))
+    info_t, info_l, info_h = {}, {}, {}
+    tight = osamp.sample_dpm_adaptive(den, x0.clone(), 0.05, 80.0, rtol=0.01, atol=0.01, info=info_t)
+    loose = osamp.sample_dpm_adaptive(den, x0.clone(), 0.05, 80.0, rtol=0.2, atol=0.2, info=info_l)
+    err = lambda v: ((v - exact).norm() / exact.norm()).item()
+    tighter = osamp.sample_dpm_adaptive(den, x0.clone(), 0.05, 80.0, rtol=0.001, atol=0.001)
+    assert err(tight) < 5e-2 and err(tighter) < 0.3 * err(tight) and err(loose) > err(tight)    # local control, global error follows
+    assert info_l["steps"] < info_t["steps"] and info_t["nfe"] == 3 * info_t["steps"]
+    osamp.sample_dpm_adaptive(den, x0.clone(), 0.05, 80.0, h_init=5.0, info=info_h)
+    assert info_h["n_reject"] >= 1
