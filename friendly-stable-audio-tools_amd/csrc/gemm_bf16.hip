@@ -407,7 +407,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------
 template <int BK>
 __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
-    if constexpr (BK == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    if constexpr (BK == 128) return row * 256 + ((chunk ^ (row & 15)) << 4);      // 256-B rows: 16 chunks, XOR with the row
+    else if constexpr (BK == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
     else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
@@ -422,9 +423,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
     constexpr int TN = BN / WN;
-    static_assert(TN == 64, "wave tile is TM x 64");
+    // the fused epilogues need a whole head / a value-gate pair per wave (64 columns); plain fp32 output takes any 32-multiple
+    static_assert(TN % 32 == 0 && (TN == 64 || EPI == EPI_F32), "wave tile is TM x 64 (TM x 32k for EPI_F32)");
     constexpr int MI = TM / 32;
-    constexpr int NI = 2;
+    constexpr int NI = TN / 32;
     constexpr int CPR = BK / 8;                    // 16-B chunks per row
     // One LDS-DMA instruction of one wave moves 64 chunks = 1 KiB.  A stage holds WL_A + WL_B of them (A rows first, then
     // W rows, contiguous); wave w issues wave-loads w, w+NW, w+2NW, ...  When NW does not divide WL (256x192 on 12 waves:
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         const bool is_a = L < WL_A;
         int q = (is_a ? L : L - WL_A) * 64 + lane;
         int row = q / CPR, pos = q % CPR;
-        int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
+        int c = (BK == 128) ? (pos ^ (row & 15)) : (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
         int gm = (dbg_same ? 0 : m0) + row;
         gm = gm < M ? gm : M - 1;
         int gn = (dbg_same ? 0 : n0) + row;
@@ -644,12 +646,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
             // pin the interleave: one ds_read of the NEXT step's fragments behind each MFMA of this step
             if (ks + 1 < KS) {
+                constexpr int NR = MI + NI, NM = MI * NI;
 #pragma unroll
-                for (int r = 0; r < MI + NI; ++r) {
+                for (int r = 0; r < (NR < NM ? NR : NM); ++r) {
                     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - (MI + NI), 0);
+                if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x8, NM - NR, 0);
+                if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
             }
@@ -783,7 +787,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
         const bool is_a = L < WL_A;
         int q = (is_a ? L : L - WL_A) * 64 + lane;
         int row = q / CPR, pos = q % CPR;
-        int c = (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
+        int c = (BK == 128) ? (pos ^ (row & 15)) : (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
         int gm = (dbg_same ? 0 : m0) + row;
         gm = gm < M ? gm : M - 1;
         int gn = (dbg_same ? 0 : n0) + row;
@@ -1025,7 +1029,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             else if (s64 > best) v = 16;
             else if (best == s256) v = (cdiv(a.M, 256) > 16) ? 26 : 22;   // 26: grouped raster + 4-stage ring (large M)
             else if (best == s192) v = 30;
-            else v = 15;
+            else v = 15;      // (variants 36-40, smaller wave tiles / 256-B rows, win 5 % in isolation and lose 2 % in the plan)
         } else {
             v = 5;
         }
@@ -1061,8 +1065,23 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 28: return launch_pipe2<128, 128, 64, 4, 2, 4, EPI>(a, stream);
         case 29: return launch_pipe2<256, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
-        default: sat_set_error("gemm: unknown variant %d", v); return SAT_E_INVALID;
+        case 36:
+            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 4, 3, EPI>(a, stream);    // 16 waves of 32x32
+            break;
+        case 39: return launch_pipe<128, 128, 128, 4, 2, 2, EPI>(a, stream);       // 256-B rows: half the barriers per k
+        case 40:
+            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 128, 4, 4, 2, EPI>(a, stream);
+            break;
+        case 37:
+            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 2, 4, 3, EPI>(a, stream);    // 8 waves of 64x32
+            break;
+        case 38:
+            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 4, 2, EPI>(a, stream);    // 16 waves, 2 stages: 2 per CU
+            break;
+        default: break;
     }
+    sat_set_error("gemm: unknown variant %d (or not built for this epilogue)", v);
+    return SAT_E_INVALID;
 }
 
 }  // namespace
