@@ -126,6 +126,11 @@ def test_dit_adaln_vs_reference_golden(dev):
     assert_close("adaLN cfg7 vs reference", got, gold["cfg7_T77"], 1.5e-1)
     got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), cfg_scale=1.0)
     assert_close("adaLN without global cond vs reference", got, gold["noglobal_T77"], 3e-2)
+    # adaLN-modulated LayerNorm fused with the e4m3 row quantisation (fp8 GEMM mode)
+    dit.set_gemm_dtype("fp8")
+    got8 = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
+    assert_close("adaLN fp8 vs matched fp8 oracle", got8, odit.dit_forward(sd, x, t, c, g, 3, 4, rnd=odit.Fp8Rounding(), adaln=True), 5e-3)
+    dit.set_gemm_dtype("bf16")
     # fused sampler-step entry point
     dit.prepare_generation(c.to(dev), g.to(dev), 7.0)
     sigma = 2.3
@@ -528,3 +533,25 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
     fn = lambda xin, tt: odit.dit_forward(dsd2, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
     want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), z0 + noise * sig[0], sig, lambda i, s, sn: step_noise[i])
     assert_close("audio-to-audio latents", lat, want, 2e-2)
+
+    # inpainting through the public entry point (generation.py:195-213): cut & paste of the init latents + soft mask; the
+    # region the last step's binary mask keeps (mask <= 1: everything) must come out as init + renoise * sigma_last
+    from stable_audio_tools.inference.generation import build_mask
+    margs = dict(cropfrom=0, pastefrom=25, pasteto=100, maskstart=25, maskend=75, softnessL=10, softnessR=10, marination=0)
+    itn2 = iter(step_noise)
+    renoise = [synthetic.synth_input(f"rn_a2a{i}", (b, 64, t_len), 90 + i) for i in range(steps)]
+    bn.encode = lambda x, return_info=False, **kw: orig(x, return_info=return_info, noise=vnoise.to(x.device))
+    try:
+        lat_in = generate_diffusion_cond(model, steps=steps, cfg_scale=7.0, conditioning_tensors=cond, sample_size=t_len * ratio_d,
+                                         seed=1, device=str(dev), init_audio=(44100, init), mask_args=margs, return_latents=True,
+                                         sampler_type="dpmpp-2m-sde", sigma_min=0.3, sigma_max=50, noise=noise,
+                                         noise_sampler=lambda s, sn: next(itn2).to(dev), inpaint_noise=lambda i: renoise[i].to(dev))
+    finally:
+        bn.encode = orig
+    cut = torch.zeros_like(z0)
+    pf, cl = int(0.25 * t_len), t_len - int(0.25 * t_len)
+    cut[:, :, pf:pf + cl] = z0[:, :, :cl]
+    sig_in = osamp.get_sigmas_polyexponential(steps, 0.3, 50.0, 1.0)
+    x0, cb = osamp.inpainting_start_and_callback(cut, noise * sig_in[0], build_mask(t_len, margs), steps, lambda i: renoise[i])
+    want_in = osamp.sample_dpmpp_2m_sde(lambda x, s: osamp.vdenoise(fn, x, s), x0.clone(), sig_in, lambda i, s, sn: step_noise[i], callback=cb)
+    assert_close("inpainting latents (generate_diffusion_cond)", lat_in, want_in, 2e-2)
