@@ -36,12 +36,17 @@ FORCE_DIST = os.environ.get("SAT_BENCH_FORCE_DIST") == "1"
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+# --workload sa2_a2a = BASELINE config 4: Stable Audio 2.0 shape (285-s context, T = 6144 latent frames, S = 6145), audio-to-audio:
+# VAE encode of the init audio + 100 sampler steps + decode.  Not the headline; an extra measured point.
+WORKLOAD = {"name": "sa_open"}
+
+
 def build_model(dev):
     import stable_audio_tools as S
     from stable_audio_tools import model_configs as MC, synthetic
     from stable_audio_tools.models import _init
     with _init.skip_init():
-        model = S.create_model_from_config(MC.stable_audio_open_1_0())
+        model = S.create_model_from_config(MC.stable_audio_2_0() if WORKLOAD["name"] == "sa2_a2a" else MC.stable_audio_open_1_0())
     sd = synthetic.synth_state_dict(model.state_dict(), 0)
     model.load_state_dict(sd)
     return model.to(dev).eval(), sd
@@ -50,7 +55,7 @@ def build_model(dev):
 def conditioning(model, prompt_ids, dev):
     """Random 'T5' embeddings (seeded per prompt id) + the model's own number conditioners."""
     from stable_audio_tools import synthetic
-    cond = model.conditioner([{"seconds_start": 0, "seconds_total": 47} for _ in prompt_ids])
+    cond = model.conditioner([{"seconds_start": 0, "seconds_total": int(SAMPLE_SIZE / SAMPLE_RATE)} for _ in prompt_ids])
     emb = torch.stack([synthetic.synth_input(f"prompt{i}", (128, 768), 2) for i in prompt_ids]).to(dev)
     cond["prompt"] = (emb, torch.ones(len(prompt_ids), 128, device=dev))
     return {k: cond[k] for k in ("prompt", "seconds_start", "seconds_total")}
@@ -59,8 +64,11 @@ def conditioning(model, prompt_ids, dev):
 def one_generation(model, cond, seed, dev, world):
     from stable_audio_tools import _hip
     from stable_audio_tools.inference.generation import generate_diffusion_cond
+    extra = dict(SAMPLER)
+    if WORKLOAD["name"] == "sa2_a2a":
+        extra.update(init_audio=(SAMPLE_RATE, WORKLOAD["init_audio"]), init_noise_level=7.0)
     audio = generate_diffusion_cond(model, steps=DIT_STEPS, cfg_scale=CFG_SCALE, conditioning_tensors=cond, sample_size=SAMPLE_SIZE,
-                                    seed=seed, device=str(dev), **SAMPLER)
+                                    seed=seed, device=str(dev), **extra)
     # per-item int16 quantisation on the device (reference generate.py:142-151 / audio_utils.py:21-26)
     b, c, n = audio.shape
     out = torch.empty((b, c, n), dtype=torch.int16, device=dev)
@@ -116,7 +124,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
                     help="GEMM operand type: bf16 (headline) or fp8 = BASELINE config 5 (e4m3 to_qkv / cross to_q / FF-in, rest bf16)")
+    ap.add_argument("--workload", choices=("sa_open", "sa2_a2a"), default="sa_open",
+                    help="sa_open: the headline (BASELINE config 2/3); sa2_a2a: config 4, SA-2.0 shape, audio-to-audio, 1 GPU")
     args = ap.parse_args()
+    global SAMPLE_SIZE
+    WORKLOAD["name"] = args.workload
+    if args.workload == "sa2_a2a":
+        SAMPLE_SIZE = 12582912
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +145,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     model, sd = build_model(dev)
+    if args.workload == "sa2_a2a":
+        g = torch.Generator(device="cpu").manual_seed(11)
+        WORKLOAD["init_audio"] = (torch.rand(2, SAMPLE_SIZE, generator=g) - 0.5).to(dev)
+        args.no_cpu_baseline = True
     if rank != 0 or args.no_cpu_baseline:
         sd = None
     # rank-strided prompt sharding, as the reference's generate.py:119-120
@@ -143,6 +161,7 @@ def main():
     lib = _hip.lib()
     for i in range(args.warmup):
         one_generation(model, cond, 1000 + i, dev, world)
+    dit._ensure_plan()                              # --warmup 0: the plan is otherwise built lazily by the first generation
     _hip.check(lib.sat_dit_profile(dit._plan, 1))
     if use_dist:
         dist.barrier()
@@ -176,7 +195,8 @@ def main():
         if os.path.exists(tpath) and args.batch == 1:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line = {
-            "metric": "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-Open-1.0 shape",
+            "metric": "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-Open-1.0 shape" if args.workload == "sa_open" else
+                      "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-2.0 shape audio-to-audio (encode + sample + decode)",
             "value": audio_seconds / elapsed,
             "unit": "audio-seconds/sec",
             "n_gpus": world,
@@ -187,9 +207,11 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 (to_qkv, cross to_q, FF-in; per-token x per-channel scales) + bf16, fp32 accumulate",
-            "data": "synthetic (random-init weights of the SA-Open-1.0 architecture, random T5 embeddings)",
-            "config": {"workload": "Stable-Audio-Open-1.0 DiT shape (24 layers, D=1536, S=1025, CFG 7 -> 2 sequences/prompt) + Oobleck decode, "
-                                   f"{args.batch} prompt(s)/GPU x 47.55 s, 100 DPM-Solver++(3M) SDE steps", "prompts_per_gpu": args.batch,
+            "data": "synthetic (random-init weights of the SA-Open-1.0 / SA-2.0 DiT + Oobleck architecture, random text embeddings)",
+            "config": {"workload": ("Stable-Audio-Open-1.0 DiT shape (24 layers, D=1536, S=1025, CFG 7 -> 2 sequences/prompt) + Oobleck decode, "
+                                    f"{args.batch} prompt(s)/GPU x 47.55 s, 100 DPM-Solver++(3M) SDE steps") if args.workload == "sa_open" else
+                                   ("Stable Audio 2.0 shape (24 layers, D=1536, S=6145, CFG 7) audio-to-audio: Oobleck encode of 285.3 s init audio + "
+                                    f"100 DPM-Solver++(3M) SDE steps from sigma 7 + decode, {args.batch} prompt(s)/GPU"), "prompts_per_gpu": args.batch,
                        "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
             "roofline": {"bound": "mfma", "kernel": f"FFN-in SwiGLU GEMM M={m.value} N={n.value} K={k.value} ({args.dtype} MFMA, fp32 acc)", "achieved": achieved,
                          "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
