@@ -43,7 +43,7 @@ struct LayerW {
     float *pre_g, *pre_b, *cross_g, *cross_b, *ff_g, *ff_b;
     bf16_t *w_qkv, *w_o, *w_cq, *w_ckv, *w_co, *w_ff1, *w_ff2;
     float *b_ff1, *b_ff2;
-    float *s_qkv, *s_cq, *s_ff1;      // fp8_gemm: per-output-channel scales (the weights above then hold e4m3 bytes)
+    float *s_qkv, *s_cq, *s_ff1, *s_ff2;      // fp8_gemm: per-output-channel scales (the weights above then hold e4m3 bytes)
 };
 
 }  // namespace
@@ -185,7 +185,8 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
             SAT_TRY(get_tensor(p, pf + "ff.ff.0.proj.bias", 2 * inner, &b1));
             SAT_TRY(sat_launch_pack_bias(b1, L.b_ff1, 2 * inner, 1, s));
         }
-        SAT_TRY(pack_w(p, ar, pf + "ff.ff.2.weight", D, inner, 0, &L.w_ff2, s));
+        if (f8) SAT_TRY(pack_w8(p, ar, pf + "ff.ff.2.weight", D, inner, 0, &L.w_ff2, &L.s_ff2, s));
+        else SAT_TRY(pack_w(p, ar, pf + "ff.ff.2.weight", D, inner, 0, &L.w_ff2, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff.ff.2.bias", D, &L.b_ff2, s));
     }
     return 0;
@@ -196,6 +197,7 @@ struct Workspace {
     bf16_t *A, *AO, *Q, *K, *Vt, *Hh;
     float *ff, *h1, *mo;
     float* As;              // fp8_gemm: per-row scale of the quantised LayerNorm output in A
+    unsigned char* Hs;      // fp8_gemm: E8M0 block scales of the MXFP8 hidden activation in Hh, [M][inner / 32]
     float *gsum, *ssg;      // adaLN: silu(global + timestep embed) [bf, D]; per-layer modulation [bf, depth, 6, D]
     size_t qkv_bytes;
     size_t total;
@@ -227,6 +229,7 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     w.h1 = (float*)take((size_t)bf * D * 4);
     w.mo = (float*)take((size_t)bf * c.io_channels * T * 4);
     w.As = c.fp8_gemm ? (float*)take(M * 4) : nullptr;
+    w.Hs = c.fp8_gemm ? (unsigned char*)take(M * (size_t)(p->inner / 32)) : nullptr;
     w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
     w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
     w.total = off;
@@ -318,7 +321,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                                               ssg_ld, s));
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
-        if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_ff1; }
+        if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_ff1; g.H8 = (unsigned char*)w.Hh; g.Hs = w.Hs; }
         const bool prof = p->prof_on && l == c.depth / 2 && p->prof_n < kProfMaxPairs;
         if (prof) {
             if ((int)p->prof_ev.size() < 2 * (p->prof_n + 1)) {
@@ -338,6 +341,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         }
         g = GemmArgs{};
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
+        if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.Hs; g.w_scale = L.s_ff2; }
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
     }
@@ -398,6 +402,7 @@ extern "C" int sat_dit_plan_finalize(sat_dit_plan* p, sat_stream_t stream) {
     SAT_CHECK_ARG(it->second.second % (2 * (int64_t)D) == 0, SAT_E_INVALID, "dit plan: FF weight size not divisible by 2*embed_dim");
     p->inner = (int)(it->second.second / (2 * (int64_t)D));
     SAT_CHECK_ARG(p->inner % 64 == 0, SAT_E_UNSUPPORTED, "dit plan: FF inner dim %d must be a multiple of 64", p->inner);
+    SAT_CHECK_ARG(!p->cfg.fp8_gemm || p->inner % 128 == 0, SAT_E_UNSUPPORTED, "dit plan: fp8_gemm needs an FF inner dim that is a multiple of 128");
     if (p->arena) {
         (void)hipFree(p->arena);
         p->arena = nullptr;
@@ -634,5 +639,19 @@ extern "C" int sat_gemm_fp8_f32(const void* a8, const float* a_scale, const void
     g.A = (const bf16_t*)a8; g.W = (const bf16_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & 0xff;
     g.C = c; g.ldc = n; g.accumulate = accumulate; g.a_scale = a_scale; g.w_scale = w_scale;
     g.fp8 = (variant & 256) ? 1 : 2;      // bit 8 of variant: the plain 32x32x16 fp8 MFMA instead of the 2x-rate scaled 32x32x64
+    return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);
+}
+
+extern "C" int sat_quant_mx_rows_fp8(const float* x, void* out8, void* scales, int32_t rows, int32_t k, sat_stream_t stream) {
+    return sat_launch_quant_mx_rows(x, out8, scales, rows, k, (hipStream_t)stream);
+}
+
+extern "C" int sat_gemm_mxfp8_f32(const void* a8, const void* a_scales, const void* w8, const float* w_scale, const float* bias,
+                                  float* c, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream) {
+    SAT_CHECK_ARG(a8 && w8 && a_scales && w_scale && c, SAT_E_INVALID, "gemm_mxfp8: null pointer");
+    SAT_CHECK_ARG(((uintptr_t)a_scales & 3) == 0, SAT_E_INVALID, "gemm_mxfp8: the scale array must be 4-byte aligned");
+    GemmArgs g{};
+    g.A = (const bf16_t*)a8; g.W = (const bf16_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & 0xff;
+    g.C = c; g.ldc = n; g.accumulate = accumulate; g.a_bscale = (const unsigned*)a_scales; g.w_scale = w_scale; g.fp8 = 3;
     return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);
 }

@@ -71,10 +71,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float hv = 0.f;
                 if (m < M) {
                     float v = acc[i][0][r] + bv;
                     float gt = acc[i][1][r] + bg;
-                    H[(size_t)m * ldh + hc] = f32_to_bf16(v * silu_f(gt));
+                    hv = v * silu_f(gt);
+                }
+                if (g.H8) {
+                    // MXFP8: the 32 lanes of this half hold the 32 consecutive hidden columns of one block of row m.
+                    // scale = 2^e with e = ceil(log2(amax / 448)) (so that amax / scale <= 448), stored as E8M0 = e + 127
+                    const float am = half32_max(fabsf(hv));
+                    const float t = am * (1.0f / 448.0f);
+                    const unsigned tb = __float_as_uint(t);
+                    int e = (int)((tb >> 23) & 0xff) - 127 + ((tb & 0x7fffff) ? 1 : 0);
+                    e = am > 0.f ? (e < -127 ? -127 : (e > 127 ? 127 : e)) : -127;
+                    const float inv = __uint_as_float((unsigned)(127 - e) << 23);          // 2^-e (e = -127 -> 2^254: only for an all-zero block)
+                    const unsigned q = __builtin_amdgcn_cvt_pk_fp8_f32(hv * inv, 0.f, 0u, false);
+                    if (m < M) {
+                        g.H8[(size_t)m * ldh + hc] = (unsigned char)(q & 0xff);
+                        if (l31 == 0) g.Hs[(size_t)m * (ldh >> 5) + (hc >> 5)] = (unsigned char)(e + 127);
+                    }
+                } else if (m < M) {
+                    H[(size_t)m * ldh + hc] = f32_to_bf16(hv);
                 }
             }
     } else {   // EPI_HEADS
@@ -438,8 +456,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int N_FULL = WL - (LPT - 1) * NW;    // waves [0, N_FULL) issue LPT, the others LPT-1
     constexpr bool UNIFORM = (WL % NW) == 0;
     constexpr int ROWB = BK * 2;
-    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr bool MXA = FP8 == 3;                 // MXFP8 A operand: + one dword of E8M0 block scales per A row per stage
+    constexpr int SCALE_WAVES = MXA ? BM / 64 : 0; // the first BM/64 waves each DMA 64 scale dwords per stage
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB + (MXA ? BM * 4 : 0);
     constexpr int D = NS - 1;                      // prefetch distance
+    static_assert(!MXA || D == 1 || UNIFORM, "MXFP8: counted waits are built for uniform tiles or 2-stage rings");
     static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
     static_assert(!FP8 || (BK == 64 && DBG == 0), "fp8: 128-byte rows only");
 
@@ -492,6 +513,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         ld_ptr[i] = is_a ? g.A + (size_t)gm * K + c * 8 : g.W + (size_t)gn * K + c * 8;
     }
     const bool wave_full = UNIFORM || wave < N_FULL;
+    [[maybe_unused]] const unsigned* sc_ptr = nullptr;
+    if constexpr (MXA) {
+        int gm = m0 + wave * 64 + lane;
+        gm = gm < M ? gm : M - 1;
+        sc_ptr = g.a_bscale + (size_t)gm * (K / BK);      // [M][K/128 bytes] dwords; K counts 16-bit columns here
+    }
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -507,10 +534,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             if (UNIFORM || i + 1 < LPT || wave_full)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[i] + kt * BK),
                                                  (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024), 16, 0, 0);
+        if constexpr (MXA) {
+            if (wave < SCALE_WAVES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc_ptr + kt),
+                                                 (__attribute__((address_space(3))) void*)(sa + (BM + BN) * ROWB + wave * 256), 4, 0, 0);
+        }
     };
     // tiles k+1..k+D-1 may stay in flight: this wave issued LPT (or LPT-1) loads for each of them
     auto wait_steady = [&]() {
-        if constexpr (UNIFORM || D == 1) {
+        if constexpr (MXA && D > 1) {
+            if (wave < SCALE_WAVES) wait_vmcnt<(D - 1) * (LPT + 1)>();
+            else wait_vmcnt<(D - 1) * LPT>();
+        } else if constexpr (UNIFORM || D == 1) {
             wait_vmcnt<(D - 1) * LPT>();
         } else {
             if (wave_full) wait_vmcnt<(D - 1) * LPT>();
@@ -524,10 +559,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         const char* sa = smem + stage * STAGE_BYTES;
         const char* sb = sa + BM * ROWB;
         constexpr int KS = BK / 16;
-        if constexpr (FP8 == 2) {
-            // v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 127): twice the MFMA rate of bf16 / plain fp8.  One
-            // instruction consumes 64 k: lane (row, half) supplies 32 bytes = bytes half*32 .. +31 of the 64-byte step.  Which k
-            // the hardware assigns to a (half, byte) slot is irrelevant as long as A and W are loaded identically (they are).
+        if constexpr (FP8 >= 2) {
+            // v_mfma_scale_f32_32x32x64_f8f6f4: twice the MFMA rate of bf16 / plain fp8.  One instruction consumes 64 k = two scale
+            // blocks of 32.  Measured layout (tools/mx_probe.cpp): the FIRST 16 bytes of every lane belong to block 0, the LAST 16 to
+            // block 1, and block g takes its E8M0 scale from the lanes of half g.  So lane (row, half) loads the 16-byte chunks
+            // `half` and `2 + half` of the 64-byte step (k = half*16.. and 32 + half*16..), identically for A and W.
             typedef int i32x8 __attribute__((ext_vector_type(8)));
             constexpr int KS2 = BK / 32;               // 64-byte steps per 128-byte row
             i32x8 af[2][MI], bfr[2][NI];
@@ -535,21 +571,38 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const int row = wm * TM + i * 32 + l31;
-                    u32x4 lo = *reinterpret_cast<const u32x4*>(sa + lds_off_bk<BK>(row, ks * 4 + half * 2));
-                    u32x4 hi = *reinterpret_cast<const u32x4*>(sa + lds_off_bk<BK>(row, ks * 4 + half * 2 + 1));
+                    u32x4 lo = *reinterpret_cast<const u32x4*>(sa + lds_off_bk<BK>(row, ks * 4 + half));
+                    u32x4 hi = *reinterpret_cast<const u32x4*>(sa + lds_off_bk<BK>(row, ks * 4 + 2 + half));
                     af[buf][i] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
                 }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     const int row = wn * TN + j * 32 + l31;
-                    u32x4 lo = *reinterpret_cast<const u32x4*>(sb + lds_off_bk<BK>(row, ks * 4 + half * 2));
-                    u32x4 hi = *reinterpret_cast<const u32x4*>(sb + lds_off_bk<BK>(row, ks * 4 + half * 2 + 1));
+                    u32x4 lo = *reinterpret_cast<const u32x4*>(sb + lds_off_bk<BK>(row, ks * 4 + half));
+                    u32x4 hi = *reinterpret_cast<const u32x4*>(sb + lds_off_bk<BK>(row, ks * 4 + 2 + half));
                     bfr[buf][j] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
                 }
             };
             // 16-wave workgroups have 128 VGPRs per lane: 64 accumulators + one set of 32-byte fragments (32) fit, two sets do not;
             // four waves per SIMD cover the fragment-read latency instead
             constexpr bool DBUF = NT < 1024;
+            // MXFP8 A: dword of this row's four E8M0 block scales of the K-tile, shifted so that byte 0 / byte 2 are the blocks this
+            // lane half feeds in 64-byte step 0 / 1 (block = 2 * step + half)
+            [[maybe_unused]] int sdw[MI];
+            if constexpr (MXA) {
+                const char* ssc = sb + BN * ROWB;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    sdw[i] = (int)(*reinterpret_cast<const unsigned*>(ssc + (wm * TM + i * 32 + l31) * 4) >> (8 * half));
+            }
+            auto mx = [&](const i32x8& af_, const i32x8& bf_, f32x16 c_, int ks, int i) -> f32x16 {
+                if constexpr (MXA) {
+                    if (ks == 0) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af_, bf_, c_, 0, 0, 0, sdw[i], 0, 0x7F7F7F7F);
+                    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af_, bf_, c_, 0, 0, 2, sdw[i], 0, 0x7F7F7F7F);
+                } else {
+                    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af_, bf_, c_, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                }
+            };
             if constexpr (!DBUF) {
 #pragma unroll
                 for (int ks = 0; ks < KS2; ++ks) {
@@ -558,8 +611,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0,
-                                                                                        0x7F7F7F7F);
+                            acc[i][j] = mx(af[0][i], bfr[0][j], acc[i][j], ks, i);
                 }
                 return;
             }
@@ -572,8 +624,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0,
-                                                                                    0x7F7F7F7F, 0, 0x7F7F7F7F);
+                        acc[i][j] = mx(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], ks, i);
                 if (ks + 1 < KS2) {
                     constexpr int NR = 2 * (MI + NI), NM = MI * NI;
 #pragma unroll
@@ -720,7 +771,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                 for (int r = 0; r < 16; ++r) {
                     int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     row = row < M ? row : M - 1;
-                    const float sa_r = g.a_scale[row];
+                    const float sa_r = MXA ? 1.0f : g.a_scale[row];
 #pragma unroll
                     for (int j = 0; j < NI; ++j) acc[i][j][r] *= sa_r * sw[j];
                 }
@@ -919,7 +970,7 @@ int launch_pipe2(const GemmArgs& a, hipStream_t stream) {
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int FP8 = 0>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
-    constexpr int LDS = NS * (BM + BN) * BK * 2;
+    constexpr int LDS = NS * ((BM + BN) * BK * 2 + (FP8 == 3 ? BM * 4 : 0));
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
     auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG, FP8>;
     static bool attr_set = false;
@@ -929,7 +980,8 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     }
     GemmArgs b = a;
     if (FP8) {
-        SAT_CHECK_ARG(a.K % 128 == 0 && a.a_scale && a.w_scale, SAT_E_UNSUPPORTED, "gemm(fp8): K=%d must be a multiple of 128 and both scale vectors given", a.K);
+        SAT_CHECK_ARG(a.K % 128 == 0 && a.w_scale && (FP8 == 3 ? (const void*)a.a_bscale : (const void*)a.a_scale), SAT_E_UNSUPPORTED,
+                      "gemm(fp8): K=%d must be a multiple of 128 and both scale vectors given", a.K);
         b.K = a.K / 2;       // the kernel counts 16-bit columns: 128-byte LDS rows = 128 e4m3
     }
     SAT_CHECK_ARG(b.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", b.N, BN);
@@ -992,7 +1044,16 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             v = (s64 > best) ? 16 : (best == s256) ? 22 : (best == s192) ? 30 : 15;
             if (a.K < 384 && (v == 15 || v == 16)) v = 22;     // the 3-stage tiles need K >= 384 bytes
         }
-        if (a.fp8 == 2) {      // block-scaled MFMA with unit scales: 2x the MFMA rate
+        if (a.fp8 == 3) {      // MXFP8 A operand (hardware block scales), fp32 output only: FF-out
+            if constexpr (EPI == EPI_F32) {
+                switch (v) {
+                    case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 3>(a, stream);
+                    case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 0, 3>(a, stream);
+                    case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 0, 3>(a, stream);
+                    case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 3>(a, stream);
+                }
+            }
+        } else if (a.fp8 == 2) {      // block-scaled MFMA with unit scales: 2x the MFMA rate
             switch (v) {
                 case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 2>(a, stream);
                 case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 0, 2>(a, stream);

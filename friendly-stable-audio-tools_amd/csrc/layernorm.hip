@@ -184,6 +184,27 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __rest
     if (threadIdx.x == 0) row_scale[row] = scale;
 }
 
+// MXFP8 rows (reference producer for the kernel tests; in the plan the SwiGLU epilogue writes this format): one wave per row,
+// lane l owns elements l, l + 64, ...; every 32 consecutive elements share one E8M0 scale 2^ceil(log2(amax / 448))
+__global__ __launch_bounds__(256) void quant_mx_rows_kernel(const float* __restrict__ x, unsigned char* __restrict__ out,
+                                                            unsigned char* __restrict__ scales, int rows, int k) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    for (int c0 = 0; c0 < k; c0 += 64) {
+        const float v = x[(size_t)row * k + c0 + lane];
+        const float am = half32_max(fabsf(v));
+        const float t = am * (1.0f / 448.0f);
+        const unsigned tb = __float_as_uint(t);
+        int e = (int)((tb >> 23) & 0xff) - 127 + ((tb & 0x7fffff) ? 1 : 0);
+        e = am > 0.f ? (e < -127 ? -127 : (e > 127 ? 127 : e)) : -127;
+        const float inv = __uint_as_float((unsigned)(127 - e) << 23);
+        const unsigned q = __builtin_amdgcn_cvt_pk_fp8_f32(v * inv, 0.f, 0u, false);
+        out[(size_t)row * k + c0 + lane] = (unsigned char)(q & 0xff);
+        if ((lane & 31) == 0) scales[(size_t)row * (k >> 5) + ((c0 + lane) >> 5)] = (unsigned char)(e + 127);
+    }
+}
+
 __global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int n, int interleave) {
     int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
@@ -280,6 +301,14 @@ int sat_launch_quant_rows_fp8(const float* w, void* out8, float* row_scale, int 
     SAT_CHECK_ARG(!swiglu_interleave || n % 128 == 0, SAT_E_UNSUPPORTED, "quant_rows_fp8: swiglu needs n %% 128 == 0");
     hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3(n), dim3(256), 0, s, w, reinterpret_cast<unsigned char*>(out8), row_scale, n, k,
                        swiglu_interleave);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int sat_launch_quant_mx_rows(const float* x, void* out8, void* scales, int rows, int k, hipStream_t s) {
+    SAT_CHECK_ARG(x && out8 && scales && rows > 0 && k > 0 && k % 64 == 0, SAT_E_INVALID, "quant_mx_rows: bad args (k %% 64 == 0)");
+    hipLaunchKernelGGL(quant_mx_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, reinterpret_cast<unsigned char*>(out8),
+                       reinterpret_cast<unsigned char*>(scales), rows, k);
     SAT_LAUNCH_CHECK();
     return 0;
 }

@@ -72,6 +72,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// max over the 32 lanes of a wave half (lanes 0-31 / 32-63), result in every lane: four DPP steps (quad xor 1, quad xor 2,
+// row_half_mirror, row_mirror -> max of each row of 16) and one ds_swizzle that swaps the two rows of a half.  No address
+// VGPRs, no ds_bpermute: 6 instructions against ~15 for five __shfl_xor steps.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float half32_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));       // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_move<0x4E>(v));       // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_move<0x141>(v));      // row_half_mirror
+    v = fmaxf(v, dpp_move<0x140>(v));      // row_mirror
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)));   // lane ^ 16
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids
 // land on the same XCD (hardware places block b on XCD b % 8), so neighbouring tiles share
 // one L2.  Speed only -- never correctness.
@@ -132,6 +148,12 @@ struct GemmArgs {
     int fp8;
     const float* a_scale;   // [M]
     const float* w_scale;   // [N]
+    // fp8 == 3 (MXFP8 A operand): one E8M0 scale per 32 k of every A row, [M][K/32] bytes = [M][K/128] dwords, applied by the
+    // block-scaled MFMA itself; a_scale is unused
+    const unsigned* a_bscale;
+    // EPI_SWIGLU with H8 != nullptr: the hidden activation is written as MXFP8 (e4m3 bytes [M, N/2] + E8M0 [M, N/64]) instead of bf16
+    unsigned char* H8;
+    unsigned char* Hs;
     const float* gate;   // adaLN: (acc + bias) * gate[(row / gate_rows) * gate_ld + col] before the residual add; or nullptr
     int gate_rows, gate_ld;
     // EPI_SWIGLU
@@ -150,6 +172,7 @@ int sat_launch_layernorm_fp8(const float* x, const float* gamma, const float* be
                              const float* scale1p, const float* shift, int rows_per_seq, int ld, hipStream_t s);
 // rows of an fp32 matrix -> fp8 e4m3 with one scale per row (weights: per output channel; optional SwiGLU interleave)
 int sat_launch_quant_rows_fp8(const float* w, void* out8, float* row_scale, int n, int k, int swiglu_interleave, hipStream_t s);
+int sat_launch_quant_mx_rows(const float* x, void* out8, void* scales_e8m0, int rows, int k, hipStream_t s);
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
                          int sq, int sk, int sq_pad, int sk_pad, hipStream_t s);
 int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);

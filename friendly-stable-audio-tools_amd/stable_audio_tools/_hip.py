@@ -50,6 +50,9 @@ _SIGNATURES = {
     "sat_layernorm_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sat_gemm_fp8_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                    c_int32, c_void_p]),
+    "sat_quant_mx_rows_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "sat_gemm_mxfp8_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                     c_int32, c_void_p]),
     "sat_lincomb": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float,
                               c_int64, c_void_p]),
     "sat_dpm_error_partials": (c_int32, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64, c_void_p, c_int32, c_void_p]),

@@ -70,7 +70,9 @@ typedef struct sat_dit_cfg {
     int32_t fp8_gemm;          /* 0: bf16 GEMM operands everywhere (default, the headline path);
                                   1: BASELINE config 5 -- the GEMMs fed by a LayerNorm (self-attention to_qkv, cross-attention
                                   to_q, FF-in; transformer.py:314, 311, 222) take OCP e4m3 operands with one scale per token
-                                  (activations) and per output channel (weights), fp32 accumulation; everything else as 0 */
+                                  (activations) and per output channel (weights), fp32 accumulation; FF-out (transformer.py:270)
+                                  takes the SwiGLU output as MXFP8 (e4m3 + one E8M0 scale per 32 hidden channels, written by the
+                                  FF-in epilogue, consumed as hardware block scales) and e4m3 weights; everything else as 0 */
 } sat_dit_cfg;
 
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
@@ -158,6 +160,13 @@ int sat_layernorm_fp8(const float* x_dev, const float* gamma_dev, const float* b
 int sat_gemm_fp8_f32(const void* a8_dev, const float* a_scale_dev, const void* w8_dev, const float* w_scale_dev,
                      const float* bias_dev, float* c_dev, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant,
                      sat_stream_t stream);
+/*   sat_quant_mx_rows_fp8: x [rows, k] fp32 -> MXFP8: out8 [rows, k] e4m3 bytes + scales [rows, k/32] E8M0 bytes
+ *                          (scale = 2^ceil(log2(amax_block / 448)), byte = exponent + 127); k % 64 == 0
+ *   sat_gemm_mxfp8_f32   : as sat_gemm_fp8_f32 with an MXFP8 A operand: the block scales are applied by the MFMA itself */
+int sat_quant_mx_rows_fp8(const float* x_dev, void* out8_dev, void* scales_e8m0_dev, int32_t rows, int32_t k, sat_stream_t stream);
+int sat_gemm_mxfp8_f32(const void* a8_dev, const void* a_scales_e8m0_dev, const void* w8_dev, const float* w_scale_dev,
+                       const float* bias_dev, float* c_dev, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant,
+                       sat_stream_t stream);
 
 /* Error estimate of one DPM-Solver adaptive step (k-diffusion sample_dpm_adaptive, inference/sampling.py:222-224):
  * partial_dev[j], j < n_partials, receive block-wise partial sums of ((x_low - x_high) / delta)^2 with

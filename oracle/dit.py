@@ -36,15 +36,34 @@ def fp8_rows(x):
     return (x * (1.0 / scale)).to(torch.float8_e4m3fn).to(torch.float32) * scale
 
 
+def mxfp8_blocks(x, block=32):
+    """MXFP8 as the fp8_gemm SwiGLU epilogue writes it: every ``block`` consecutive elements of the last dim share a power-of-two
+    scale 2^ceil(log2(amax / 448)) (E8M0), values are e4m3 -- returned de-quantised."""
+    shp = x.shape
+    xb = x.reshape(*shp[:-1], shp[-1] // block, block)
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    t = amax * (1.0 / 448.0)
+    # ceil(log2(t)) through the float representation, exactly as the kernel does it (no rounding issues of log2 at powers of two)
+    tb = t.contiguous().view(torch.int32)
+    e_bits = ((tb >> 23) & 0xff) - 127 + ((tb & 0x7fffff) != 0).to(torch.int32)
+    e = torch.where(amax > 0, e_bits.clamp(-127, 127).float(), torch.full_like(amax, -127.0))
+    scale = torch.pow(2.0, e.double()).float()
+    q = (xb * torch.pow(2.0, -e.double()).float()).to(torch.float8_e4m3fn).to(torch.float32)
+    return (q * scale).reshape(shp)
+
+
 class Fp8Rounding:
     """Matched-rounding hook of BASELINE config 5 (sat_dit_cfg.fp8_gemm): bf16 everywhere, except that the LayerNorm outputs
-    and the weights of the three GEMMs they feed (to_qkv, cross to_q, FF-in) are e4m3 with per-row scales."""
+    and the weights of the three GEMMs they feed (to_qkv, cross to_q, FF-in) are e4m3 with per-row scales, and FF-out takes the
+    SwiGLU output as MXFP8 (block-32 power-of-two scales) and per-channel e4m3 weights."""
 
     def __call__(self, x):
         return bf16_round(x)
 
     act = staticmethod(fp8_rows)
     weight = staticmethod(fp8_rows)
+    hidden = staticmethod(mxfp8_blocks)       # SwiGLU output = A operand of FF-out (hardware block scales)
+    weight2 = staticmethod(fp8_rows)          # FF-out weight, per output channel
 
 
 def _ra(rnd, x):      # a LayerNorm output that feeds a GEMM
@@ -140,8 +159,9 @@ def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
 def feed_forward(sd, pfx, x, rnd=None):
     h = F.linear(x, _rw(rnd, sd[pfx + "ff.0.proj.weight"]), sd[pfx + "ff.0.proj.bias"])
     val, gate = h.chunk(2, dim=-1)
-    h = _r(rnd, val * F.silu(gate))
-    return F.linear(h, _r(rnd, sd[pfx + "ff.2.weight"]), sd[pfx + "ff.2.bias"])
+    h = rnd.hidden(val * F.silu(gate)) if hasattr(rnd, "hidden") else _r(rnd, val * F.silu(gate))
+    w2 = rnd.weight2(sd[pfx + "ff.2.weight"]) if hasattr(rnd, "weight2") else _r(rnd, sd[pfx + "ff.2.weight"])
+    return F.linear(h, w2, sd[pfx + "ff.2.bias"])
 
 
 # models/transformer.py:656-702 (TransformerBlock.forward: adaLN branch :665-689, plain branch :691-700)

@@ -298,3 +298,43 @@ def test_gemm_fp8(dev, variant, m, n, k, plain):
     assert_close(f"gemm fp8 v{variant} {m}x{n}x{k}", cd, want, 1e-4)
     full = a @ w.T + bias + c0
     assert rel_l2(cd, full) < 5e-2, "e4m3 operands: a few percent from the fp32 product"
+
+
+def _deq_mx(q_bytes, e8m0):
+    sc = torch.pow(2.0, e8m0.to(torch.float64) - 127.0).float()
+    return (q_bytes.view(torch.float8_e4m3fn).to(torch.float32).reshape(q_bytes.shape[0], -1, 32) * sc[:, :, None]).reshape(q_bytes.shape)
+
+
+@pytest.mark.parametrize("variant", [0, 15, 16, 22, 30])
+@pytest.mark.parametrize("m,n,k", [(2050, 1536, 6144), (257, 768, 1536), (130, 256, 384), (1, 768, 256)])
+def test_gemm_mxfp8(dev, variant, m, n, k):
+    """MXFP8 A operand (e4m3 + one E8M0 scale per 32 k, applied by v_mfma_scale_f32_32x32x64_f8f6f4 itself; the scales ride
+    through the LDS ring as one more 4-byte LDS-DMA per row) x per-channel e4m3 W -> fp32: the producer against the oracle's
+    block quantiser, the GEMM against an fp32 matmul of the de-quantised operands."""
+    from oracle import dit as odit
+    if variant == 22 and n % 256:
+        pytest.skip("256-column tile")
+    if variant == 30 and n % 192:
+        pytest.skip("192-column tile")
+    if variant in (15, 16) and k < 384:
+        pytest.skip("3-stage tiles need K >= 384")
+    _hip, lib = _lib()
+    a = _rand((m, k), 220, 2.0) * torch.logspace(-2, 1, k)[None, :]      # block amax spans three decades
+    a[0, :64] = 0
+    w = _rand((n, k), 221) * 0.05 + torch.linspace(-0.02, 0.03, n)[:, None]
+    bias, c0 = _rand((n,), 222), _rand((m, n), 223)
+    ad, wd = a.to(dev), w.to(dev)
+    a8 = torch.empty((m, k), dtype=torch.uint8, device=dev)
+    asc = torch.empty((m, k // 32), dtype=torch.uint8, device=dev)
+    w8 = torch.empty((n, k), dtype=torch.uint8, device=dev)
+    sw = torch.empty((n,), dtype=torch.float32, device=dev)
+    _hip.check(lib.sat_quant_mx_rows_fp8(_hip.ptr(ad), _hip.ptr(a8), _hip.ptr(asc), m, k, _hip.stream()))
+    _hip.check(lib.sat_quant_rows_fp8(_hip.ptr(wd), _hip.ptr(w8), _hip.ptr(sw), n, k, _hip.stream()))
+    a_deq = _deq_mx(a8.cpu(), asc.cpu())
+    assert_close("mxfp8 producer vs oracle", a_deq, odit.mxfp8_blocks(a), 1e-3)
+    assert (asc.cpu()[0, :2] == 0).all() and (a8.cpu()[0, :64] == 0).all()
+    want = a_deq @ _deq8(w8.cpu(), sw.cpu()).T + bias + c0
+    cd, bd = c0.to(dev), bias.to(dev)
+    _hip.check(lib.sat_gemm_mxfp8_f32(_hip.ptr(a8), _hip.ptr(asc), _hip.ptr(w8), _hip.ptr(sw), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1,
+                                      variant, _hip.stream()))
+    assert_close(f"gemm mxfp8 v{variant} {m}x{n}x{k}", cd, want, 1e-4)
