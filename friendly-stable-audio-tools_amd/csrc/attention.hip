@@ -24,8 +24,12 @@ namespace {
 constexpr int KV_TILE = 64;
 constexpr int Q_BLOCK = 128;
 
+// MX8: fp8_gemm mode -- the output is the A operand of the to_out GEMM and is written as MXFP8 (e4m3 bytes at `out`, one E8M0
+// scale per 32 channels = half a head at `out_scales` [B*Sq][H*2]) instead of bf16
+template <bool MX8>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                         const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+                                                        unsigned char* __restrict__ out_scales,
                                                         int H, int KVH, int Sq, int Sk, int Sq_pad, int Sk_pad,
                                                         float scale_log2) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE * 128];   // [stage][K | Vt][64 rows * 128 B]
@@ -188,7 +192,32 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (qi < Sq) {
+    if constexpr (MX8) {
+        // block db (32 channels of this head): this lane holds 16 of them, lane ^ 32 the other 16
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float am = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(oacc[db][r] * inv));
+            am = fmaxf(am, __shfl_xor(am, 32, 64));
+            const float t = am * (1.0f / 448.0f);
+            const unsigned tb = __float_as_uint(t);
+            int e = (int)((tb >> 23) & 0xff) - 127 + ((tb & 0x7fffff) ? 1 : 0);
+            e = am > 0.f ? (e < -127 ? -127 : (e > 127 ? 127 : e)) : -127;
+            const float qs = inv * __uint_as_float((unsigned)(127 - e) << 23);
+            if (qi < Sq) {
+                unsigned char* op = reinterpret_cast<unsigned char*>(out) + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64 + db * 32;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    unsigned p = 0;
+                    p = __builtin_amdgcn_cvt_pk_fp8_f32(oacc[db][rq * 4] * qs, oacc[db][rq * 4 + 1] * qs, p, false);
+                    p = __builtin_amdgcn_cvt_pk_fp8_f32(oacc[db][rq * 4 + 2] * qs, oacc[db][rq * 4 + 3] * qs, p, true);
+                    *reinterpret_cast<unsigned*>(op + rq * 8 + half * 4) = p;
+                }
+                if (half == 0) out_scales[((size_t)b * Sq + qi) * ((size_t)H * 2) + h * 2 + db] = (unsigned char)(e + 127);
+            }
+        }
+    } else if (qi < Sq) {
         bf16_t* op = out + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -205,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 }  // namespace
 
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
-                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s) {
+                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales) {
     SAT_CHECK_ARG(q && k && vt && out, SAT_E_INVALID, "attention: null pointer");
     SAT_CHECK_ARG(b > 0 && h > 0 && kvh > 0 && h % kvh == 0, SAT_E_INVALID, "attention: bad heads %d/%d", h, kvh);
     SAT_CHECK_ARG(sq > 0 && sk > 0 && sq_pad >= sq && sk_pad >= sk, SAT_E_INVALID, "attention: bad lengths");
@@ -214,7 +243,10 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
     SAT_CHECK_ARG(sk_pad >= sk + 3, SAT_E_INVALID, "attention: sk_pad must be >= sk + 3 (key-side shift), got %d for sk=%d", sk_pad, sk);
     const float scale_log2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
     dim3 grid(cdiv(sq, Q_BLOCK), h, b);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, q, k, vt, out, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
+    if (out_scales)
+        hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
+    else
+        hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
     SAT_LAUNCH_CHECK();
     return 0;
 }

@@ -43,7 +43,7 @@ struct LayerW {
     float *pre_g, *pre_b, *cross_g, *cross_b, *ff_g, *ff_b;
     bf16_t *w_qkv, *w_o, *w_cq, *w_ckv, *w_co, *w_ff1, *w_ff2;
     float *b_ff1, *b_ff2;
-    float *s_qkv, *s_cq, *s_ff1, *s_ff2;      // fp8_gemm: per-output-channel scales (the weights above then hold e4m3 bytes)
+    float *s_qkv, *s_cq, *s_ff1, *s_ff2, *s_o, *s_co;      // fp8_gemm: per-output-channel scales (the weights above then hold e4m3 bytes)
 };
 
 }  // namespace
@@ -168,14 +168,16 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
         const bool f8 = c.fp8_gemm != 0;
         if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, &L.s_qkv, s));
         else SAT_TRY(pack_w(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, s));
-        SAT_TRY(pack_w(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, s));
+        if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, &L.s_o, s));
+        else SAT_TRY(pack_w(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, s));
         if (Dct > 0) {
             SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.gamma", D, &L.cross_g, s));
             SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.beta", D, &L.cross_b, s));
             if (f8) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, &L.s_cq, s));
             else SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, s));
             SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_kv.weight", 2 * Dc, Dc, 0, &L.w_ckv, s));
-            SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, s));
+            if (f8) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, &L.s_co, s));
+            else SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, s));
         }
         if (f8) SAT_TRY(pack_w8(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, &L.s_ff1, s));
         else SAT_TRY(pack_w(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, s));
@@ -198,6 +200,7 @@ struct Workspace {
     float *ff, *h1, *mo;
     float* As;              // fp8_gemm: per-row scale of the quantised LayerNorm output in A
     unsigned char* Hs;      // fp8_gemm: E8M0 block scales of the MXFP8 hidden activation in Hh, [M][inner / 32]
+    unsigned char* AOs;     // fp8_gemm: E8M0 block scales of the MXFP8 attention output in AO, [M][D / 32]
     float *gsum, *ssg;      // adaLN: silu(global + timestep embed) [bf, D]; per-layer modulation [bf, depth, 6, D]
     size_t qkv_bytes;
     size_t total;
@@ -230,6 +233,7 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     w.mo = (float*)take((size_t)bf * c.io_channels * T * 4);
     w.As = c.fp8_gemm ? (float*)take(M * 4) : nullptr;
     w.Hs = c.fp8_gemm ? (unsigned char*)take(M * (size_t)(p->inner / 32)) : nullptr;
+    w.AOs = c.fp8_gemm ? (unsigned char*)take(M * (size_t)(D / 32)) : nullptr;
     w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
     w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
     w.total = off;
@@ -286,9 +290,10 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
         g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
         SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
-        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s));
+        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, f8 ? w.AOs : nullptr));
         g = GemmArgs{};
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
+        if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
         // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
@@ -308,9 +313,10 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
                 const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lcpad * 64;
                 SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
-                                             p->ctx_lc, Spad, p->ctx_lcpad, s));
+                                             p->ctx_lc, Spad, p->ctx_lcpad, s, f8 ? w.AOs : nullptr));
                 g = GemmArgs{};
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
+                if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
                 SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
             }
         }

@@ -173,8 +173,9 @@ int sat_launch_layernorm_fp8(const float* x, const float* gamma, const float* be
 // rows of an fp32 matrix -> fp8 e4m3 with one scale per row (weights: per output channel; optional SwiGLU interleave)
 int sat_launch_quant_rows_fp8(const float* w, void* out8, float* row_scale, int n, int k, int swiglu_interleave, hipStream_t s);
 int sat_launch_quant_mx_rows(const float* x, void* out8, void* scales_e8m0, int rows, int k, hipStream_t s);
+// out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
-                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s);
+                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales = nullptr);
 int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
 int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swiglu_interleave, hipStream_t s);
 int sat_launch_pack_bias(const float* b, float* out, int n, int swiglu_interleave, hipStream_t s);

@@ -72,7 +72,8 @@ typedef struct sat_dit_cfg {
                                   to_q, FF-in; transformer.py:314, 311, 222) take OCP e4m3 operands with one scale per token
                                   (activations) and per output channel (weights), fp32 accumulation; FF-out (transformer.py:270)
                                   takes the SwiGLU output as MXFP8 (e4m3 + one E8M0 scale per 32 hidden channels, written by the
-                                  FF-in epilogue, consumed as hardware block scales) and e4m3 weights; everything else as 0 */
+                                  FF-in epilogue, consumed as hardware block scales) and e4m3 weights; the attention kernels write
+                                  MXFP8 too (one scale per half head) for the to_out projections (transformer.py:319); rest as 0 */
 } sat_dit_cfg;
 
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);

@@ -55,7 +55,8 @@ def mxfp8_blocks(x, block=32):
 class Fp8Rounding:
     """Matched-rounding hook of BASELINE config 5 (sat_dit_cfg.fp8_gemm): bf16 everywhere, except that the LayerNorm outputs
     and the weights of the three GEMMs they feed (to_qkv, cross to_q, FF-in) are e4m3 with per-row scales, and FF-out takes the
-    SwiGLU output as MXFP8 (block-32 power-of-two scales) and per-channel e4m3 weights."""
+    SwiGLU output as MXFP8 (block-32 power-of-two scales) and per-channel e4m3 weights; the attention outputs feed the to_out
+    projections as MXFP8 too.  I.e. every GEMM of the blocks except the per-generation to_kv of the context."""
 
     def __call__(self, x):
         return bf16_round(x)
@@ -64,6 +65,8 @@ class Fp8Rounding:
     weight = staticmethod(fp8_rows)
     hidden = staticmethod(mxfp8_blocks)       # SwiGLU output = A operand of FF-out (hardware block scales)
     weight2 = staticmethod(fp8_rows)          # FF-out weight, per output channel
+    attn_out = staticmethod(mxfp8_blocks)     # attention output = A operand of to_out: MXFP8, one scale per half head
+    weight_o = staticmethod(fp8_rows)         # to_out weights (self and cross), per output channel
 
 
 def _ra(rnd, x):      # a LayerNorm output that feeds a GEMM
@@ -138,8 +141,9 @@ def self_attention(sd, pfx, x, freqs, num_heads, rnd=None):
     k = apply_rotary(k.float(), freqs)
     q, k, v = _r(rnd, q), _r(rnd, k), _r(rnd, v)
     out = _merge(attention_core(q, k, v, rnd))
-    out = _r(rnd, out)
-    return F.linear(out, _r(rnd, sd[pfx + "to_out.weight"]))
+    out = rnd.attn_out(out) if hasattr(rnd, "attn_out") else _r(rnd, out)
+    w_o = rnd.weight_o(sd[pfx + "to_out.weight"]) if hasattr(rnd, "weight_o") else _r(rnd, sd[pfx + "to_out.weight"])
+    return F.linear(out, w_o)
 
 
 # models/transformer.py:407-554, cross-attention branch (to_q / to_kv; no RoPE: :438)
@@ -151,8 +155,9 @@ def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
     k, v = _heads(k, kv_heads), _heads(v, kv_heads)
     q, k, v = _r(rnd, q), _r(rnd, k), _r(rnd, v)
     out = _merge(attention_core(q, k, v, rnd))
-    out = _r(rnd, out)
-    return F.linear(out, _r(rnd, sd[pfx + "to_out.weight"]))
+    out = rnd.attn_out(out) if hasattr(rnd, "attn_out") else _r(rnd, out)
+    w_o = rnd.weight_o(sd[pfx + "to_out.weight"]) if hasattr(rnd, "weight_o") else _r(rnd, sd[pfx + "to_out.weight"])
+    return F.linear(out, w_o)
 
 
 # models/transformer.py:211-287 (GLU + FeedForward; value = first half, gate = second half)

@@ -140,7 +140,8 @@ def test_dit_adaln_vs_reference_golden(dev):
 
 
 def test_dit_fp8_gemm_mode(dev, small_dit):
-    """BASELINE config 5: e4m3 operands (per-token / per-output-channel scales) for to_qkv, cross to_q and FF-in.  Against
+    """BASELINE config 5: e4m3 operands for every GEMM of the blocks (per-token scales after a LayerNorm, MXFP8 block scales for
+    the attention and SwiGLU outputs, per-output-channel weight scales).  Against
     the matched-rounding oracle that quantises at the same points (gate 5e-3: accumulation order + the rare code flipped by
     x * (1/s) vs the kernel's own rounding), and against the fp32 oracle at the stated looser tolerance (1e-1 without
     CFG: e4m3 carries 3 mantissa bits; the bf16 path sits at ~5e-3 on the same case)."""
@@ -164,7 +165,8 @@ def test_dit_fp8_gemm_mode(dev, small_dit):
         assert e_b > 1e-4, "fp8 mode must actually change the arithmetic"
         got7 = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=7.0)
         want7 = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=odit.Fp8Rounding())
-        assert_close("fp8 dit cfg7 vs matched fp8 oracle", got7, want7, 2e-2)
+        # CFG 7 extrapolates the cond/uncond difference ~7x: 7 x (4e-3, a handful of e4m3 codes flipped by accumulation order) + margin
+        assert_close("fp8 dit cfg7 vs matched fp8 oracle", got7, want7, 5e-2)
     finally:
         dit.set_gemm_dtype("bf16")
     again = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0)
