@@ -208,3 +208,29 @@ def test_full_dit_golden_exists_and_oracle_matches():
     x, t, c, gl = cases.dit_inputs(1, 1024, 768, 1536, 1)
     out = odit.dit_forward(sd, x, t, c, gl, 24, 24)
     assert rel_l2(out, g["out"]) < 5e-5
+
+
+def test_fp8_rounding_hooks_of_the_oracle():
+    """The matched-rounding hooks of the fp8 GEMM mode (BASELINE config 5) are test infrastructure too: pin their arithmetic.
+    e4m3 per-row scaling: amax maps to exactly 448, relative error <= 2^-4 per element of the same binade; MXFP8: power-of-two
+    block scales with amax / scale in (224, 448], zero blocks stay zero, idempotent."""
+    x = synthetic.synth_input("q8", (5, 256), 300, 3.0)
+    x[2] = 0
+    q = odit.fp8_rows(x)
+    assert torch.equal(q[2], torch.zeros(256))
+    assert torch.allclose(q.abs().amax(dim=1)[[0, 1, 3, 4]], x.abs().amax(dim=1)[[0, 1, 3, 4]], rtol=1e-6)
+    assert rel_l2(q, x) < 4e-2 and torch.allclose(odit.fp8_rows(q), q, rtol=1e-6, atol=0)      # idempotent up to the fp32 scale product
+    big = x.abs() > x.abs().amax(dim=1, keepdim=True) / 16          # normal range of e4m3 after scaling
+    assert ((q - x).abs()[big] <= x.abs()[big] * 2.0 ** -4 + 1e-12).all()
+
+    m = odit.mxfp8_blocks(x * torch.logspace(-3, 2, 256)[None, :])
+    xb = (x * torch.logspace(-3, 2, 256)[None, :]).reshape(5, 8, 32)
+    mb = m.reshape(5, 8, 32)
+    assert torch.equal(mb[2], torch.zeros(8, 32))
+    amax = xb.abs().amax(dim=-1)
+    # the block maximum is representable to within one e4m3 step of its binade and never saturates
+    assert (mb.abs().amax(dim=-1) <= amax * (1 + 2.0 ** -3)).all() and torch.isfinite(m).all()
+    assert rel_l2(m, x * torch.logspace(-3, 2, 256)[None, :]) < 4e-2
+    assert torch.equal(odit.mxfp8_blocks(m), m)
+    r = odit.Fp8Rounding()
+    assert torch.equal(r(x), odit.bf16_round(x)) and r.act is odit.fp8_rows and r.hidden is odit.mxfp8_blocks
