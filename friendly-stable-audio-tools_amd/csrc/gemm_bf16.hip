@@ -541,7 +541,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         }
     };
     // tiles k+1..k+D-1 may stay in flight: this wave issued LPT (or LPT-1) loads for each of them
-    auto wait_steady = [&]() {
+    [[maybe_unused]] auto wait_steady = [&]() {
         if constexpr (MXA && D > 1) {
             if (wave < SCALE_WAVES) wait_vmcnt<(D - 1) * (LPT + 1)>();
             else wait_vmcnt<(D - 1) * LPT>();
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
-    constexpr int NT = WM * WN * 64;
+    [[maybe_unused]] constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
     constexpr int TN = BN / WN;
     static_assert(TN % 64 == 0, "wave tile is TM x (NJ*64)");
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
                                                  (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024), 16, 0, 0);
     };
     // tiles k+1..k+D-1 may stay in flight: this wave issued LPT (or LPT-1) loads for each of them
-    auto wait_steady = [&]() {
+    [[maybe_unused]] auto wait_steady = [&]() {
         if constexpr (UNIFORM || D == 1) {
             wait_vmcnt<(D - 1) * LPT>();
         } else {
