@@ -43,6 +43,8 @@ def get_args():
     p.add_argument("--batch-size", type=int, default=10)
     p.add_argument("--clip-length", action="store_true")
     p.add_argument("--seed", type=int, default=-1)
+    p.add_argument("--gemm-dtype", choices=["bf16", "fp8"], default="bf16",
+                   help="build extension: fp8 = OCP e4m3 / MXFP8 operands for the transformer GEMMs (faster, ~1e-2 from the bf16 output)")
     return p.parse_args()
 
 
@@ -93,6 +95,8 @@ def main():
             model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), args.synthetic_weights))
     sample_rate, sample_size = model_config["sample_rate"], model_config["sample_size"]
     model = model.to(device).eval()
+    if args.gemm_dtype != "bf16":
+        model.model.model.set_gemm_dtype(args.gemm_dtype)
     cond_dim = model_config["model"]["conditioning"]["cond_dim"]
 
     conds = flatten_conditions(yaml.safe_load(open(args.cond_yaml_path)))
