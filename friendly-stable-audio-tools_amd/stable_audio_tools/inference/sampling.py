@@ -189,7 +189,6 @@ def _dpm_adaptive(denoise, after_denoise, x, sigma_min, sigma_max, rtol=0.01, at
         h = t - s
         ss = sig(s)
         denoise(x, ss, den)                                              # eps = (x - den) / sigma(s)
-        after_denoise(stats["steps"], x, ss, den)
         s1, s2 = s + r1 * h, s + r2 * h
         c = -sig(s1) * math.expm1(r1 * h) / ss
         _lin(u1, [(1 + c, x), (-c, den)])
@@ -216,6 +215,9 @@ def _dpm_adaptive(denoise, after_denoise, x, sigma_min, sigma_max, rtol=0.01, at
             stats["n_reject"] += 1
         stats["nfe"] += 3
         stats["steps"] += 1
+        # DPMSolver.dpm_solver_adaptive calls info_callback at the END of the attempted step, with the (possibly advanced) state
+        # and time and i = index of that step; `den` still holds the denoised estimate of the step's starting point
+        after_denoise(stats["steps"] - 1, x, sig(s), den)
     if info is not None:
         info.update(stats)
     return x
@@ -230,6 +232,7 @@ def _single_step_sampler(sampler_type, denoise, after_denoise, x, sigmas, sigma_
     den = torch.empty_like(x)
     den2 = torch.empty_like(x)
     x2 = torch.empty_like(x)
+    d0 = torch.empty_like(x)
 
     def draw(s_from, s_to):
         nz = noise_sampler(s_from, s_to) if noise_sampler is not None else torch.randn_like(x)
@@ -248,71 +251,77 @@ def _single_step_sampler(sampler_type, denoise, after_denoise, x, sigmas, sigma_
         sig = lambda t: math.exp(-t)
         eps1 = torch.empty_like(x)
         u = torch.empty_like(x)
+        e = torch.empty_like(x)
         for i, order_i in enumerate(orders):
             t, t_next = ts[i], ts[i + 1]
             h = t_next - t
             denoise(x, sig(t), den)
-            after_denoise(i, x, sig(t), den)
             st = sig(t)
-            # eps = (x - den)/st is never materialised: every combination below is written in (x, den, u, den_u)
+            # k-diffusion's DPMSolver caches eps(x, t) BEFORE it reports to the callback; the inpainting callback then mutates x in
+            # place, and the step functions combine the mutated x with the cached eps
+            _lin(e, [(1 / st, x), (-1 / st, den)])
+            after_denoise(i, x, st, den)
             if order_i == 1:
-                c = -sig(t_next) * math.expm1(h) / st
-                _lin(x, [(1 + c, x), (-c, den)])
+                _lin(x, [(1.0, x), (-sig(t_next) * math.expm1(h), e)])
             elif order_i == 2:
                 r1 = 0.5
                 s1 = t + r1 * h
-                c = -sig(s1) * math.expm1(r1 * h) / st
-                _lin(u, [(1 + c, x), (-c, den)])                       # u1 = x - sigma(s1) expm1(r1 h) eps
+                _lin(u, [(1.0, x), (-sig(s1) * math.expm1(r1 * h), e)])  # u1 = x - sigma(s1) expm1(r1 h) eps
                 denoise(u, sig(s1), den2)                              # eps_r1 = (u1 - den2) / sigma(s1)
                 a = -sig(t_next) * math.expm1(h)
                 b = -sig(t_next) / (2 * r1) * math.expm1(h)
                 # x_2 = x + a eps + b (eps_r1 - eps)
-                _lin(x, [(1 + (a - b) / st, x), (-(a - b) / st, den), (b / sig(s1), u), (-b / sig(s1), den2)])
+                _lin(x, [(1.0, x), (a - b, e), (b / sig(s1), u), (-b / sig(s1), den2)])
             else:
                 r1, r2 = 1 / 3, 2 / 3
                 s1, s2 = t + r1 * h, t + r2 * h
-                c = -sig(s1) * math.expm1(r1 * h) / st
-                _lin(u, [(1 + c, x), (-c, den)])                       # u1
+                _lin(u, [(1.0, x), (-sig(s1) * math.expm1(r1 * h), e)])  # u1
                 denoise(u, sig(s1), den2)                              # eps_r1 = (u - den2)/sigma(s1)
                 _lin(eps1, [(1 / sig(s1), u), (-1 / sig(s1), den2)])
                 a2 = -sig(s2) * math.expm1(r2 * h)
                 b2 = -sig(s2) * (r2 / r1) * (math.expm1(r2 * h) / (r2 * h) - 1)
                 # u2 = x + a2 eps + b2 (eps_r1 - eps)
-                _lin(u, [(1 + (a2 - b2) / st, x), (-(a2 - b2) / st, den), (b2, eps1)])
+                _lin(u, [(1.0, x), (a2 - b2, e), (b2, eps1)])
                 denoise(u, sig(s2), den2)                              # eps_r2 = (u2 - den2)/sigma(s2)
                 a3 = -sig(t_next) * math.expm1(h)
                 b3 = -sig(t_next) / r2 * (math.expm1(h) / h - 1)
-                _lin(x, [(1 + (a3 - b3) / st, x), (-(a3 - b3) / st, den), (b3 / sig(s2), u), (-b3 / sig(s2), den2)])
+                _lin(x, [(1.0, x), (a3 - b3, e), (b3 / sig(s2), u), (-b3 / sig(s2), den2)])
         return x
 
     hist = []                                                          # k-lms: derivative history, newest last
     for i in range(len(sigmas) - 1):
         s_i, s_n = sigmas[i], sigmas[i + 1]
         denoise(x, s_i, den)
-        after_denoise(i, x, s_i, den)
+        # k-diffusion's sample_lms / sample_heun / sample_dpm_2 form d = to_d(x, sigma, denoised) BEFORE calling `callback`; the
+        # reference's inpainting callback (sampling.py:175-190) then mutates x in place, so d must come from the pre-callback x.
+        # sample_dpmpp_2s_ancestral calls back first and derives everything from the mutated x.
         if sampler_type == "k-lms":
             d = hist.pop(0) if len(hist) == order else torch.empty_like(x)
             _lin(d, [(1 / s_i, x), (-1 / s_i, den)])                    # to_d
             hist.append(d)
+            after_denoise(i, x, s_i, den)
             cur = min(i + 1, order)
             cs = [lms_coefficient(cur, sigmas, i, j) for j in range(cur)]
             _lin(x, [(1.0, x)] + [(c, dd) for c, dd in zip(cs, reversed(hist))])
         elif sampler_type in ("k-heun", "k-dpm-2"):
+            _lin(d0, [(1 / s_i, x), (-1 / s_i, den)])                   # to_d
+            after_denoise(i, x, s_i, den)
             dt = s_n - s_i
             if s_n == 0:
-                _lin(x, [(1 + dt / s_i, x), (-dt / s_i, den)])          # Euler: x + (x - D)/sigma * dt
+                _lin(x, [(1.0, x), (dt, d0)])                           # Euler
             elif sampler_type == "k-heun":
-                _lin(x2, [(1 + dt / s_i, x), (-dt / s_i, den)])
+                _lin(x2, [(1.0, x), (dt, d0)])
                 denoise(x2, s_n, den2)
-                # x + dt/2 * [(x - D)/s_i + (x2 - D2)/s_n]
-                _lin(x, [(1 + dt / (2 * s_i), x), (-dt / (2 * s_i), den), (dt / (2 * s_n), x2), (-dt / (2 * s_n), den2)])
+                # x + dt/2 * [d + (x2 - D2)/s_n]
+                _lin(x, [(1.0, x), (dt / 2, d0), (dt / (2 * s_n), x2), (-dt / (2 * s_n), den2)])
             else:
                 s_mid = math.exp(0.5 * (math.log(s_i) + math.log(s_n)))
                 dt1, dt2 = s_mid - s_i, s_n - s_i
-                _lin(x2, [(1 + dt1 / s_i, x), (-dt1 / s_i, den)])
+                _lin(x2, [(1.0, x), (dt1, d0)])
                 denoise(x2, s_mid, den2)
                 _lin(x, [(1.0, x), (dt2 / s_mid, x2), (-dt2 / s_mid, den2)])
         elif sampler_type == "k-dpmpp-2s-ancestral":
+            after_denoise(i, x, s_i, den)
             s_down, s_up = get_ancestral_step(s_i, s_n, eta)
             if s_down == 0:
                 dt = s_down - s_i
@@ -417,7 +426,8 @@ def sample_k(model_fn, noise, init_data=None, mask=None, steps=100, sampler_type
 @torch.no_grad()
 def sample_discrete_euler(model, x, steps, sigma_max=1, verbose=False, callback=None, **extra_args):
     """Rectified-flow Euler integration (reference sampling.py:28-60): t from sigma_max down to 0, x <- x + dt * model(x, t)."""
-    x = x.float().contiguous()
+    xf = x.float().contiguous()
+    x = xf.clone() if xf.data_ptr() == x.data_ptr() else xf          # updated in place below: never the caller's tensor
     t = torch.linspace(sigma_max, 0, steps + 1)
     for i in range(steps):
         t_curr, t_prev = float(t[i]), float(t[i + 1])

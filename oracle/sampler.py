@@ -149,9 +149,9 @@ def sample_heun(denoiser, x, sigmas, callback=None):                      # K.sa
     s_in = x.new_ones([x.shape[0]])
     for i in range(len(sigmas) - 1):
         denoised = denoiser(x, sigmas[i] * s_in)
+        d = to_d(x, sigmas[i], denoised)          # k-diffusion forms d BEFORE the callback (which may mutate x in place)
         if callback is not None:
             callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
-        d = to_d(x, sigmas[i], denoised)
         dt = sigmas[i + 1] - sigmas[i]
         if sigmas[i + 1] == 0:
             x = x + d * dt
@@ -166,9 +166,9 @@ def sample_dpm_2(denoiser, x, sigmas, callback=None):                     # K.sa
     s_in = x.new_ones([x.shape[0]])
     for i in range(len(sigmas) - 1):
         denoised = denoiser(x, sigmas[i] * s_in)
+        d = to_d(x, sigmas[i], denoised)          # before the callback, as in k-diffusion
         if callback is not None:
             callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
-        d = to_d(x, sigmas[i], denoised)
         if sigmas[i + 1] == 0:
             x = x + d * (sigmas[i + 1] - sigmas[i])
         else:
@@ -199,11 +199,11 @@ def sample_lms(denoiser, x, sigmas, order=4, callback=None):               # K.s
     ds = []
     for i in range(len(sigmas) - 1):
         denoised = denoiser(x, sigmas[i] * s_in)
-        if callback is not None:
-            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
-        ds.append(to_d(x, sigmas[i], denoised))
+        ds.append(to_d(x, sigmas[i], denoised))   # before the callback, as in k-diffusion
         if len(ds) > order:
             ds.pop(0)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": denoised})
         cur_order = min(i + 1, order)
         coeffs = [linear_multistep_coeff(cur_order, sig, i, j) for j in range(cur_order)]
         x = x + sum(c * d for c, d in zip(coeffs, reversed(ds)))
@@ -286,7 +286,8 @@ class PIDStepSizeController:                                               # K.s
 
 # K.sampling.sample_dpm_adaptive(model, x, sigma_min, sigma_max, rtol=0.01, atol=0.01) as called at sampling.py:222-224
 # -> DPMSolver.dpm_solver_adaptive(order=3, eta=0): embedded DPM-Solver-2 (r1 = 1/3) / DPM-Solver-3 pair, PID step control
-def sample_dpm_adaptive(denoiser, x, sigma_min, sigma_max, rtol=0.01, atol=0.01, h_init=0.05, accept_safety=0.81, info=None):
+def sample_dpm_adaptive(denoiser, x, sigma_min, sigma_max, rtol=0.01, atol=0.01, h_init=0.05, accept_safety=0.81, info=None,
+                        callback=None):
     s_in = x.new_ones([x.shape[0]])
     sigma = lambda t: math.exp(-t)
     eps = lambda xx, t: (xx - denoiser(xx, sigma(t) * s_in)) / sigma(t)
@@ -299,6 +300,7 @@ def sample_dpm_adaptive(denoiser, x, sigma_min, sigma_max, rtol=0.01, atol=0.01,
         t = min(t_end, s + pid.h)
         h = t - s
         e = eps(x, s)
+        x_start, s_start = x, s
         s1, s2 = s + r1 * h, s + r2 * h
         u1 = x - sigma(s1) * math.expm1(r1 * h) * e
         e1 = eps(u1, s1)
@@ -315,6 +317,9 @@ def sample_dpm_adaptive(denoiser, x, sigma_min, sigma_max, rtol=0.01, atol=0.01,
             stats["n_reject"] += 1
         stats["nfe"] += 3
         stats["steps"] += 1
+        if callback is not None:      # DPMSolver.dpm_solver_adaptive reports at the END of the attempted step: the (possibly
+            # advanced) state and time, i = index of the step just attempted, denoised of the step's starting point
+            callback({"x": x, "i": stats["steps"] - 1, "sigma": sigma(s), "sigma_hat": sigma(s), "denoised": x_start - sigma(s_start) * e})
     if info is not None:
         info.update(stats)
     return x

@@ -119,7 +119,7 @@ def import_reference():
     sys.path.insert(0, REFERENCE_ROOT)
     try:
         importlib.import_module("stable_audio_tools")
-        for sub in ("models.dit", "models.transformer", "models.autoencoders", "models.diffusion",
+        for sub in ("models.factory", "models.dit", "models.transformer", "models.autoencoders", "models.diffusion",
                     "models.conditioners", "models.bottleneck", "models.pretransforms", "models.blocks",
                     "inference.generation", "inference.sampling", "inference.utils",
                     "utils.audio_utils", "utils.torch_common", "data.modification"):
@@ -130,6 +130,14 @@ def import_reference():
     for k, v in ref.items():
         sys.modules["ref_" + k] = v
         del sys.modules[k]
+        # The reference imports lazily inside functions (``from .diffusion import create_diffusion_cond_from_config`` in
+        # models/factory.py:14 ...).  A relative import resolves through ``__package__`` -> ``sys.modules``; with the original
+        # package name it would silently pick up the BUILD's same-named module once the names are handed back.  Rename.
+        v.__name__ = "ref_" + v.__name__
+        if getattr(v, "__package__", None):
+            v.__package__ = "ref_" + v.__package__
+        if getattr(v, "__spec__", None) is not None:
+            v.__spec__.name = "ref_" + v.__spec__.name
     sys.modules.update(saved)
     return sys.modules["ref_stable_audio_tools"]
 

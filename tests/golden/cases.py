@@ -34,6 +34,28 @@ MASK_ARGS = [
 ]
 
 
+# reference-orchestration goldens (make_golden.py gen_generate -> generate.npz): reduced SA-Open model (MC.reduced), 2 prompts
+GEN = {
+    "t_len": 24,
+    "calls": {      # generate_diffusion_cond(model, conditioning_tensors=..., sample_size=t_len*ratio, device="cpu", **kw)
+        "plain": dict(steps=6, cfg_scale=7.0, seed=5, sampler_type="dpmpp-3m-sde", sigma_min=0.3, sigma_max=500),
+        "a2a": dict(steps=5, cfg_scale=7.0, seed=6, init_audio=True, init_noise_level=4.0, sampler_type="dpmpp-3m-sde", sigma_min=0.3,
+                    sigma_max=500),
+        "inpaint": dict(steps=5, cfg_scale=7.0, seed=7, init_audio=True, sampler_type="dpmpp-2m-sde", sigma_min=0.3, sigma_max=50,
+                        mask_args=dict(cropfrom=0, pastefrom=25, pasteto=100, maskstart=25, maskend=75, softnessL=10, softnessR=10,
+                                       marination=0)),
+    },
+    "sample_k_mask": dict(maskstart=20, maskend=80, softnessL=15, softnessR=10, marination=0.1),
+    "sample_k": {   # sample_k(model.model, noise, init, mask, device="cpu", cfg_scale=7, **kw, **conditioning_inputs)
+        "heun_inpaint": dict(steps=4, sampler_type="k-heun", sigma_min=0.3, sigma_max=80.0, init=True, mask=True),
+        "lms_inpaint": dict(steps=5, sampler_type="k-lms", sigma_min=0.3, sigma_max=80.0, init=True, mask=True),
+        "dpm2_variation": dict(steps=4, sampler_type="k-dpm-2", sigma_min=0.3, sigma_max=6.0, init=True),
+        "ancestral_plain": dict(steps=4, sampler_type="k-dpmpp-2s-ancestral", sigma_min=0.3, sigma_max=80.0),
+        "fast_inpaint": dict(steps=6, sampler_type="k-dpm-fast", sigma_min=0.3, sigma_max=80.0, init=True, mask=True),
+    },
+}
+
+
 def dit_inputs(b, t_len, cond_dim, global_dim, seed, lc=130):
     x = synthetic.synth_input("x", (b, 64, t_len), seed)
     c = synthetic.synth_input("c", (b, lc, cond_dim), seed + 1)

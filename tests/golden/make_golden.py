@@ -194,6 +194,147 @@ def gen_adaln():
     save("dit_adaln_small", **out)
 
 
+class _DrawRecorder:
+    """Records, in order, every Gaussian draw the reference makes during one call (torch.randn for the initial noise,
+    torch.randn_like for the VAE bottleneck and the inpainting callback) and every per-step draw of the stand-in noise sampler."""
+
+    def __init__(self):
+        self.randn, self.randn_like, self.step = [], [], []
+        self._orig = (torch.randn, torch.randn_like)
+
+    def __enter__(self):
+        orig_randn, orig_like = self._orig
+
+        def randn(*a, **k):
+            t = orig_randn(*a, **k)
+            self.randn.append(t.clone())
+            return t
+
+        def randn_like(*a, **k):
+            t = orig_like(*a, **k)
+            self.randn_like.append(t.clone())
+            return t
+
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._orig
+
+    def step_noise(self, x):
+        t = self._orig[1](x)                 # i.i.d. unit Gaussian from the global generator (k-diffusion: BrownianTree, torchsde)
+        self.step.append(t.clone())
+        return t
+
+
+def _install_kdiffusion_standin(rec):
+    """k-diffusion 0.1.1 is not installed.  The REFERENCE's own generate_diffusion_cond / sample_k
+    (generation.py:95-261, sampling.py:144-228) are run on top of a stand-in ``k_diffusion`` whose entry points are the
+    restated algorithms of oracle/sampler.py with k-diffusion's call signatures.  What these goldens pin is therefore the
+    reference-resident half of the path: RNG order, sample_size // ratio, sigma_max <- init_noise_level, cut & paste,
+    build_mask, init_data / mask mixing, the in-place inpainting callback, the DiTWrapper / VDenoiser plumbing, decode."""
+    from oracle import sampler as osamp
+    K = sys.modules["k_diffusion"]
+
+    class VDenoiser(torch.nn.Module):
+        def __init__(self, inner_model):
+            super().__init__()
+            self.inner_model = inner_model
+            self.sigma_data = 1.0
+
+        def forward(self, x, sigma, **kwargs):
+            return osamp.vdenoise(lambda xin, t: self.inner_model(xin, t, **kwargs), x, sigma)
+
+    K.external.VDenoiser = VDenoiser
+    K.utils.append_dims = lambda x, n: x[(...,) + (None,) * (n - x.ndim)]
+    K.sampling.get_sigmas_polyexponential = lambda n, smin, smax, rho=1.0, device="cpu": \
+        osamp.get_sigmas_polyexponential(n, smin, smax, rho).to(device)
+
+    def wrap(fn, takes_noise):
+        def sampler(model, x, sigmas, extra_args=None, callback=None, disable=None, **kw):
+            den = lambda xx, sg: model(xx, sg, **(extra_args or {}))
+            if takes_noise:
+                return fn(den, x, sigmas, lambda i, a, b: rec().step_noise(x), callback=callback, **kw)
+            return fn(den, x, sigmas, callback=callback, **kw)
+        return sampler
+
+    K.sampling.sample_dpmpp_3m_sde = wrap(osamp.sample_dpmpp_3m_sde, True)
+    K.sampling.sample_dpmpp_2m_sde = wrap(osamp.sample_dpmpp_2m_sde, True)
+    K.sampling.sample_dpmpp_2s_ancestral = wrap(osamp.sample_dpmpp_2s_ancestral, True)
+    K.sampling.sample_heun = wrap(osamp.sample_heun, False)
+    K.sampling.sample_lms = wrap(osamp.sample_lms, False)
+    K.sampling.sample_dpm_2 = wrap(osamp.sample_dpm_2, False)
+    K.sampling.sample_dpm_fast = lambda model, x, smin, smax, n, extra_args=None, callback=None, disable=None: \
+        osamp.sample_dpm_fast(lambda xx, sg: model(xx, sg, **(extra_args or {})), x, smin, smax, n, callback=callback)
+    K.sampling.sample_dpm_adaptive = lambda model, x, smin, smax, rtol=0.05, atol=0.0078, extra_args=None, callback=None, disable=None: \
+        osamp.sample_dpm_adaptive(lambda xx, sg: model(xx, sg, **(extra_args or {})), x, smin, smax, rtol=rtol, atol=atol, callback=callback)
+
+
+def gen_generate():
+    """The reference's generate_diffusion_cond and sample_k on the reduced SA-Open model (CPU, fp32; torch.cuda.amp.autocast
+    disables itself without CUDA), with every Gaussian draw recorded so that the oracle and the product can replay them."""
+    from stable_audio_tools import model_configs as MC
+    holder = {}
+    _install_kdiffusion_standin(lambda: holder["rec"])
+    cfg = MC.reduced(MC.stable_audio_open_1_0())
+    model = R.ref("models.factory").create_model_from_config(cfg)
+    model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), 0))
+    model.eval()
+    dc = cfg["model"]["diffusion"]["config"]
+    ratio = cfg["model"]["pretransform"]["config"]["downsampling_ratio"]
+    b, t_len = 2, cases.GEN["t_len"]
+    cond = model.conditioner([{"seconds_start": 0, "seconds_total": 10 + i} for i in range(b)])
+    cond["prompt"] = [synthetic.synth_input("prompt", (b, 128, dc["cond_token_dim"]), 31), torch.ones(b, 128)]
+    cond = {k: cond[k] for k in ("prompt", "seconds_start", "seconds_total")}
+    init = synthetic.synth_input("init", (2, t_len * ratio - 100), 70, 0.3)
+    out = {}
+
+    def run(name, **kw):
+        for latents in (True, False):
+            with _DrawRecorder() as rec:
+                holder["rec"] = rec
+                y = rgen.generate_diffusion_cond(model, conditioning_tensors=dict(cond), sample_size=t_len * ratio, device="cpu",
+                                                 return_latents=latents, **kw)
+            key = "latents" if latents else "audio"
+            out[f"{name}.{key}"] = y
+            if latents:
+                assert len(rec.randn) == 1
+                out[f"{name}.noise"] = rec.randn[0]
+                for i, t in enumerate(rec.randn_like):
+                    out[f"{name}.randn_like{i}"] = t
+                for i, t in enumerate(rec.step):
+                    out[f"{name}.step{i}"] = t
+                print(name, "draws: randn_like", len(rec.randn_like), "step", len(rec.step), "latents", tuple(y.shape), float(y.std()))
+
+    for name, kw in cases.GEN["calls"].items():
+        kw = dict(kw)
+        if kw.pop("init_audio", False):
+            kw["init_audio"] = (44100, init)
+        run(name, **kw)
+    # sample_k directly (sampling.py:144-228): inpainting under a single-step sampler whose derivative is formed before the
+    # callback (k-heun), and the model-evaluation count / callback indices of plain sampling
+    rsamp = R.ref("inference.sampling")
+    ci = model.get_conditioning_inputs(cond)
+    for name, kw in cases.GEN["sample_k"].items():
+        noise = synthetic.synth_input("noise_" + name, (b, 64, t_len), 63)
+        init_lat = synthetic.synth_input("init_" + name, (b, 64, t_len), 64)
+        mask = rgen.build_mask(t_len, cases.GEN["sample_k_mask"]) if kw.get("mask") else None
+        args = {k: v for k, v in kw.items() if k not in ("mask", "init")}
+        seen = []
+        with _DrawRecorder() as rec:
+            holder["rec"] = rec
+            y = rsamp.sample_k(model.model, noise, init_lat if kw.get("init") else None, mask, device="cpu", cfg_scale=7.0, batch_cfg=True,
+                               rescale_cfg=True, callback=lambda a: seen.append(int(a["i"])), **args, **ci)
+        out[f"sample_k.{name}.out"] = y
+        out[f"sample_k.{name}.callback_i"] = torch.tensor(seen)
+        for i, t in enumerate(rec.randn_like):
+            out[f"sample_k.{name}.randn_like{i}"] = t
+        for i, t in enumerate(rec.step):
+            out[f"sample_k.{name}.step{i}"] = t
+        print("sample_k", name, "draws: randn_like", len(rec.randn_like), "step", len(rec.step), "callbacks", seen)
+    save("generate", **out)
+
+
 def gen_keys():
     """State-dict keys + shapes of the reference's SA-Open-1.0 model (T5 entry removed) and of the VAE config:
     the checkpoint-compatibility contract."""
@@ -230,6 +371,8 @@ if __name__ == "__main__":
         gen_adaln()
     if "keys" in which:
         gen_keys()
+    if "generate" in which:
+        gen_generate()
     if "full" in which:
         gen_full(False)
     if "full_long" in which:

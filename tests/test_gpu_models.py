@@ -6,9 +6,10 @@ Tolerances (bf16 GEMM operands, fp32 accumulate / residual / LN / softmax):
     remains is accumulation order and P rounded against a running instead of the final max; <= 1e-2
     for the ~35-conv-deep codec, where a 1-ulp fp32 difference before a bf16 store flips the stored
     value (2^-8 relative) for a small fraction of elements at every layer, plus __sinf;
-  * vs the pure-fp32 oracle (= the reference's CPU path): reported, gated loosely (<= 3e-2 without
-    CFG, <= 1.5e-1 at cfg_scale 7 -- CFG extrapolation amplifies rounding noise ~7x; SURVEY.md
-    section 7 measured 1.5e-2 / 1.05e-1 for a bf16 autocast of the REFERENCE itself).
+  * vs the pure-fp32 oracle / the reference's own fp32 outputs: gated at ~2x the measured value
+    (round-1 GPU log: reduced DiT 1.1e-3 -> 2.5e-3, CFG 7 5.4e-3 -> 1.2e-2, full-size DiT 3.7e-3 ->
+    8e-3, codec 5.6..7.7e-3 -> 1.5e-2), so that a regression of the bf16 path cannot hide behind
+    the gate; the fp32-class mode (gemm_dtype="fp32x") is gated at north_star's 1e-3.
 """
 import pytest
 import torch
@@ -61,7 +62,7 @@ def test_dit_forward_no_cfg(dev, small_dit, t_len):
     want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=bf16_round)
     want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"])
     e_m = assert_close("dit forward vs matched oracle", got, want_m, 3e-3)
-    e_f = assert_close("dit forward vs fp32 oracle", got, want_f, 3e-2)
+    e_f = assert_close("dit forward vs fp32 oracle", got, want_f, 2.5e-3)
     print(f"\n[dit T={t_len}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
 
 
@@ -78,7 +79,7 @@ def test_dit_forward_cfg_and_denoise(dev, small_dit):
         want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, scale_phi=phi, rnd=bf16_round)
         want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, scale_phi=phi)
         e_m = assert_close(f"dit cfg7 phi={phi} vs matched", got, want_m, 1e-2)
-        e_f = assert_close(f"dit cfg7 phi={phi} vs fp32", got, want_f, 1.5e-1)
+        e_f = assert_close(f"dit cfg7 phi={phi} vs fp32", got, want_f, 1.2e-2)
         print(f"\n[dit cfg7 phi={phi}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
     # fused VDenoiser evaluation == oracle vdenoise around the CFG model
     sigma = 3.7
@@ -99,7 +100,7 @@ def test_dit_adaln_vs_reference_golden(dev):
     """global_cond_type='adaLN' (dit.py:205-206, transformer.py:665-689): no prepend token; LayerNorm modulated by
     (1 + scale, shift) and the self-attention / FF branch outputs gated by sigmoid(1 - gate), all from one stacked
     to_scale_shift_gate GEMV per forward.  Against the matched-rounding oracle (3e-3) and against the outputs of the
-    REFERENCE itself (tests/golden/dit_adaln_small.npz, fp32; 3e-2 / 1.5e-1 with CFG 7 as for the prepend model)."""
+    REFERENCE itself (tests/golden/dit_adaln_small.npz, fp32; 4e-3 / 1.5e-2 with CFG 7, ~2x the measured error)."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import cases
@@ -118,14 +119,15 @@ def test_dit_adaln_vs_reference_golden(dev):
         got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
         want_m = odit.dit_forward(sd, x, t, c, g, 3, 4, rnd=bf16_round, adaln=True)
         e_m = assert_close(f"adaLN T={t_len} vs matched oracle", got, want_m, 3e-3)
-        e_f = assert_close(f"adaLN T={t_len} vs reference", got, gold[f"cfg1_T{t_len}"], 3e-2)
+        e_f = assert_close(f"adaLN T={t_len} vs reference", got, gold[f"cfg1_T{t_len}"], 4e-3)
         print(f"\n[adaLN T={t_len}] rel-L2 vs matched {e_m:.2e}, vs the reference {e_f:.2e}")
     x, t, c, g = cases.dit_inputs(2, 77, 128, 96, 1)
     got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0)
     assert_close("adaLN cfg7 vs matched oracle", got, odit.dit_forward(sd, x, t, c, g, 3, 4, cfg_scale=7.0, rnd=bf16_round, adaln=True), 1e-2)
-    assert_close("adaLN cfg7 vs reference", got, gold["cfg7_T77"], 1.5e-1)
+    e7 = assert_close("adaLN cfg7 vs reference", got, gold["cfg7_T77"], 1.5e-2)
+    print(f"\n[adaLN cfg7] rel-L2 vs the reference {e7:.2e}")
     got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), cfg_scale=1.0)
-    assert_close("adaLN without global cond vs reference", got, gold["noglobal_T77"], 3e-2)
+    assert_close("adaLN without global cond vs reference", got, gold["noglobal_T77"], 4e-3)
     # adaLN-modulated LayerNorm fused with the e4m3 row quantisation (fp8 GEMM mode)
     dit.set_gemm_dtype("fp8")
     got8 = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
@@ -193,7 +195,7 @@ def test_oobleck_decode(dev, small_vae, b, t_len):
     want_f = oob.oobleck_decoder(dsd, z, strides=strides)
     want_m = oob.oobleck_decoder(dsd, z, strides=strides, rnd=bf16_round)
     assert got.shape == want_f.shape
-    e_f = assert_close("decode vs fp32 oracle", got, want_f, 3e-2)
+    e_f = assert_close("decode vs fp32 oracle", got, want_f, 1.5e-2)
     e_m = assert_close("decode vs matched oracle", got, want_m, 1e-2)
     print(f"\n[decode b={b} T={t_len}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
 
@@ -210,12 +212,12 @@ def test_oobleck_encode_and_vae(dev, small_vae, b, t_len):
     esd = _sub(sd, "encoder.")
     want_f = oob.oobleck_encoder(esd, audio, strides=strides)
     want_m = oob.oobleck_encoder(esd, audio, strides=strides, rnd=bf16_round)
-    e_f = assert_close("encode vs fp32 oracle", got, want_f, 3e-2)
+    e_f = assert_close("encode vs fp32 oracle", got, want_f, 1.5e-2)
     e_m = assert_close("encode vs matched oracle", got, want_m, 1e-2)
     print(f"\n[encode b={b} T={t_len}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
     noise = synthetic.synth_input("vn", (b, 64, t_len), 13)
     z = model.encode(audio.to(dev), noise=noise.to(dev))
-    assert_close("encode+vae_sample", z, oob.vae_sample(want_f, noise), 3e-2)
+    assert_close("encode+vae_sample", z, oob.vae_sample(want_f, noise), 1.5e-2)
 
 
 def test_generate_diffusion_cond_small(dev, small_dit):
@@ -382,32 +384,112 @@ def test_rectified_flow_euler(dev, small_dit):
     assert_close("rectified-flow Euler trajectory", got, want, 1e-2)
 
 
-@pytest.mark.parametrize("t_len", [1024, 6144])
-def test_full_size_dit_vs_reference_golden(dev, t_len):
-    """Full-size SA-Open DiT (24 layers, D=1536, 1.06 B synthetic parameters, seed 0) against the output of the
-    REFERENCE itself (tests/golden/dit_full_T*.npz: fp32 CPU run of /root/reference in the build container) at the
-    SA-Open (T=1024) and SA-2.0 (T=6144) context lengths.  bf16 GEMM operands vs the fp32 reference: gate 3e-2
-    (SURVEY.md section 7 measured 1.5e-2 for a bf16 autocast of the reference itself)."""
+@pytest.fixture(scope="module")
+def full_dit(dev):
+    """Full-size SA-Open DiT (24 layers, D=1536, 1.06 B synthetic parameters, seed 0), built once for all full-size tests."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import cases
-    path = os.path.join(cases.GOLDEN_DIR, f"dit_full_T{t_len}.npz")
-    if not os.path.exists(path):
-        pytest.skip(f"{os.path.basename(path)} not generated")
     from stable_audio_tools import synthetic
     from stable_audio_tools.models import _init
     from stable_audio_tools.models.dit import DiffusionTransformer
-    want = cases.load(f"dit_full_T{t_len}")["out"]
     with _init.skip_init():
         dit = DiffusionTransformer(**cases.FULL_DIT)
     dit.load_state_dict(synthetic.synth_state_dict(dit.state_dict(), 0))
     dit = dit.to(dev).eval()
-    x, t, c, g = cases.dit_inputs(1, t_len, 768, 1536, 1)
-    got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
-    e = assert_close(f"full-size DiT T={t_len} vs reference", got, want, 3e-2)
-    print(f"\n[full DiT T={t_len}] rel-L2 vs the reference's fp32 output {e:.2e} (out std {want.std():.3f})")
+    yield dit
     del dit
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("t_len", [1024, 6144])
+def test_full_size_dit_vs_reference_golden(dev, full_dit, t_len):
+    """Full-size SA-Open DiT against the output of the REFERENCE itself (tests/golden/dit_full_T*.npz: fp32 CPU run of
+    /root/reference in the build container) at the SA-Open (T=1024) and SA-2.0 (T=6144) context lengths.  bf16 GEMM operands
+    vs the fp32 reference: gate 8e-3 (measured 3.7e-3 / 3.5e-3; SURVEY.md section 7 measured 1.5e-2 for a bf16 autocast of
+    the reference itself)."""
+    import cases
+    import os
+    path = os.path.join(cases.GOLDEN_DIR, f"dit_full_T{t_len}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated")
+    want = cases.load(f"dit_full_T{t_len}")["out"]
+    x, t, c, g = cases.dit_inputs(1, t_len, 768, 1536, 1)
+    got = full_dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
+    e = assert_close(f"full-size DiT T={t_len} vs reference", got, want, 8e-3)
+    print(f"\n[full DiT T={t_len}] rel-L2 vs the reference's fp32 output {e:.2e} (out std {want.std():.3f})")
+
+
+def _batch8_inputs():
+    """item 0 = the inputs of the reference golden dit_full_T1024, items 1..7 = other seeds."""
+    import cases
+    xs, ts, cs, gs = zip(*[cases.dit_inputs(1, 1024, 768, 1536, 1 + 10 * i) for i in range(8)])
+    t = torch.tensor([0.5, 0.11, 0.23, 0.37, 0.52, 0.68, 0.81, 0.93])
+    return torch.cat(xs), t, torch.cat(cs), torch.cat(gs)
+
+
+@pytest.mark.parametrize("gemm_dtype", ["bf16", "fp8"])
+def test_full_size_batch8_config3_config5(dev, full_dit, gemm_dtype):
+    """BASELINE config 3 (8 prompts per GPU: Bf = 16 sequences with CFG, M = 16400 rows -> the large-M tile path, 65 row-tile
+    bands, EPI_HEADS across 16 sequences) and config 5 (the same with e4m3 / MXFP8 GEMM operands) at FULL size:
+      * batch invariance: every one of the 8 prompts of the batched CFG-7 evaluation equals its own B=1 evaluation (different
+        tile shapes, same k order) within 1e-3 (bf16) / 2e-2 (fp8: per-token scales are batch independent, but a flipped e4m3
+        code is 2^-4 relative);
+      * prompt 0 at cfg_scale 1 inside the batch of 8 vs the REFERENCE's fp32 output dit_full_T1024.npz: 8e-3 (bf16), 8e-2 (fp8,
+        the stated looser tolerance of config 5: e4m3 has 3 mantissa bits)."""
+    import cases
+    x, t, c, g = _batch8_inputs()
+    t[0] = cases.dit_inputs(1, 1024, 768, 1536, 1)[1][0]
+    want0 = cases.load("dit_full_T1024")["out"]
+    full_dit.set_gemm_dtype(gemm_dtype)
+    try:
+        xd, td, cd, gd = x.to(dev), t.to(dev), c.to(dev), g.to(dev)
+        got1 = full_dit(xd, td, cross_attn_cond=cd, global_embed=gd, cfg_scale=1.0)                 # M = 8200
+        e0 = assert_close(f"[{gemm_dtype}] prompt 0 of 8 vs reference", got1[:1], want0, 8e-3 if gemm_dtype == "bf16" else 8e-2)
+        got7 = full_dit(xd, td, cross_attn_cond=cd, global_embed=gd, cfg_scale=7.0)                 # Bf = 16, M = 16400
+        assert torch.isfinite(got7).all()
+        worst = 0.0
+        for i in range(8):
+            one = full_dit(xd[i:i + 1], td[i:i + 1], cross_attn_cond=cd[i:i + 1], global_embed=gd[i:i + 1], cfg_scale=7.0)
+            worst = max(worst, rel_l2(got7[i:i + 1], one))
+        print(f"\n[config {'3' if gemm_dtype == 'bf16' else '5'} full size, B=8] prompt 0 vs reference {e0:.2e}; "
+              f"batched CFG-7 vs B=1, worst of 8: {worst:.2e}")
+        assert worst <= (1e-3 if gemm_dtype == "bf16" else 2e-2), f"batch of 8 differs from B=1 by {worst:.3e}"
+        # the fused sampler-step entry point at B=8 (what generate_diffusion_cond calls 100 times)
+        sigma = 2.5
+        full_dit.prepare_generation(cd, gd, 7.0)
+        den = full_dit.denoise(xd * sigma, sigma, cfg_scale=7.0)
+        from oracle import sampler as osamp
+        want_den = osamp.vdenoise(lambda xin, tt: full_dit(xin.to(dev), tt.to(dev), cross_attn_cond=cd, global_embed=gd, cfg_scale=7.0).cpu(),
+                                  x * sigma, torch.full((8,), sigma))
+        assert_close(f"[{gemm_dtype}] denoise_cfg B=8 vs forward + VDenoiser scalings", den, want_den, 1e-3 if gemm_dtype == "bf16" else 2e-2)
+    finally:
+        full_dit.set_gemm_dtype("bf16")
+
+
+def test_fp8_full_width_slice_vs_matched_oracle(dev):
+    """Config 5 at full WIDTH: a 2-layer slice of the SA-Open DiT (D=1536, 24 heads, FF 6144, cond 768) in fp8 mode against the
+    oracle that quantises at the same points (oracle.dit.Fp8Rounding): gate 5e-3, as for the reduced model."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    from oracle import dit as odit
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.models import _init
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    kw = dict(cases.FULL_DIT, depth=2)
+    with _init.skip_init():
+        dit = DiffusionTransformer(**kw)
+    sd = synthetic.synth_state_dict(dit.state_dict(), 5)
+    dit.load_state_dict(sd)
+    dit = dit.to(dev).eval().set_gemm_dtype("fp8")
+    x, t, c, g = cases.dit_inputs(2, 200, 768, 1536, 3)
+    got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
+    want_m = odit.dit_forward(sd, x, t, c, g, 2, 24, rnd=odit.Fp8Rounding())
+    want_f = odit.dit_forward(sd, x, t, c, g, 2, 24)
+    e_m = assert_close("fp8 full-width slice vs matched fp8 oracle", got, want_m, 5e-3)
+    e_f = assert_close("fp8 full-width slice vs fp32 oracle", got, want_f, 1e-1)
+    print(f"\n[fp8 full-width 2-layer slice] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
 
 
 def test_full_size_decoder_vs_reference_golden(dev):
@@ -423,12 +505,12 @@ def test_full_size_decoder_vs_reference_golden(dev):
         dec = OobleckDecoder(**cases.vae_kwargs(cases.FULL_VAE, True))
     dec.load_state_dict(synthetic.synth_state_dict(dec.state_dict(), 0))
     got = dec.to(dev)(synthetic.synth_input("z_full", (1, 64, 43), 1).to(dev))
-    e = assert_close("full-size decode vs reference", got, g["full_decode_T43"], 3e-2)
+    e = assert_close("full-size decode vs reference", got, g["full_decode_T43"], 1.5e-2)
     with _init.skip_init():
         enc = OobleckEncoder(**cases.vae_kwargs(cases.FULL_VAE, False))
     enc.load_state_dict(synthetic.synth_state_dict(enc.state_dict(), 0))
     got = enc.to(dev)(synthetic.synth_input("a_full", (1, 2, 2048 * 16), 2, 0.3).to(dev))
-    e2 = assert_close("full-size encode vs reference", got, g["full_encode_T16"], 3e-2)
+    e2 = assert_close("full-size encode vs reference", got, g["full_encode_T16"], 1.5e-2)
     print(f"\n[full codec] decode rel-L2 {e:.2e}, encode rel-L2 {e2:.2e} vs the reference's fp32 output")
 
 
