@@ -1,7 +1,7 @@
 """Headline benchmark (BASELINE.json): audio-seconds/sec @ 44.1 kHz stereo, 100-step DPM-Solver++(3M) SDE,
 Stable-Audio-Open-1.0 shape, synthetic random-init weights + random T5 embeddings.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 it re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one full ``generate_diffusion_cond`` call on this rank's prompts: conditioning -> 100 sampler steps
@@ -132,10 +132,26 @@ def main():
     if args.workload == "sa2_a2a":
         SAMPLE_SIZE = 12582912
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or FORCE_DIST):
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL), exactly the command line
+        # the driver would use; rank 0 of the child job prints the JSON line on our stdout
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched with a different --nproc-per-node?)")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or FORCE_DIST
@@ -190,10 +206,15 @@ def main():
         avg_ms = tot.value / max(cnt.value, 1)
         flops = 2.0 * m.value * n.value * k.value          # algorithmic FLOPs of one launch (ff_in 38.69 GFLOP/seq/layer)
         achieved = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_ffn_traffic.json")
-        if os.path.exists(tpath) and args.batch == 1:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        # HBM traffic of the dominant kernel cannot be measured inside a timed run (PMC passes serialise the kernels): it is the
+        # figure of the latest committed rocprofv3 --pmc pass of this same command (FETCH_SIZE x2 + WRITE_SIZE, separate passes)
+        traffic, traffic_source = None, None
+        for tname in ("r02_ffn_traffic.json", "r01_ffn_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and args.batch == 1 and args.dtype == "bf16" and args.workload == "sa_open":
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/{tname} (rocprofv3 --pmc passes of this command, not measured in this run)"
+                break
         line = {
             "metric": "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-Open-1.0 shape" if args.workload == "sa_open" else
                       "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-2.0 shape audio-to-audio (encode + sample + decode)",
@@ -215,7 +236,8 @@ def main():
                        "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
             "roofline": {"bound": "mfma", "kernel": f"FFN-in SwiGLU GEMM M={m.value} N={n.value} K={k.value} ({args.dtype} MFMA, fp32 acc)", "achieved": achieved,
                          "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "avg_launch_us": avg_ms * 1e3, "launches_timed": cnt.value},
+                         "traffic_source": traffic_source, "avg_launch_us": avg_ms * 1e3, "launches_timed": cnt.value},
+            "rccl_ranks": world if use_dist else 0,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd)

@@ -352,11 +352,7 @@ int glue_input_proj(const float* x, const float* Weff, float* X, int Bf, int xB,
 int glue_output_proj(const float* X, const float* WeffT, float* out, int Bf, int C, int T, int S, int D, hipStream_t s) {
     SAT_CHECK_ARG(C <= 64 && D % 16 == 0, SAT_E_UNSUPPORTED, "output_proj: C=%d D=%d unsupported", C, D);
     const int lds = 4 * OP_ROWS * D * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(output_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(output_proj_kernel), 160 * 1024));
     hipLaunchKernelGGL(output_proj_kernel, dim3(cdiv((int64_t)Bf * T, 4 * OP_ROWS)), dim3(256), lds, s, X, WeffT, out, Bf, C, T, S, D);
     SAT_LAUNCH_CHECK();
     return 0;

@@ -6,6 +6,8 @@
 #include <stdarg.h>
 
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,18 @@ void sat_set_error(const char* fmt, ...) {
     g_last_error = buf;
 }
 extern "C" const char* sat_last_error(void) { return g_last_error.c_str(); }
+
+int sat_ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    SAT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return 0;
+    SAT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kernel, dev});
+    return 0;
+}
 extern "C" int sat_version(void) { return 3; }
 
 // ------------------------------------------------------------------------------ plan
@@ -642,7 +656,7 @@ extern "C" int sat_gemm_fp8_f32(const void* a8, const float* a_scale, const void
                                 float* c, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(a8 && w8 && a_scale && w_scale && c, SAT_E_INVALID, "gemm_fp8: null pointer");
     GemmArgs g{};
-    g.A = (const bf16_t*)a8; g.W = (const bf16_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & 0xff;
+    g.A = (const bf16_t*)a8; g.W = (const bf16_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & ~256;
     g.C = c; g.ldc = n; g.accumulate = accumulate; g.a_scale = a_scale; g.w_scale = w_scale;
     g.fp8 = (variant & 256) ? 1 : 2;      // bit 8 of variant: the plain 32x32x16 fp8 MFMA instead of the 2x-rate scaled 32x32x64
     return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);

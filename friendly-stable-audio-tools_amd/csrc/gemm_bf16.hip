@@ -11,6 +11,8 @@
 //              32 gate so both land in one wave tile; models/transformer.py:232-235)
 //   EPI_HEADS  split into heads, partial RoPE (models/transformer.py:158-183,438-452) on
 //              q/k, store q/k as [B,H,Spad,64] and v transposed as [B,H,64,Spad]
+#include <type_traits>
+
 #include "sat_common.h"
 
 namespace {
@@ -171,6 +173,183 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                         }
                 }
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogues on TRANSPOSED accumulators.  The deep-prefetch kernels issue their MFMAs with the operands swapped
+// (W fragment as the A operand, activation fragment as the B operand), so a 32x32 block holds C^T: lane l31 owns TOKEN row
+// m = mw + i*32 + l31, and its 16 registers are output channels n = nw + j*32 + 8*(r>>2) + 4*half + (r&3) -- four runs of
+// four consecutive channels.  Everything a token needs is then lane-local:
+//   * fp32 output / residual: 16-byte loads and stores (4 per 32x32 block instead of 16 dword accesses);
+//   * bf16 / e4m3 output: two runs are exchanged between the wave halves with v_permlane32_swap (lane l takes the partner's
+//     low run, lane l+32 the high runs), so every lane writes 8 consecutive channels = one 16-byte (8-byte for e4m3) store
+//     instead of sixteen 2-byte stores -- the epilogue is store-issue bound (guide T21), not bandwidth bound;
+//   * RoPE: the rotation partner d^16 is register r^8 of the same lane, no cross-lane traffic, cos/sin are two 16-byte loads;
+//   * SwiGLU / MXFP8 block maximum: value and gate, resp. the 32 channels of a block, sit in one lane pair.
+// V^T (token-contiguous destination) keeps the un-swapped orientation and the epilogue above.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void half_swap(unsigned& lo_run, unsigned& hi_run) {
+    // lo_run / hi_run: the same dword of channel runs g and g+1.  Afterwards lanes 0-31 hold (run g of half 0, run g of half 1)
+    // = 8 consecutive channels starting at 8g, lanes 32-63 hold (run g+1 of half 0, run g+1 of half 1) starting at 8(g+1).
+    u32x2 r = __builtin_amdgcn_permlane32_swap(lo_run, hi_run, false, false);
+    lo_run = r[0];
+    hi_run = r[1];
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    bf16x2 v;
+    v[0] = f32_to_bf16(a);
+    v[1] = f32_to_bf16(b);
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int EPI, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
+                                                const int l31) {
+    const int M = g.M, N = g.N;
+    (void)N;
+    if constexpr (EPI == EPI_F32) {
+        const bool accum = g.accumulate != 0;
+        const int c0 = nw + 4 * half;                  // first channel of this lane's run 0
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mw + i * 32 + l31;
+            const int mc = m < M ? m : M - 1;
+            float* __restrict__ crow = g.C + (size_t)mc * g.ldc + c0;
+            f32x4 old[NI][4];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    old[j][q] = accum ? *reinterpret_cast<const f32x4*>(crow + j * 32 + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* grow = g.gate ? g.gate + (size_t)(mc / g.gate_rows) * g.gate_ld + c0 : nullptr;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + c0 + j * 32 + q * 8);
+                    if (grow) v *= *reinterpret_cast<const f32x4*>(grow + j * 32 + q * 8);      // adaLN gate (transformer.py:674, 688)
+                    v += old[j][q];
+                    if (m < M) *reinterpret_cast<f32x4*>(crow + j * 32 + q * 8) = v;
+                }
+        }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        static_assert(NI == 2, "value block + gate block");
+        const int ldh = N >> 1;
+        const int hc0 = nw >> 1;                       // first hidden column of this wave's 32
+        f32x4 bv[4], bg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bv[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nw + 4 * half + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bg[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nw + 32 + 4 * half + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mw + i * 32 + l31;
+            float hv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][0][r] + bv[r >> 2][r & 3];
+                const float gt = acc[i][1][r] + bg[r >> 2][r & 3];
+                hv[r] = m < M ? v * silu_f(gt) : 0.f;
+            }
+            if (g.H8) {
+                // MXFP8: the 32 hidden columns of this wave are ONE block of row m, held by the lane pair (l31, l31 + 32)
+                float am = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(hv[r]));
+                {
+                    unsigned a = __float_as_uint(am), b = a;
+                    half_swap(a, b);                   // a: this value of the low half in both halves, b: of the high half
+                    am = fmaxf(__uint_as_float(a), __uint_as_float(b));
+                }
+                const float t = am * (1.0f / 448.0f);
+                const unsigned tb = __float_as_uint(t);
+                int e = (int)((tb >> 23) & 0xff) - 127 + ((tb & 0x7fffff) ? 1 : 0);
+                e = am > 0.f ? (e < -127 ? -127 : (e > 127 ? 127 : e)) : -127;
+                const float inv = __uint_as_float((unsigned)(127 - e) << 23);          // 2^-e
+                unsigned q8[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned w = __builtin_amdgcn_cvt_pk_fp8_f32(hv[4 * q] * inv, hv[4 * q + 1] * inv, 0u, false);
+                    q8[q] = __builtin_amdgcn_cvt_pk_fp8_f32(hv[4 * q + 2] * inv, hv[4 * q + 3] * inv, w, true);
+                }
+                half_swap(q8[0], q8[1]);
+                half_swap(q8[2], q8[3]);
+                if (m < M) {
+                    unsigned char* hrow = g.H8 + (size_t)m * ldh + hc0 + 8 * half;
+                    *reinterpret_cast<u32x2*>(hrow) = u32x2{q8[0], q8[1]};
+                    *reinterpret_cast<u32x2*>(hrow + 16) = u32x2{q8[2], q8[3]};
+                    if (half == 0) g.Hs[(size_t)m * (ldh >> 5) + (hc0 >> 5)] = (unsigned char)(e + 127);
+                }
+            } else {
+                unsigned pk[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pk[2 * q] = pack_bf16x2(hv[4 * q], hv[4 * q + 1]);
+                    pk[2 * q + 1] = pack_bf16x2(hv[4 * q + 2], hv[4 * q + 3]);
+                }
+                half_swap(pk[0], pk[2]);
+                half_swap(pk[1], pk[3]);
+                half_swap(pk[4], pk[6]);
+                half_swap(pk[5], pk[7]);
+                if (m < M) {
+                    bf16_t* hrow = g.H + (size_t)m * ldh + hc0 + 8 * half;
+                    *reinterpret_cast<u32x4*>(hrow) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    *reinterpret_cast<u32x4*>(hrow + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+                }
+            }
+        }
+    } else {   // EPI_HEADS, row-major destinations only ([B,H,Spad,64]: q, k); V^T takes the un-swapped orientation
+        static_assert(NI == 2, "one head = two 32-column blocks");
+        const HeadsEpi& he = g.heads;
+        const int hp = he.heads * 64;
+        const int part = nw / hp;
+        const int head = (nw - part * hp) >> 6;
+        const int kind = he.kind[part];
+        bf16_t* __restrict__ dst = he.out[part];
+        const int S = he.S, Spad = he.Spad;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = mw + i * 32 + l31;
+            const int mc = m < M ? m : M - 1;
+            const int b = mc / S;
+            const int s = mc - b * S;
+            const int ob = (kind & 4) ? ((b * S) & 3) : 0;
+            if (kind & 2) {   // partial RoPE on d < 32 (block j = 0): partner of d < 16 is d + 16 = register r + 8 of this lane
+                const f32x4 cs0 = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 4 * half);
+                const f32x4 cs1 = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 8 + 4 * half);
+                const f32x4 sn0 = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 4 * half);
+                const f32x4 sn1 = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 8 + 4 * half);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float cs = (r < 4) ? cs0[r & 3] : cs1[r & 3];
+                    const float sn = (r < 4) ? sn0[r & 3] : sn1[r & 3];
+                    const float x1 = acc[i][0][r], x2 = acc[i][0][r + 8];
+                    acc[i][0][r] = x1 * cs - x2 * sn;
+                    acc[i][0][r + 8] = x2 * cs + x1 * sn;
+                }
+            }
+            bf16_t* row = dst + ((size_t)(b * he.heads + head) * Spad + s + ob) * 64 + 8 * half;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned pk[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pk[2 * q] = pack_bf16x2(acc[i][j][4 * q], acc[i][j][4 * q + 1]);
+                    pk[2 * q + 1] = pack_bf16x2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                }
+                half_swap(pk[0], pk[2]);
+                half_swap(pk[1], pk[3]);
+                half_swap(pk[4], pk[6]);
+                half_swap(pk[5], pk[7]);
+                if (m < M) {
+                    *reinterpret_cast<u32x4*>(row + j * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    *reinterpret_cast<u32x4*>(row + j * 32 + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+                }
+            }
+        }
     }
 }
 
@@ -555,7 +734,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // fragments are double-buffered across the k-steps: the ds_reads of step ks+1 are issued BEFORE the MFMAs of
     // step ks, so the wave waits with a counted lgkmcnt and LDS latency hides behind the matrix pipe
     typedef long i64x2 __attribute__((ext_vector_type(2)));
-    auto compute = [&](int stage) {
+    // TRc: operands swapped -> acc holds C^T (lane = token row), see gemm_epilogue_t
+    auto compute = [&](int stage, auto trc) {
+        constexpr bool TRc = decltype(trc)::value;
         const char* sa = smem + stage * STAGE_BYTES;
         const char* sb = sa + BM * ROWB;
         constexpr int KS = BK / 16;
@@ -597,8 +778,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             }
             auto mx = [&](const i32x8& af_, const i32x8& bf_, f32x16 c_, int ks, int i) -> f32x16 {
                 if constexpr (MXA) {
+                    static_assert(!TRc, "MXFP8 A operand: block scales were probed on the A side only (tools/mx_probe.cpp)");
                     if (ks == 0) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af_, bf_, c_, 0, 0, 0, sdw[i], 0, 0x7F7F7F7F);
                     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af_, bf_, c_, 0, 0, 2, sdw[i], 0, 0x7F7F7F7F);
+                } else if constexpr (TRc) {
+                    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bf_, af_, c_, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
                 } else {
                     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af_, bf_, c_, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
                 }
@@ -662,7 +846,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(af[ks & 1][i][h2], bfr[ks & 1][j][h2], acc[i][j], 0, 0, 0);
+                            acc[i][j] = TRc ? __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(bfr[ks & 1][j][h2], af[ks & 1][i][h2], acc[i][j], 0, 0, 0)
+                                            : __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(af[ks & 1][i][h2], bfr[ks & 1][j][h2], acc[i][j], 0, 0, 0);
                 if (ks + 1 < KS) {
 #pragma unroll
                     for (int r = 0; r < MI + NI; ++r) {
@@ -694,7 +879,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TRc ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
             // pin the interleave: one ds_read of the NEXT step's fragments behind each MFMA of this step
             if (ks + 1 < KS) {
                 constexpr int NR = MI + NI, NM = MI * NI;
@@ -727,32 +913,48 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) fb0[j] = *reinterpret_cast<const bf16x8*>(smem + BM * ROWB + lds_off_bk<BK>(wn * TN + j * 32 + l31, half));
     }
-    for (int k = 0; k < nk - D; ++k) {
-        if constexpr (!dbg_nobar) {
-            wait_steady();
-            __builtin_amdgcn_s_barrier();
-        }
-        if constexpr (!dbg_noload) stage_in(k + D, wr);
-        if constexpr (dbg_nolds) {
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
-        } else if constexpr (!dbg_nomfma) {
-            if (wave_rows_valid) compute(rd);
-        }
-        rd = (rd + 1 == NS) ? 0 : rd + 1;
-        wr = (wr + 1 == NS) ? 0 : wr + 1;
+    // Orientation (uniform over the workgroup: tiles never straddle a q / k / v part): transposed accumulators everywhere except
+    // for a V^T destination (token-contiguous stores want lane = channel), the MXFP8 A operand, the ablation modes, and when the
+    // caller asks for the legacy orientation (variant bit 12; A/B measurements and tests of the un-swapped epilogue).
+    bool tr = DBG == 0 && !MXA && !(g.variant & 0x1000);
+    if constexpr (EPI == EPI_HEADS) {
+        const int hp = g.heads.heads * 64;
+        tr = tr && !(g.heads.kind[(n0 + wn * TN) / hp] & 1);
     }
-    // drain: nothing left to issue
-    for (int k = nk - D; k < nk; ++k) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (wave_rows_valid) compute(rd);
-        rd = (rd + 1 == NS) ? 0 : rd + 1;
+    auto main_loop = [&](auto trc) {
+        for (int k = 0; k < nk - D; ++k) {
+            if constexpr (!dbg_nobar) {
+                wait_steady();
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (!dbg_noload) stage_in(k + D, wr);
+            if constexpr (dbg_nolds) {
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+            } else if constexpr (!dbg_nomfma) {
+                if (wave_rows_valid) compute(rd, trc);
+            }
+            rd = (rd + 1 == NS) ? 0 : rd + 1;
+            wr = (wr + 1 == NS) ? 0 : wr + 1;
+        }
+        // drain: nothing left to issue
+        for (int k = nk - D; k < nk; ++k) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (wave_rows_valid) compute(rd, trc);
+            rd = (rd + 1 == NS) ? 0 : rd + 1;
+        }
+    };
+    if constexpr (DBG != 0 || MXA) {
+        main_loop(std::false_type{});
+    } else {
+        if (tr) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
     }
 
     if constexpr (dbg_noepi) {
@@ -762,22 +964,46 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         // dequantise: per-token scale of A x per-output-channel scale of W (kept out of the last K-tile's MFMA schedule)
         __builtin_amdgcn_sched_barrier(0);
         if (wave_rows_valid) {
-            float sw[NI];
+            if (tr) {      // lane = token row, registers = channels 8*(r>>2) + 4*half + (r&3)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) sw[j] = g.w_scale[n0 + wn * TN + j * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                for (int i = 0; i < MI; ++i) {
+                    int row = m0 + wm * TM + i * 32 + l31;
                     row = row < M ? row : M - 1;
-                    const float sa_r = MXA ? 1.0f : g.a_scale[row];
+                    const float sa_r = g.a_scale[row];
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) acc[i][j][r] *= sa_r * sw[j];
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 sw = *reinterpret_cast<const f32x4*>(g.w_scale + n0 + wn * TN + j * 32 + q * 8 + 4 * half);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] *= sa_r * sw[e];
+                        }
                 }
+            } else {
+                float sw[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) sw[j] = g.w_scale[n0 + wn * TN + j * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        row = row < M ? row : M - 1;
+                        const float sa_r = MXA ? 1.0f : g.a_scale[row];
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) acc[i][j][r] *= sa_r * sw[j];
+                    }
+            }
         }
     }
-    if (wave_rows_valid) gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+    if (wave_rows_valid) {
+        if constexpr (NI == 2 || EPI == EPI_F32) {
+            if (tr) gemm_epilogue_t<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+            else gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+        } else {
+            gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+        }
+    }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
@@ -890,7 +1116,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
         for (int j = 0; j < NI; ++j)
             bfr[buf][j] = *reinterpret_cast<const bf16x8*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
     };
-    auto compute = [&](int stage, int next_stage, bool has_next) {
+    auto compute = [&](int stage, int next_stage, bool has_next, auto trc) {
+        constexpr bool TRc = decltype(trc)::value;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bool pre = (ks + 1 < KS) || has_next;
@@ -901,7 +1128,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[j >> 1][i][j & 1] =
-                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[j >> 1][i][j & 1], 0, 0, 0);
+                        TRc ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[j >> 1][i][j & 1], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[j >> 1][i][j & 1], 0, 0, 0);
             if (pre) {
 #pragma unroll
                 for (int r = 0; r < MI + NI; ++r) {
@@ -926,26 +1154,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
     int wr = D;          // stage that receives tile k+D (== stage of tile k-1)
     // steady state.  Top of iteration k: tile k visible, its step-0 fragments already requested.  Waiting for tile k+1
     // here (instead of at the top of iteration k+1) is what lets the last k-step prefetch across the tile boundary.
-    for (int k = 0; k < nk - D; ++k) {
-        wait_vmcnt<(D - 2) * LPT>();
-        __builtin_amdgcn_s_barrier();            // tile k+1 visible; everybody is done with stage wr (tile k-1)
-        if (!dbg_noload) stage_in(k + D, wr);
-        const int nx = (rd + 1 == NS) ? 0 : rd + 1;
-        if (!dbg_nomfma) compute(rd, nx, true);
-        rd = nx;
-        wr = (wr + 1 == NS) ? 0 : wr + 1;
+    // orientation: see gemm_pipe_kernel (uniform over the workgroup)
+    bool tr = !(g.variant & 0x1000);
+    if constexpr (EPI == EPI_HEADS) {
+        const int hp = g.heads.heads * 64;
+        tr = tr && !(g.heads.kind[(n0 + wn * TN) / hp] & 1);
     }
-    // drain: nothing left to issue
-    for (int k = nk - D; k < nk; ++k) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        const int nx = (rd + 1 == NS) ? 0 : rd + 1;
-        compute(rd, nx, k + 1 < nk);
-        rd = nx;
-    }
+    auto main_loop = [&](auto trc) {
+        for (int k = 0; k < nk - D; ++k) {
+            wait_vmcnt<(D - 2) * LPT>();
+            __builtin_amdgcn_s_barrier();            // tile k+1 visible; everybody is done with stage wr (tile k-1)
+            if (!dbg_noload) stage_in(k + D, wr);
+            const int nx = (rd + 1 == NS) ? 0 : rd + 1;
+            if (!dbg_nomfma) compute(rd, nx, true, trc);
+            rd = nx;
+            wr = (wr + 1 == NS) ? 0 : wr + 1;
+        }
+        // drain: nothing left to issue
+        for (int k = nk - D; k < nk; ++k) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            const int nx = (rd + 1 == NS) ? 0 : rd + 1;
+            compute(rd, nx, k + 1 < nk, trc);
+            rd = nx;
+        }
+    };
+    if (tr) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 
 #pragma unroll
-    for (int q = 0; q < NJ; ++q) gemm_epilogue<EPI, MI, 2>(g, acc[q], m0 + wm * TM, n0 + wn * TN + q * 64, half, l31);
+    for (int q = 0; q < NJ; ++q) {
+        if (tr) gemm_epilogue_t<EPI, MI, 2>(g, acc[q], m0 + wm * TM, n0 + wn * TN + q * 64, half, l31);
+        else gemm_epilogue<EPI, MI, 2>(g, acc[q], m0 + wm * TM, n0 + wn * TN + q * 64, half, l31);
+    }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
@@ -954,11 +1195,7 @@ int launch_pipe2(const GemmArgs& a, hipStream_t stream) {
     constexpr int LDS = NS * (BM + BN) * BK * 2;
     static_assert(LDS <= 160 * 1024 && NS >= 3, "pipe2 needs a >= 3-stage ring within 160 KiB");
     auto kern = gemm_pipe2_kernel<BM, BN, BK, WM, WN, NS, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
     SAT_CHECK_ARG(a.K % BK == 0 && a.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
     int tiles = cdiv(a.M, BM) * (a.N / BN);
@@ -973,11 +1210,7 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int LDS = NS * ((BM + BN) * BK * 2 + (FP8 == 3 ? BM * 4 : 0));
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
     auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG, FP8>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     GemmArgs b = a;
     if (FP8) {
         SAT_CHECK_ARG(a.K % 128 == 0 && a.w_scale && (FP8 == 3 ? (const void*)a.a_bscale : (const void*)a.a_scale), SAT_E_UNSUPPORTED,
@@ -997,11 +1230,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
     auto kern = GLDS ? gemm_glds_kernel<BM, BN, WM, WN, EPI> : gemm_kernel<BM, BN, WM, WN, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
+    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
     int tiles = cdiv(a.M, BM) * (a.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, a);
@@ -1009,42 +1238,50 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// Shipped tile configurations (variant ids as in round 1; everything else was an experiment and lives behind
+// -DSAT_GEMM_EXPERIMENTS, see profiles/r01_gemm_variants*.txt for what they measured):
+//    1  128x128, 4 waves, register-staged double buffer   (reference tile; tiny per-generation GEMMs: cross-attention to_kv)
+//    5  128x128, 4 waves, LDS-DMA double buffer            (K < 192: too short for a 3-stage ring)
+//   15  128x128x64, 8 waves, 3-stage LDS-DMA ring          (to_out / FF-out at 1 prompt)
+//   16  128x64x64,  4 waves, 3-stage ring                  (cross-attention projections, M = 1025)
+//   22  256x256x64, 16 waves, 2-stage ring                 (FF-in at 1 prompt)
+//   26  256x256x32, 16 waves, 4-stage ring, cross-tile fragment prefetch, grouped raster   (everything at >= 4 prompts)
+//   30  256x192x64, 12 waves, 2-stage ring                 (to_qkv at 1 prompt)
+// fp8 (e4m3) operands: 15 / 16 / 22 / 30 in three flavours (plain fp8 MFMA, 2x-rate block-scaled MFMA, MXFP8 A operand).
+// Bit 12 of the variant asks for the legacy accumulator orientation (lane = channel) instead of the transposed one.
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
-    if (a.variant >= 100) {   // micro-benchmark ablations (tools/gpu_probe.py), EPI_F32 only
+#ifdef SAT_GEMM_EXPERIMENTS
+    if ((a.variant & 0xfff) >= 100) {   // micro-benchmark ablations (tools/gpu_probe.py), EPI_F32 only
         if constexpr (EPI == EPI_F32) {
-            switch (a.variant) {
+            switch (a.variant & 0xfff) {
                 case 122: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 1>(a, stream);
                 case 222: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 2>(a, stream);
                 case 322: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 3>(a, stream);
                 case 422: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 4>(a, stream);
                 case 522: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 5>(a, stream);
                 case 622: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 6>(a, stream);
-                case 213: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 2>(a, stream);
-                case 413: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 4>(a, stream);
-                case 513: return launch_pipe<256, 256, 32, 2, 4, 3, EPI, 5>(a, stream);
-                case 415: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 4>(a, stream);
-                case 515: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 5>(a, stream);
             }
         }
         sat_set_error("gemm: unknown ablation variant %d", a.variant);
         return SAT_E_INVALID;
     }
+#endif
     int v = a.variant & 0xff;
+    // fill of the last round of 256 CUs x measured in-kernel rate of the tile, relative to the 256x256 tile
+    auto score = [&](int bm, int bn, double rate) {
+        if (a.N % bn) return 0.0;
+        long t = (long)cdiv(a.M, bm) * (a.N / bn);
+        return rate * (double)t / (double)(((t + 255) / 256) * 256);
+    };
     if (a.fp8) {
-        // e4m3 operands: the LDS-DMA tiles only (22 / 30 / 15 / 16); the same fill x rate choice, K counted in bytes
-        auto score = [&](int bm, int bn, double rate) {
-            if (a.N % bn) return 0.0;
-            long t = (long)cdiv(a.M, bm) * (a.N / bn);
-            return rate * (double)t / (double)(((t + 255) / 256) * 256);
-        };
         if (v == 0) {
             const double s256 = score(256, 256, 1.0), s192 = score(256, 192, 0.95), s128 = score(128, 128, 0.7), s64 = score(128, 64, 0.6);
             const double best = s256 > s192 ? (s256 > s128 ? s256 : s128) : (s192 > s128 ? s192 : s128);
             v = (s64 > best) ? 16 : (best == s256) ? 22 : (best == s192) ? 30 : 15;
             if (a.K < 384 && (v == 15 || v == 16)) v = 22;     // the 3-stage tiles need K >= 384 bytes
         }
-        if (a.fp8 == 3) {      // MXFP8 A operand (hardware block scales), fp32 output only: FF-out
+        if (a.fp8 == 3) {      // MXFP8 A operand (hardware block scales), fp32 output only: FF-out, to_out
             if constexpr (EPI == EPI_F32) {
                 switch (v) {
                     case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 3>(a, stream);
@@ -1072,17 +1309,9 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         return SAT_E_INVALID;
     }
     if (v == 0) {
-        // Pick the tile whose (fill of the last round of 256 CUs) x (measured in-kernel rate relative to the 256x256
-        // tile) is best.  Rates from profiles/r01_gemm_variants.txt: 256x256 (16 waves) 1.0, 256x192 (12 waves) 0.95,
-        // 128x128 (8 waves, 3 stages) 0.7, 128x64 0.6.  At B=1 this gives FFN-in 256x256 (432 workgroups, 2 rounds),
-        // QKV 256x192 (216 instead of 162 workgroups), to_out / FFN-out 128x128 (204) and the cross-attention
-        // projections (M = 1025) 128x64 (216); at B >= 4 everything takes the 256x256 tile.
-        auto score = [&](int bm, int bn, double rate) {
-            if (a.N % bn) return 0.0;
-            long t = (long)cdiv(a.M, bm) * (a.N / bn);
-            long rounds = (t + 255) / 256;
-            return rate * (double)t / (double)(rounds * 256);
-        };
+        // At 1 prompt (M = 2050) this gives FF-in 256x256 (432 workgroups, 2 rounds), to_qkv 256x192 (216 instead of 162
+        // workgroups), to_out / FF-out 128x128 (204) and the cross-attention projections (M = 1025) 128x64 (216); from 4 prompts on
+        // everything takes the 256x256 tile.
         if (a.K >= 192) {
             const double s256 = score(256, 256, 1.0), s192 = score(256, 192, 0.95), s128 = score(128, 128, 0.7), s64 = score(128, 64, 0.6);
             const double best = s256 > s192 ? (s256 > s128 ? s256 : s128) : (s192 > s128 ? s192 : s128);
@@ -1090,60 +1319,31 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             else if (s64 > best) v = 16;
             else if (best == s256) v = (cdiv(a.M, 256) > 16) ? 26 : 22;   // 26: grouped raster + 4-stage ring (large M)
             else if (best == s192) v = 30;
-            else v = 15;      // (variants 36-40, smaller wave tiles / 256-B rows, win 5 % in isolation and lose 2 % in the plan)
+            else v = 15;
         } else {
             v = 5;
         }
     }
     switch (v) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
-        case 2: return launch_cfg<256, 128, 4, 2, EPI>(a, stream);
-        case 3: return launch_cfg<256, 256, 2, 4, EPI>(a, stream);
-        case 4: return launch_cfg<128, 256, 1, 4, EPI>(a, stream);
         case 5: return launch_cfg<128, 128, 2, 2, EPI, true>(a, stream);
-        case 6: return launch_cfg<256, 128, 4, 2, EPI, true>(a, stream);
-        case 7: return launch_cfg<256, 256, 2, 4, EPI, true>(a, stream);
-        case 8: return launch_cfg<128, 256, 1, 4, EPI, true>(a, stream);
-        case 9: return launch_pipe<128, 128, 64, 2, 2, 4, EPI>(a, stream);
-        case 10: return launch_pipe<128, 128, 64, 2, 2, 3, EPI>(a, stream);
-        case 11: return launch_pipe<256, 256, 32, 2, 4, 4, EPI>(a, stream);
-        case 12: return launch_pipe<256, 128, 64, 4, 2, 3, EPI>(a, stream);
-        case 13: return launch_pipe<256, 256, 32, 2, 4, 3, EPI>(a, stream);
-        case 14: return launch_pipe<128, 128, 32, 2, 2, 4, EPI>(a, stream);
         case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);
-        case 17: return launch_pipe<64, 128, 64, 2, 2, 3, EPI>(a, stream);
-        case 18: return launch_pipe<128, 128, 64, 2, 2, 2, EPI>(a, stream);
-        case 19: return launch_pipe<64, 128, 64, 2, 2, 4, EPI>(a, stream);
-        case 20: return launch_pipe<128, 128, 64, 4, 2, 2, EPI>(a, stream);
-        case 21: return launch_pipe<256, 256, 32, 4, 4, 3, EPI>(a, stream);
         case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI>(a, stream);
-        case 23: return launch_pipe<256, 128, 64, 8, 2, 3, EPI>(a, stream);
-        case 24: return launch_pipe2<256, 256, 32, 2, 4, 3, EPI>(a, stream);
-        case 25: return launch_pipe2<256, 256, 32, 4, 4, 3, EPI>(a, stream);
         case 26: return launch_pipe2<256, 256, 32, 4, 4, 4, EPI>(a, stream);
-        case 27: return launch_pipe2<128, 128, 64, 4, 2, 3, EPI>(a, stream);
-        case 28: return launch_pipe2<128, 128, 64, 4, 2, 4, EPI>(a, stream);
-        case 29: return launch_pipe2<256, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
-        case 36:
-            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 4, 3, EPI>(a, stream);    // 16 waves of 32x32
-            break;
+#ifdef SAT_GEMM_EXPERIMENTS
+        case 2: return launch_cfg<256, 128, 4, 2, EPI>(a, stream);
+        case 3: return launch_cfg<256, 256, 2, 4, EPI>(a, stream);
+        case 7: return launch_cfg<256, 256, 2, 4, EPI, true>(a, stream);
+        case 10: return launch_pipe<128, 128, 64, 2, 2, 3, EPI>(a, stream);
+        case 12: return launch_pipe<256, 128, 64, 4, 2, 3, EPI>(a, stream);
+        case 13: return launch_pipe<256, 256, 32, 2, 4, 3, EPI>(a, stream);
+        case 24: return launch_pipe2<256, 256, 32, 2, 4, 3, EPI>(a, stream);
+        case 27: return launch_pipe2<128, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 39: return launch_pipe<128, 128, 128, 4, 2, 2, EPI>(a, stream);       // 256-B rows: half the barriers per k
-        // 41-43: two / three co-resident workgroups per CU so that one tile's prologue and epilogue overlap the neighbour's main
-        // loop -- in-plan A/B: FFN-in 105-110 us against 93.7 us for the single 256x256 workgroup (variant 22)
         case 41: return launch_pipe<256, 128, 32, 4, 2, 3, EPI>(a, stream);        // 72 KiB, <= 128 VGPRs: two workgroups per CU
-        case 42: return launch_pipe<128, 256, 32, 2, 4, 3, EPI>(a, stream);
-        case 43: return launch_pipe<256, 128, 32, 4, 2, 2, EPI>(a, stream);        // 48 KiB: three per CU
-        case 40:
-            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 128, 4, 4, 2, EPI>(a, stream);
-            break;
-        case 37:
-            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 2, 4, 3, EPI>(a, stream);    // 8 waves of 64x32
-            break;
-        case 38:
-            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 4, 2, EPI>(a, stream);    // 16 waves, 2 stages: 2 per CU
-            break;
+#endif
         default: break;
     }
     sat_set_error("gemm: unknown variant %d (or not built for this epilogue)", v);
@@ -1157,6 +1357,10 @@ int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, SAT_E_INVALID, "gemm: bad shape %d %d %d", a.M, a.N, a.K);
     SAT_CHECK_ARG(a.K % (a.fp8 ? 128 : 64) == 0, SAT_E_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", a.K, a.fp8 ? 128 : 64);
     SAT_CHECK_ARG(a.N % 128 == 0, SAT_E_UNSUPPORTED, "gemm: N=%d must be a multiple of 128", a.N);
+    // the epilogues move 16 bytes per lane
+    SAT_CHECK_ARG((((uintptr_t)a.bias | (uintptr_t)a.C | (uintptr_t)a.H | (uintptr_t)a.gate | (uintptr_t)a.w_scale) & 15) == 0 && a.ldc % 4 == 0 &&
+                      a.gate_ld % 4 == 0,
+                  SAT_E_INVALID, "gemm: bias / output / gate / scale pointers must be 16-byte aligned and ldc a multiple of 4");
     switch (epi) {
         case EPI_F32:
         case EPI_RESID: return launch_epi<EPI_F32>(a, stream);

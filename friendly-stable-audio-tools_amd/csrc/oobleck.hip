@@ -464,11 +464,7 @@ template <int BM, int BN, int WM, int WN, int NS>
 int launch_conv_cfg(const ConvArgs& a, int B, hipStream_t s) {
     constexpr int LDS = NS * (BM + BN) * 128;
     auto kern = conv_pipe_kernel<BM, BN, WM, WN, NS>;
-    static bool set = false;
-    if (!set) {
-        SAT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        set = true;
-    }
+    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     hipLaunchKernelGGL(kern, dim3(cdiv(a.M, BM) * (a.N / BN), B), dim3(WM * WN * 64), LDS, s, a);
     SAT_LAUNCH_CHECK();
     return 0;

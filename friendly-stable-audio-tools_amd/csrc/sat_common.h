@@ -50,6 +50,10 @@ void sat_set_error(const char* fmt, ...);
         if (rc__ != 0) return rc__; \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: raise it once per (kernel, device), not once
+// per process (a second GPU in the same process would otherwise launch with the 64 KiB default and fail).  Thread-safe.
+int sat_ensure_dynamic_lds(const void* kernel, int bytes);
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

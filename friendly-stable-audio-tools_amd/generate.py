@@ -4,8 +4,9 @@
 Same flags as the reference plus what an offline MI355X box needs:
   --model-config / --ckpt-path   instead of the Hugging Face download of --model-name
   --synthetic-weights SEED       random-init weights of the configured architecture (benchmarks)
-  --text-embeds random           T5/CLAP encoders are out of scope for this build: the "prompt" entry of the
-                                 conditioning is a seed-from-text Gaussian embedding [128, cond_dim]
+  --text-embeds FILE | random    T5/CLAP encoders are out of scope for this build: the "prompt" entry of the conditioning comes
+                                 from a file of precomputed embeddings; "random" (seed-from-text Gaussian [128, cond_dim]) is
+                                 accepted only with --synthetic-weights, never with a real checkpoint
 Launch with ``python -m torch.distributed.run --nproc-per-node N generate.py ...`` for N GPUs: one process per GPU,
 full replica each, prompts ``items[rank::world]``, every rank writes its own files (as the reference does).
 """
@@ -35,7 +36,10 @@ def get_args():
     p.add_argument("--model-config", type=str, default=None, help="model config json; default: the built-in SA-Open-1.0 shape")
     p.add_argument("--ckpt-path", type=str, default=None)
     p.add_argument("--synthetic-weights", type=int, default=None, metavar="SEED")
-    p.add_argument("--text-embeds", choices=["random"], default="random")
+    p.add_argument("--text-embeds", type=str, default=None,
+                   help="source of the text-encoder ('prompt') conditioning, which this build does not compute: a .pt / .safetensors file "
+                        "mapping each prompt string (or condition path) to a precomputed [tokens, cond_dim] embedding, or 'random' = "
+                        "seed-from-text Gaussian embeddings (benchmarks; only with --synthetic-weights)")
     p.add_argument("--sampler-type", type=str, default="dpmpp-3m-sde")
     p.add_argument("--sample-steps", type=int, default=100)
     p.add_argument("--cfg-scale", type=float, default=7.0)
@@ -70,6 +74,37 @@ def text_embedding(prompt: str, dim: int, tokens: int = 128):
     return torch.randn(tokens, dim, generator=g)
 
 
+def text_embed_source(args, cond_dim):
+    """Returns ``fn(path, cond) -> [tokens, cond_dim]``.  Random embeddings carry no meaning: they are allowed only next to
+    random weights; with a real checkpoint the embeddings must come from a file (computed by the T5 / CLAP encoder elsewhere)."""
+    src = args.text_embeds
+    if src is None:
+        src = "random" if args.synthetic_weights is not None else None
+    if src == "random":
+        if args.synthetic_weights is None:
+            raise SystemExit("--text-embeds random produces audio unrelated to the prompt text: it is only accepted together with "
+                             "--synthetic-weights.  With real weights pass --text-embeds FILE (precomputed text-encoder outputs).")
+        return lambda path, cond: text_embedding(str(cond["prompt"]), cond_dim)
+    if src is None:
+        raise SystemExit("this build has no text encoder (T5 / CLAP need a download): pass --text-embeds FILE with the precomputed "
+                         "embedding of every prompt, or --synthetic-weights SEED for a random-weights benchmark run")
+    if src.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        table = load_file(src)
+    else:
+        table = torch.load(src, map_location="cpu", weights_only=True)
+
+    def lookup(path, cond):
+        for key in (str(cond["prompt"]), path):
+            if key in table:
+                emb = table[key].float()
+                if emb.ndim != 2 or emb.shape[1] != cond_dim:
+                    raise SystemExit(f"--text-embeds: entry '{key}' has shape {tuple(emb.shape)}, expected [tokens, {cond_dim}]")
+                return emb
+        raise SystemExit(f"--text-embeds: no entry for prompt '{cond['prompt']}' (nor for '{path}') in {src}")
+    return lookup
+
+
 def main():
     args = get_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,6 +133,9 @@ def main():
     if args.gemm_dtype != "bf16":
         model.model.model.set_gemm_dtype(args.gemm_dtype)
     cond_dim = model_config["model"]["conditioning"]["cond_dim"]
+    # ids the diffusion model consumes but the conditioner cannot produce here (text / audio encoders): fail before any work is done
+    needs_text = any(k not in model.conditioner.conditioners for k in model.cross_attn_cond_ids)
+    embed_of = text_embed_source(args, cond_dim) if needs_text else None
 
     conds = flatten_conditions(yaml.safe_load(open(args.cond_yaml_path)))
     paths, items = [], []
@@ -115,13 +153,22 @@ def main():
         p_i, c_i = paths[i * batch:(i + 1) * batch], items[i * batch:(i + 1) * batch]
         cond = model.conditioner(c_i)
         if "prompt" not in cond:
-            emb = torch.stack([text_embedding(str(c["prompt"]), cond_dim) for c in c_i]).to(device)
-            cond["prompt"] = (emb, torch.ones(len(c_i), emb.shape[1], device=device))
+            embs = [embed_of(p, c) for p, c in zip(p_i, c_i)]
+            width = max(e.shape[0] for e in embs)
+            emb = torch.zeros(len(embs), width, cond_dim)
+            mask = torch.zeros(len(embs), width)
+            for n, e in enumerate(embs):                                  # right-pad like the tokenizer (conditioners.py:322-331)
+                emb[n, : e.shape[0]] = e
+                mask[n, : e.shape[0]] = 1
+            cond["prompt"] = (emb.to(device), mask.to(device))
+        # --seed (build extension; the reference always draws a fresh seed, generate.py:129-141): every call of every rank gets its own
+        # stream, so copies of one prompt on different ranks / batches never repeat the noise
+        call_seed = -1 if args.seed < 0 else args.seed + rank + world * i
         order = model.cross_attn_cond_ids + [k for k in cond if k not in model.cross_attn_cond_ids]
         cond = {k: cond[k] for k in order if k in cond}
         audio = generate_diffusion_cond(model, steps=args.sample_steps, cfg_scale=args.cfg_scale, conditioning_tensors=cond,
                                         sample_size=sample_size, sigma_min=0.3, sigma_max=500, sampler_type=args.sampler_type,
-                                        device=str(device), seed=args.seed)
+                                        device=str(device), seed=call_seed)
         for n in range(audio.shape[0]):
             pcm = float_to_int16_audio(audio[n])
             if args.clip_length:

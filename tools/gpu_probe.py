@@ -71,7 +71,7 @@ def gemm_bench():
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         c = torch.zeros(m, n, device=dev)
-        for v in (15, 37, 39, 40, 22):
+        for v in (15, 16, 22, 26, 30):
             if v % 100 in (3, 4, 7, 8, 11, 13, 21, 22, 24, 25, 26) and n % 256:
                 continue
             if v == 30 and n % 192:
@@ -80,6 +80,58 @@ def gemm_bench():
             ms = timeit(f)
             print(f"gemm {name:14s} v{v} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
         del a, w, c
+
+
+def epi_ab():
+    """A/B of the accumulator orientation (transposed: lane = token, 16-byte stores | legacy: lane = channel, bit 12 of the variant)
+    on the shipped tiles at the shapes the plan launches, all three epilogues, interleaved rounds, median of per-round means."""
+    import statistics
+    LEG = 0x1000
+    rounds = 5
+
+    def ab(label, make, flops):
+        fs = {"T": make(0), "L": make(LEG)}
+        res = {k: [] for k in fs}
+        for _ in range(rounds):
+            for k, f in fs.items():
+                res[k].append(timeit(f, iters=10, warm=2))
+        t, l = statistics.median(res["T"]), statistics.median(res["L"])
+        print(f"{label:44s} transposed {t*1e3:7.1f} us {flops/t/1e9:7.1f} TF | legacy {l*1e3:7.1f} us {flops/l/1e9:7.1f} TF | x{l/t:.3f}", flush=True)
+
+    # fp32 output + residual accumulate (to_out, FF-out, cross out)
+    for name, m, n, k, v in [("to_out B1 v15", 2050, 1536, 1536, 15), ("ff_out B1 v15", 2050, 1536, 6144, 15), ("cross B1 v16", 1025, 1536, 1536, 16),
+                             ("to_out B8 v26", 16400, 1536, 1536, 26), ("ff_out B8 v26", 16400, 1536, 6144, 26), ("ff_out B1 v22", 2050, 1536, 6144, 22)]:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        c = torch.zeros(m, n, device=dev)
+        bias = torch.randn(n, device=dev)
+        ab(f"f32+resid {name} {m}x{n}x{k}", lambda flag: (lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(c), m, n, k, 1,
+                                                                                                  v | flag, _hip.stream()))), 2.0 * m * n * k)
+    # SwiGLU (FF-in)
+    for name, m, v in [("ff_in B1 v22", 2050, 22), ("ff_in B1 v26", 2050, 26), ("ff_in B8 v26", 16400, 26), ("ff_in B8 v22", 16400, 22)]:
+        n, k = 12288, 1536
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = torch.randn(n, k, device=dev) * 0.05
+        bias = torch.randn(n, device=dev) * 0.1
+        wp = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
+        bp = torch.empty((n,), dtype=torch.float32, device=dev)
+        out = torch.empty((m, n // 2), dtype=torch.bfloat16, device=dev)
+        # pack once, then time the GEMM alone through the same entry point (the repack is two tiny launches: subtract by timing it)
+        ab(f"swiglu {name} {m}x{n}x{k} (+pack)", lambda flag: (lambda: _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp),
+                                                                                                    _hip.ptr(out), m, n, k, v | flag, _hip.stream()))), 2.0 * m * n * k)
+    # heads + RoPE (to_qkv)
+    for name, b, v in [("qkv B1 v30", 2, 30), ("qkv B1 v22", 2, 22), ("qkv B8 v26", 16, 26)]:
+        s_len, s_pad, d = 1025, 1152, 1536
+        a = torch.randn(b * s_len, d, device=dev).to(torch.bfloat16)
+        w = (torch.randn(3 * d, d, device=dev) * 0.05).to(torch.bfloat16)
+        inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+        q = torch.empty((b, 24, s_pad, 64), dtype=torch.bfloat16, device=dev)
+        kk = torch.empty_like(q)
+        vt = torch.empty((b, 24, 64, s_pad), dtype=torch.bfloat16, device=dev)
+        scratch = torch.empty((2 * s_len * 16,), dtype=torch.float32, device=dev)
+        ab(f"heads {name} {b*s_len}x{3*d}x{d} (+memsets)", lambda flag: (lambda: _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(inv_freq), _hip.ptr(q), _hip.ptr(kk),
+                                                                                                          _hip.ptr(vt), _hip.ptr(scratch), b, s_len, s_pad, d, v | flag,
+                                                                                                          _hip.stream()))), 2.0 * b * s_len * 3 * d * d)
 
 
 def gemm_pmc():
@@ -155,6 +207,8 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     if "gemm" in which:
         section("gemm", gemm_bench)
+    if "epi" in which:
+        section("epilogue A/B", epi_ab)
     if "gemm_pmc" in which:
         section("gemm_pmc", gemm_pmc)
     if "attn" in which:
