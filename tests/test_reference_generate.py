@@ -111,8 +111,11 @@ def gpu_model(dev):
     return _model(dev)
 
 
-# measured on MI355X (bf16 GEMM operands against the reference's fp32 trajectories), gates = ~2x
-_GATES = {"plain": (2.5e-2, 3e-2), "a2a": (2.5e-2, 3e-2), "inpaint": (2.5e-2, 3e-2)}
+# (latents, audio) gates = ~2x the error measured on MI355X (bf16 GEMM operands against the reference's fp32 trajectories:
+# latents 1.4e-3 / 8.0e-4 / 1.4e-3, audio 7.8e-3 / 8.0e-3 / 7.3e-3 -- the audio figure is the codec's 35 bf16-stored layers)
+_GATES = {"plain": (3e-3, 1.6e-2), "a2a": (2e-3, 1.6e-2), "inpaint": (3e-3, 1.6e-2)}
+# sample_k: inpainting re-injects the init data every step, which keeps the error at 3e-5..7e-5; free-running samplers ~1e-3
+_GATES_K = {"heun_inpaint": 2e-4, "lms_inpaint": 2e-4, "fast_inpaint": 1e-4, "dpm2_variation": 2e-3, "ancestral_plain": 2.5e-3}
 
 
 @pytest.mark.gpu
@@ -167,5 +170,5 @@ def test_product_sample_k_matches_reference(dev, gpu_model, name):
                    callback=lambda a: seen.append(int(a["i"])), noise_sampler=lambda s, sn: next(it).to(dev),
                    inpaint_noise=lambda i: like[i].to(dev), **kw, **ci)
     assert seen == gold[f"sample_k.{name}.callback_i"].tolist(), "callback indices differ from the reference's"
-    e = assert_close(f"sample_k {name}: product vs reference", got, gold[f"sample_k.{name}.out"], 3e-2)
+    e = assert_close(f"sample_k {name}: product vs reference", got, gold[f"sample_k.{name}.out"], _GATES_K[name])
     print(f"\n[reference sample_k / {name}] rel-L2 {e:.2e}")

@@ -14,6 +14,8 @@ import torch
 from stable_audio_tools import _hip
 
 dev = torch.device("cuda:0")
+if os.environ.get("SAT_HIP_EXP"):       # developer build with the experimental tiles / ablation modes (make -C csrc exp)
+    _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libsat_hip_exp.so")
 lib = _hip.lib()
 
 
@@ -134,6 +136,58 @@ def epi_ab():
                                                                                                           _hip.stream()))), 2.0 * b * s_len * 3 * d * d)
 
 
+def ablate():
+    """Where does the time of each shipped GEMM go?  Ablation modes of the experiments build (SAT_HIP_EXP=1): 2 = no LDS-DMA in the
+    loop, 4 = + no barrier, 5 = + no ds_read (MFMA on register fragments), 6 = + no epilogue, 7 = 5 with the epilogue arithmetic but
+    no stores, 8 = production loop without stores.  Interleaved, median of 5 rounds."""
+    import statistics
+    NOPACK = 0x4000
+
+    def run(label, fns, flops):
+        res = {k: [] for k in fns}
+        for _ in range(5):
+            for k, f in fns.items():
+                res[k].append(timeit(f, iters=10, warm=2))
+        print(f"{label:34s} " + "  ".join(f"{k}:{statistics.median(v)*1e3:6.1f}" for k, v in res.items()), flush=True)
+
+    for name, m, n, k, tile in [("ff_out B1", 2050, 1536, 6144, 15), ("to_out B1", 2050, 1536, 1536, 15), ("cross B1", 1025, 1536, 1536, 16),
+                                ("ff_out B1 tile22", 2050, 1536, 6144, 22), ("ff_out B8 tile22", 16400, 1536, 6144, 22)]:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        c = torch.zeros(m, n, device=dev)
+        bias = torch.randn(n, device=dev)
+        mk = lambda v: (lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(c), m, n, k, 1, v, _hip.stream())))
+        run(f"f32+resid {name} (us)", {"prod": mk(tile), "noload": mk(200 + tile), "nobar": mk(400 + tile), "nolds": mk(500 + tile), "noepi": mk(600 + tile)},
+            2.0 * m * n * k)
+    for name, m in [("ff_in B1", 2050), ("ff_in B8", 16400)]:
+        n, k = 12288, 1536
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = torch.randn(n, k, device=dev) * 0.05
+        bias = torch.randn(n, device=dev) * 0.1
+        wp = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
+        bp = torch.empty((n,), dtype=torch.float32, device=dev)
+        out = torch.empty((m, n // 2), dtype=torch.bfloat16, device=dev)
+        mk = lambda v: (lambda: _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m, n, k,
+                                                                    v, _hip.stream())))
+        mk(22)()        # pack once
+        run(f"swiglu {name} tile22 (us)", {"prod": mk(22 | NOPACK), "legacy": mk(22 | NOPACK | 0x1000), "nostore": mk(822 | NOPACK), "noload": mk(222 | NOPACK),
+                                           "nobar": mk(422 | NOPACK), "nolds": mk(522 | NOPACK), "nolds+math": mk(722 | NOPACK), "noepi": mk(622 | NOPACK),
+                                           "tile26": mk(26 | NOPACK)}, 2.0 * m * n * k)
+    for name, b in [("qkv B1", 2), ("qkv B8", 16)]:
+        s_len, s_pad, d = 1025, 1152, 1536
+        a = torch.randn(b * s_len, d, device=dev).to(torch.bfloat16)
+        w = (torch.randn(3 * d, d, device=dev) * 0.05).to(torch.bfloat16)
+        inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+        q = torch.empty((b, 24, s_pad, 64), dtype=torch.bfloat16, device=dev)
+        kk = torch.empty_like(q)
+        vt = torch.empty((b, 24, 64, s_pad), dtype=torch.bfloat16, device=dev)
+        scratch = torch.empty((2 * s_len * 16,), dtype=torch.float32, device=dev)
+        mk = lambda v: (lambda: _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(inv_freq), _hip.ptr(q), _hip.ptr(kk), _hip.ptr(vt),
+                                                                 _hip.ptr(scratch), b, s_len, s_pad, d, v, _hip.stream())))
+        run(f"heads {name} tile30 (+memsets, us)", {"prod": mk(30), "noload": mk(230), "nobar": mk(430), "nolds": mk(530), "noepi": mk(630), "tile22": mk(22),
+                                                    "tile26": mk(26)}, 0)
+
+
 def gemm_pmc():
     """few launches of selected variants for rocprofv3 --pmc runs"""
     for name, m, n, k, vs in [("ff_inB8", 16400, 12288, 1536, (7, 22, 26, 13)), ("ff_in", 2050, 12288, 1536, (22, 26))]:
@@ -209,6 +263,8 @@ if __name__ == "__main__":
         section("gemm", gemm_bench)
     if "epi" in which:
         section("epilogue A/B", epi_ab)
+    if "ablate" in which:
+        section("ablation", ablate)
     if "gemm_pmc" in which:
         section("gemm_pmc", gemm_pmc)
     if "attn" in which:
