@@ -85,6 +85,8 @@ struct sat_dit_plan {
     float* ge = nullptr;            // [bf, D] projected global embedding
     bf16_t* kc = nullptr;           // [depth][bf, kvh, lcpad, 64]
     bf16_t* vct = nullptr;          // [depth][bf, kvh, 64, lcpad]
+    float* kc32 = nullptr;          // fp32 verification mode: [depth][bf, kvh, lc, 64]
+    float* vc32 = nullptr;
     // optional HIP-event timing of the FFN-in (SwiGLU) GEMM of one layer per forward (sat_dit_profile)
     bool prof_on = false;
     int prof_n = 0;
@@ -179,7 +181,24 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
         SAT_TRY(copy_f32(p, ar, pf + "pre_norm.beta", D, &L.pre_b, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.gamma", D, &L.ff_g, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.beta", D, &L.ff_b, s));
-        const bool f8 = c.fp8_gemm != 0;
+        const bool f8 = c.fp8_gemm == 1;
+        if (c.fp8_gemm == 2) {      // fp32 verification mode: the reference's own fp32 weights, no re-packing (f32_ref.hip)
+            auto w32 = [&](const std::string& name, int64_t numel, bf16_t** dst) { return copy_f32(p, ar, pf + name, numel, (float**)dst, s); };
+            SAT_TRY(w32("self_attn.to_qkv.weight", (int64_t)3 * D * D, &L.w_qkv));
+            SAT_TRY(w32("self_attn.to_out.weight", (int64_t)D * D, &L.w_o));
+            if (Dct > 0) {
+                SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.gamma", D, &L.cross_g, s));
+                SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.beta", D, &L.cross_b, s));
+                SAT_TRY(w32("cross_attn.to_q.weight", (int64_t)D * D, &L.w_cq));
+                SAT_TRY(w32("cross_attn.to_kv.weight", (int64_t)2 * Dc * Dc, &L.w_ckv));
+                SAT_TRY(w32("cross_attn.to_out.weight", (int64_t)D * D, &L.w_co));
+            }
+            SAT_TRY(w32("ff.ff.0.proj.weight", (int64_t)2 * inner * D, &L.w_ff1));
+            SAT_TRY(copy_f32(p, ar, pf + "ff.ff.0.proj.bias", 2 * inner, &L.b_ff1, s));
+            SAT_TRY(w32("ff.ff.2.weight", (int64_t)D * inner, &L.w_ff2));
+            SAT_TRY(copy_f32(p, ar, pf + "ff.ff.2.bias", D, &L.b_ff2, s));
+            continue;
+        }
         if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, &L.s_qkv, s));
         else SAT_TRY(pack_w(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, s));
         if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, &L.s_o, s));
@@ -216,6 +235,7 @@ struct Workspace {
     unsigned char* Hs;      // fp8_gemm: E8M0 block scales of the MXFP8 hidden activation in Hh, [M][inner / 32]
     unsigned char* AOs;     // fp8_gemm: E8M0 block scales of the MXFP8 attention output in AO, [M][D / 32]
     float *gsum, *ssg;      // adaLN: silu(global + timestep embed) [bf, D]; per-layer modulation [bf, depth, 6, D]
+    float* f32_wide = nullptr;   // fp32 verification mode: [M, max(3D, 2 inner)] GEMM output before the head split / SwiGLU
     size_t qkv_bytes;
     size_t total;
 };
@@ -234,6 +254,24 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
         return ptr;
     };
     w.X = (float*)take(M * D * 4);
+    if (c.fp8_gemm == 2) {      // fp32 verification mode: every intermediate is fp32, q / k / v un-padded [bf, H, S, 64]
+        w.A = (bf16_t*)take(M * D * 4);
+        w.AO = (bf16_t*)take(M * D * 4);
+        w.qkv_bytes = M * D * 4;
+        w.Q = (bf16_t*)take(w.qkv_bytes);
+        w.K = (bf16_t*)take(w.qkv_bytes);
+        w.Vt = (bf16_t*)take(w.qkv_bytes);
+        w.Hh = (bf16_t*)take(M * (size_t)p->inner * 4);
+        w.f32_wide = (float*)take(M * (size_t)(2 * p->inner > 3 * D ? 2 * p->inner : 3 * D) * 4);     // [M, 3D] qkv / [M, 2 inner] FF-in
+        w.ff = (float*)take((size_t)bf * 256 * 4);
+        w.h1 = (float*)take((size_t)bf * D * 4);
+        w.mo = (float*)take((size_t)bf * c.io_channels * T * 4);
+        w.As = nullptr; w.Hs = nullptr; w.AOs = nullptr;
+        w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
+        w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
+        w.total = off;
+        return w;
+    }
     w.A = (bf16_t*)take(M * D * 2);
     w.AO = (bf16_t*)take(M * D * 2);
     w.qkv_bytes = (size_t)bf * H * Spad * 64 * 2;
@@ -245,9 +283,9 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     w.ff = (float*)take((size_t)bf * 256 * 4);
     w.h1 = (float*)take((size_t)bf * D * 4);
     w.mo = (float*)take((size_t)bf * c.io_channels * T * 4);
-    w.As = c.fp8_gemm ? (float*)take(M * 4) : nullptr;
-    w.Hs = c.fp8_gemm ? (unsigned char*)take(M * (size_t)(p->inner / 32)) : nullptr;
-    w.AOs = c.fp8_gemm ? (unsigned char*)take(M * (size_t)(D / 32)) : nullptr;
+    w.As = c.fp8_gemm == 1 ? (float*)take(M * 4) : nullptr;
+    w.Hs = c.fp8_gemm == 1 ? (unsigned char*)take(M * (size_t)(p->inner / 32)) : nullptr;
+    w.AOs = c.fp8_gemm == 1 ? (unsigned char*)take(M * (size_t)(D / 32)) : nullptr;
     w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
     w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
     w.total = off;
@@ -267,12 +305,12 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     Workspace w = carve(p, bf, T, (char*)ws);
     SAT_CHECK_ARG(ws_bytes >= w.total, SAT_E_WORKSPACE, "dit forward: workspace %zu < required %zu", ws_bytes, w.total);
     const int D = c.embed_dim, H = c.num_heads, C = c.io_channels;
-    const bool adaln = c.adaln != 0, f8 = c.fp8_gemm != 0;
+    const bool adaln = c.adaln != 0, f8 = c.fp8_gemm == 1, f32 = c.fp8_gemm == 2;
     const int S = T + (adaln ? 0 : 1), M = bf * S, Spad = (int)round_up(S + 3, 128);
     const int ssg_ld = c.depth * 6 * D;      // per-sequence stride of the adaLN modulation vectors
 
     // pads of q/k/vt must be finite (zero): one memset per forward
-    SAT_HIP(hipMemsetAsync(w.Q, 0, 3 * (size_t)round_up((int64_t)w.qkv_bytes, 256), s));
+    if (!f32) SAT_HIP(hipMemsetAsync(w.Q, 0, 3 * (size_t)round_up((int64_t)w.qkv_bytes, 256), s));
 
     // timestep embedding (dit.py:176) + global embed (dit.py:179-182) -> prepend token rows X[b,0,:]
     SAT_TRY(glue_fourier(t_dev, t_const, p->ts_w, w.ff, bf, 128, s));
@@ -290,7 +328,34 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     SAT_TRY(glue_input_proj(x, p->win_eff, w.X, bf, xB, C, T, S, D, xscale, s));
 
     GemmArgs g{};
-    for (int l = 0; l < c.depth; ++l) {
+    for (int l = 0; l < c.depth && f32; ++l) {
+        // fp32 verification mode: the same block (transformer.py:656-702) on f32_ref.hip, fp32 everywhere
+        const LayerW& L = p->layers[l];
+        const float* mod = adaln ? w.ssg + (size_t)l * 6 * D : nullptr;
+        float *A32 = (float*)w.A, *AO32 = (float*)w.AO, *Q32 = (float*)w.Q, *K32 = (float*)w.K, *V32 = (float*)w.Vt, *H32 = (float*)w.Hh;
+        SAT_TRY(sat_launch_layernorm_f32(w.X, L.pre_g, L.pre_b, A32, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
+        SAT_TRY(sat_launch_gemm_f32(A32, (const float*)L.w_qkv, nullptr, w.f32_wide, M, 3 * D, D, 3 * D, 0, nullptr, 1, 0, s));
+        SAT_TRY(sat_launch_split_heads_f32(w.f32_wide, Q32, K32, V32, M, S, 3, H, 3, p->rope_cos, p->rope_sin, s));
+        SAT_TRY(sat_launch_attention_f32(Q32, K32, V32, AO32, bf, H, H, S, S, s));
+        SAT_TRY(sat_launch_gemm_f32(AO32, (const float*)L.w_o, nullptr, w.X, M, D, D, D, 1, adaln ? mod + 2 * D : nullptr, S, ssg_ld, s));
+        if (cross) {
+            const int bc = (p->ctx_null_from >= 0 && p->ctx_null_from < bf) ? p->ctx_null_from : bf;
+            const int Mc = bc * S;
+            if (bc > 0) {
+                SAT_TRY(sat_launch_layernorm_f32(w.X, L.cross_g, L.cross_b, A32, Mc, D, nullptr, nullptr, 1, 0, s));
+                SAT_TRY(sat_launch_gemm_f32(A32, (const float*)L.w_cq, nullptr, w.f32_wide, Mc, D, D, D, 0, nullptr, 1, 0, s));
+                SAT_TRY(sat_launch_split_heads_f32(w.f32_wide, Q32, nullptr, nullptr, Mc, S, 1, H, 0, nullptr, nullptr, s));
+                const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lc * 64;
+                SAT_TRY(sat_launch_attention_f32(Q32, p->kc32 + l * per_layer, p->vc32 + l * per_layer, AO32, bc, H, p->kvh_cross, S, p->ctx_lc, s));
+                SAT_TRY(sat_launch_gemm_f32(AO32, (const float*)L.w_co, nullptr, w.X, Mc, D, D, D, 1, nullptr, 1, 0, s));
+            }
+        }
+        SAT_TRY(sat_launch_layernorm_f32(w.X, L.ff_g, L.ff_b, A32, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S, ssg_ld, s));
+        SAT_TRY(sat_launch_gemm_f32(A32, (const float*)L.w_ff1, L.b_ff1, w.f32_wide, M, 2 * p->inner, D, 2 * p->inner, 0, nullptr, 1, 0, s));
+        SAT_TRY(sat_launch_swiglu_f32(w.f32_wide, H32, M, p->inner, s));
+        SAT_TRY(sat_launch_gemm_f32(H32, (const float*)L.w_ff2, L.b_ff2, w.X, M, D, p->inner, D, 1, adaln ? mod + 5 * D : nullptr, S, ssg_ld, s));
+    }
+    for (int l = 0; l < c.depth && !f32; ++l) {
         const LayerW& L = p->layers[l];
         // ---- self-attention branch (transformer.py:692)
         const float* mod = adaln ? w.ssg + (size_t)l * 6 * D : nullptr;     // + {0..5} * D: scale1p/shift/gate self, then ff
@@ -390,7 +455,8 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
                       cfg->num_heads, kvh);
     }
     SAT_CHECK_ARG(cfg->global_cond_dim % 4 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: global_cond_dim must be a multiple of 4");
-    SAT_CHECK_ARG(!cfg->fp8_gemm || cfg->embed_dim % 256 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: fp8_gemm needs embed_dim %% 256 == 0");
+    SAT_CHECK_ARG(cfg->fp8_gemm >= 0 && cfg->fp8_gemm <= 2, SAT_E_INVALID, "dit_plan_create: fp8_gemm must be 0 (bf16), 1 (e4m3) or 2 (fp32 verification)");
+    SAT_CHECK_ARG(cfg->fp8_gemm != 1 || cfg->embed_dim % 256 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: fp8_gemm needs embed_dim %% 256 == 0");
     sat_dit_plan* p = new (std::nothrow) sat_dit_plan();
     SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_plan_create: out of host memory");
     p->cfg = *cfg;
@@ -422,7 +488,7 @@ extern "C" int sat_dit_plan_finalize(sat_dit_plan* p, sat_stream_t stream) {
     SAT_CHECK_ARG(it->second.second % (2 * (int64_t)D) == 0, SAT_E_INVALID, "dit plan: FF weight size not divisible by 2*embed_dim");
     p->inner = (int)(it->second.second / (2 * (int64_t)D));
     SAT_CHECK_ARG(p->inner % 64 == 0, SAT_E_UNSUPPORTED, "dit plan: FF inner dim %d must be a multiple of 64", p->inner);
-    SAT_CHECK_ARG(!p->cfg.fp8_gemm || p->inner % 128 == 0, SAT_E_UNSUPPORTED, "dit plan: fp8_gemm needs an FF inner dim that is a multiple of 128");
+    SAT_CHECK_ARG(p->cfg.fp8_gemm != 1 || p->inner % 128 == 0, SAT_E_UNSUPPORTED, "dit plan: fp8_gemm needs an FF inner dim that is a multiple of 128");
     if (p->arena) {
         (void)hipFree(p->arena);
         p->arena = nullptr;
@@ -471,9 +537,12 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
     const size_t o_gh = take((size_t)bf * D * 4);
     const size_t o_ch = cross ? take((size_t)R * Dc * 4) : 0;
     const size_t o_ce = cross ? take((size_t)R * Dc * 2) : 0;
-    const size_t kv_elems = cross ? (size_t)c.depth * bf * p->kvh_cross * lcpad * 64 : 0;
-    const size_t o_kc = take(kv_elems * 2);
-    const size_t o_vc = take(kv_elems * 2);
+    const bool f32 = c.fp8_gemm == 2;
+    const size_t kv_elems = cross ? (size_t)c.depth * bf * p->kvh_cross * (f32 ? lc : lcpad) * 64 : 0;
+    const size_t o_kc = take(kv_elems * (f32 ? 4 : 2));
+    const size_t o_vc = take(kv_elems * (f32 ? 4 : 2));
+    const size_t o_kv32 = (cross && f32) ? take((size_t)R * 2 * Dc * 4) : 0;
+    const size_t o_ce32 = (cross && f32) ? take((size_t)R * Dc * 4) : 0;
     if (off > p->ctx_cap) {
         SAT_HIP(hipStreamSynchronize(s));
         if (p->ctx_buf) SAT_HIP(hipFree(p->ctx_buf));
@@ -491,7 +560,21 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
         SAT_TRY(glue_small_linear(global_cond, Dg, p->ge0_w, nullptr, nullptr, 0, gh, D, bf, D, Dg, 1, false, s));
         SAT_TRY(glue_small_linear(gh, D, p->ge2_w, nullptr, nullptr, 0, p->ge, D, bf, D, D, 0, false, s));
     }
-    if (cross) {   // dit.py:150 then per-layer to_kv (transformer.py:420-427)
+    if (cross && f32) {   // fp32 verification mode: fp32 context embedding, fp32 K / V [bf, kvh, lc, 64] per layer
+        float* ch = (float*)(p->ctx_buf + o_ch);
+        float* ce32 = (float*)(p->ctx_buf + o_ce32);
+        float* kv32 = (float*)(p->ctx_buf + o_kv32);
+        p->kc32 = (float*)(p->ctx_buf + o_kc);
+        p->vc32 = (float*)(p->ctx_buf + o_vc);
+        SAT_TRY(glue_small_linear(cond, Dct, p->ce0_w, nullptr, nullptr, 0, ch, Dc, R, Dc, Dct, 1, false, s));
+        SAT_TRY(glue_small_linear(ch, Dc, p->ce2_w, nullptr, nullptr, 0, ce32, Dc, R, Dc, Dc, 0, false, s));
+        const size_t per_layer = (size_t)bf * p->kvh_cross * lc * 64;
+        for (int l = 0; l < c.depth; ++l) {
+            SAT_TRY(sat_launch_gemm_f32(ce32, (const float*)p->layers[l].w_ckv, nullptr, kv32, R, 2 * Dc, Dc, 2 * Dc, 0, nullptr, 1, 0, s));
+            SAT_TRY(sat_launch_split_heads_f32(kv32, p->kc32 + l * per_layer, p->vc32 + l * per_layer, nullptr, R, lc, 2, p->kvh_cross, 0, nullptr,
+                                               nullptr, s));
+        }
+    } else if (cross) {   // dit.py:150 then per-layer to_kv (transformer.py:420-427)
         float* ch = (float*)(p->ctx_buf + o_ch);
         bf16_t* ce = (bf16_t*)(p->ctx_buf + o_ce);
         SAT_TRY(glue_small_linear(cond, Dct, p->ce0_w, nullptr, nullptr, 0, ch, Dc, R, Dc, Dct, 1, false, s));

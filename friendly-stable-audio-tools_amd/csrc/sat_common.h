@@ -180,6 +180,16 @@ int sat_launch_quant_mx_rows(const float* x, void* out8, void* scales_e8m0, int 
 // out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
                          int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales = nullptr);
+// fp32 verification path (f32_ref.hip)
+int sat_launch_gemm_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int ldc, int accumulate,
+                        const float* gate, int gate_rows, int gate_ld, hipStream_t s);
+int sat_launch_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int m, int d, const float* sc,
+                             const float* sh, int rps, int ld, hipStream_t s);
+int sat_launch_split_heads_f32(const float* src, float* d0, float* d1, float* d2, int M, int S, int parts, int H, int rope_mask,
+                               const float* rope_cos, const float* rope_sin, hipStream_t s);
+int sat_launch_swiglu_f32(const float* hg, float* h, int64_t M, int inner, hipStream_t s);
+int sat_launch_attention_f32(const float* q, const float* k, const float* v, float* out, int b, int h, int kvh, int sq, int sk,
+                             hipStream_t s);
 int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
 int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swiglu_interleave, hipStream_t s);
 int sat_launch_pack_bias(const float* b, float* out, int n, int swiglu_interleave, hipStream_t s);

@@ -71,10 +71,11 @@ class DiffusionTransformer(nn.Module):
         self.gemm_dtype = "bf16"
 
     def set_gemm_dtype(self, dtype: str):
-        """Build extension (BASELINE config 5): "bf16" (default) or "fp8" -- OCP e4m3 operands with per-token / per-output-
-        channel scales for the GEMMs fed by a LayerNorm (to_qkv, cross to_q, FF-in).  Rebuilds the plan on next use."""
-        if dtype not in ("bf16", "fp8"):
-            raise ValueError("gemm_dtype must be 'bf16' or 'fp8'")
+        """Build extension: "bf16" (default), "fp8" (BASELINE config 5: OCP e4m3 / MXFP8 operands for the block GEMMs) or "fp32x" --
+        the fp32 verification mode (exact fp32 MFMA, fp32 q / k / v / P; ~20x slower): the same plan and data flow with no operand
+        rounding, which meets the 1e-3 of north_star against the reference's own outputs.  Rebuilds the plan on next use."""
+        if dtype not in ("bf16", "fp8", "fp32x"):
+            raise ValueError("gemm_dtype must be 'bf16', 'fp8' or 'fp32x'")
         if dtype != self.gemm_dtype:
             self.gemm_dtype = dtype
             self._plan_version = None
@@ -101,7 +102,7 @@ class DiffusionTransformer(nn.Module):
             self._plan = None
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
                              self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
-                             1 if self.global_cond_type == "adaLN" else 0, 1 if self.gemm_dtype == "fp8" else 0)
+                             1 if self.global_cond_type == "adaLN" else 0, {"bf16": 0, "fp8": 1, "fp32x": 2}[self.gemm_dtype])
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
         keep = []

@@ -73,7 +73,10 @@ typedef struct sat_dit_cfg {
                                   (activations) and per output channel (weights), fp32 accumulation; FF-out (transformer.py:270)
                                   takes the SwiGLU output as MXFP8 (e4m3 + one E8M0 scale per 32 hidden channels, written by the
                                   FF-in epilogue, consumed as hardware block scales) and e4m3 weights; the attention kernels write
-                                  MXFP8 too (one scale per half head) for the to_out projections (transformer.py:319); rest as 0 */
+                                  MXFP8 too (one scale per half head) for the to_out projections (transformer.py:319); rest as 0;
+                                  2: fp32 VERIFICATION mode -- every contraction of the blocks on the exact fp32 MFMA
+                                  (v_mfma_f32_32x32x2_f32), fp32 LayerNorm output, fp32 q / k / v / P, fp32 weights: same plan, data flow
+                                  and index arithmetic, no operand rounding (~20x slower; meets 1e-3 vs the reference's outputs) */
 } sat_dit_cfg;
 
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);

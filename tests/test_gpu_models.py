@@ -476,6 +476,48 @@ def test_full_size_batch8_config3_config5(dev, full_dit, gemm_dtype):
         full_dit.set_gemm_dtype("bf16")
 
 
+def test_fp32x_mode_vs_reference_golden(dev, full_dit, small_dit):
+    """gemm_dtype="fp32x": the fp32 verification mode (csrc/f32_ref.hip: exact fp32 MFMA, fp32 LayerNorm output, fp32 q / k / v / P)
+    through the SAME plan, workspace layout, RoPE table, prepend token, null-context skip and CFG batching as the bf16 path.
+    north_star's tolerance -- <= 1e-3 rel-L2 vs the reference latents -- against the REFERENCE's own fp32 outputs at full size
+    (T = 1024 with and without CFG 7, T = 6144), and <= 1e-4 against the fp32 oracle on the reduced model.  What the bf16 path
+    adds on top of this (3.5e-3 at full size) is therefore operand rounding, not indexing."""
+    import cases
+    from oracle import dit as odit
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dsd = _sub(sd, "model.model.")
+    dit = model.model.model
+    x, c, g = _inputs(2, 77, dc["cond_token_dim"])
+    t = torch.tensor([0.31, 0.87])
+    dit.set_gemm_dtype("fp32x")
+    try:
+        for cfg_scale, tol in ((1.0, 1e-4), (7.0, 1e-4)):
+            got = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=cfg_scale)
+            want = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=cfg_scale)
+            e = assert_close(f"fp32x reduced DiT cfg {cfg_scale} vs fp32 oracle", got, want, tol)
+            print(f"\n[fp32x reduced, cfg {cfg_scale}] rel-L2 vs fp32 oracle {e:.2e}")
+    finally:
+        dit.set_gemm_dtype("bf16")
+    full_dit.set_gemm_dtype("fp32x")
+    try:
+        gold = cases.load("dit_full_T1024")
+        x, t, c, g = cases.dit_inputs(1, 1024, 768, 1536, 1)
+        got = full_dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
+        e1 = assert_close("fp32x full-size DiT T=1024 vs reference", got, gold["out"], 1e-3)
+        got = full_dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0)
+        e7 = assert_close("fp32x full-size DiT T=1024 CFG 7 vs reference", got, gold["cfg7"], 1e-3)
+        import os
+        e6 = float("nan")
+        if os.path.exists(os.path.join(cases.GOLDEN_DIR, "dit_full_T6144.npz")):
+            x, t, c, g = cases.dit_inputs(1, 6144, 768, 1536, 1)
+            got = full_dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
+            e6 = assert_close("fp32x full-size DiT T=6144 vs reference", got, cases.load("dit_full_T6144")["out"], 1e-3)
+        print(f"\n[fp32x full size] rel-L2 vs the reference: T=1024 {e1:.2e}, T=1024 CFG 7 {e7:.2e}, T=6144 {e6:.2e}  (north_star: 1e-3)")
+    finally:
+        full_dit.set_gemm_dtype("bf16")
+
+
 def test_fp8_full_width_slice_vs_matched_oracle(dev):
     """Config 5 at full WIDTH: a 2-layer slice of the SA-Open DiT (D=1536, 24 heads, FF 6144, cond 768) in fp8 mode against the
     oracle that quantises at the same points (oracle.dit.Fp8Rounding): gate 5e-3, as for the reduced model."""
