@@ -354,6 +354,53 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 output / residual epilogue staged through LDS (un-swapped orientation, wave tile TM x 64).  Each wave writes one
+// 32 x 64 fp32 block of its accumulators into a private 8 KiB LDS region (row-major, ds_write_b32: the 32 lanes of a half cover
+// one 128-byte row segment, conflict-free) and reads it back as 16-byte pieces of whole rows, so that the read-modify-write of
+// the residual stream becomes 8 + 8 fully coalesced 16-byte accesses per block (4 rows x 256 contiguous bytes per instruction)
+// instead of 32 + 32 dword accesses.  The LDS ring is free at that point (the caller passes a barrier after the last K-tile).
+// ---------------------------------------------------------------------------------------------
+// PRE: the residual values were loaded at kernel start (`pre`, MI == 1 only): their HBM / L2 latency is then hidden behind
+// the whole K loop instead of sitting between the last MFMA and the first store.
+template <int MI, bool PRE = false>
+__device__ __forceinline__ void gemm_epilogue_f32_staged(const GemmArgs& g, f32x16 (&acc)[MI][2], float* ep, const int mw, const int nw,
+                                                         const int lane, const f32x4* pre = nullptr) {
+    const int half = lane >> 5, l31 = lane & 31;
+    const int M = g.M;
+    const int prow = lane >> 4;            // row of this lane inside a 4-row pass
+    const int c4 = (lane & 15) * 4;        // first of its 4 columns
+    const bool accum = g.accumulate != 0;
+    const f32x4 bia = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nw + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {     // two batches of four passes: 16 registers of residual values in flight
+            f32x4 old[4];
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int m = mw + i * 32 + (grp * 4 + p4) * 4 + prow;
+                if constexpr (PRE) old[p4] = pre[grp * 4 + p4];
+                else old[p4] = (accum && m < M) ? *reinterpret_cast<const f32x4*>(g.C + (size_t)m * g.ldc + nw + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int row = (grp * 4 + p4) * 4 + prow;
+                const int m = mw + i * 32 + row;
+                f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 64 + c4) + bia;
+                if (m < M) {
+                    if (g.gate) v *= *reinterpret_cast<const f32x4*>(g.gate + (size_t)(m / g.gate_rows) * g.gate_ld + nw + c4);
+                    *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + nw + c4) = v + old[p4];
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
@@ -671,6 +718,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // waves whose TM rows lie entirely beyond M (the M-tail tile: 2 valid rows of 256 at B=1) keep staging tiles and
     // joining barriers but skip their LDS reads, MFMAs and epilogue
     const bool wave_rows_valid = (m0 + wm * TM) < M;
+    // fp32 residual epilogue of the small tiles (one 32-row block per wave, registers to spare): fetch the residual values NOW.
+    // They are the oldest entries of the vector-memory queue, so every counted vmcnt wait of the K loop still holds.
+    constexpr bool PRE_RESID = EPI == EPI_F32 && MI == 1 && NI == 2 && DBG == 0 && NT <= 512;
+    [[maybe_unused]] f32x4 resid[PRE_RESID ? 8 : 1];
+    if constexpr (PRE_RESID) {
+        // (exactly the condition under which the staged epilogue runs, see the end of the kernel)
+        const bool staged = !(!MXA && !(g.variant & 0x1000) && (g.variant & 0x2000)) && !(g.variant & 0x8000);
+        const bool want = g.accumulate != 0 && wave_rows_valid && staged;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int m = m0 + wm * TM + ps * 4 + (lane >> 4);
+            resid[ps] = (want && m < M) ? *reinterpret_cast<const f32x4*>(g.C + (size_t)m * g.ldc + n0 + wn * TN + (lane & 15) * 4)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 
     constexpr bool dbg_same = DBG == 1;
     constexpr bool dbg_noload = DBG == 2 || (DBG >= 4 && DBG != 8);      // 8: production main loop, stores suppressed
@@ -1001,6 +1063,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             }
         }
     }
+    if constexpr (EPI == EPI_F32 && NI == 2 && DBG == 0) {
+        if (!tr && !(g.variant & 0x8000)) {     // (bit 15: the direct dword epilogue, for A/B measurements)
+            __builtin_amdgcn_s_barrier();       // every wave is done reading the ring: it becomes the staging area
+            if (wave_rows_valid) {
+                if constexpr (PRE_RESID)
+                    gemm_epilogue_f32_staged<MI, true>(g, acc, reinterpret_cast<float*>(smem) + wave * 2048, m0 + wm * TM, n0 + wn * TN, lane, resid);
+                else
+                    gemm_epilogue_f32_staged<MI>(g, acc, reinterpret_cast<float*>(smem) + wave * 2048, m0 + wm * TM, n0 + wn * TN, lane);
+            }
+            return;
+        }
+    }
     if (wave_rows_valid) {
         if constexpr (NI == 2 || EPI == EPI_F32) {
             if (tr) gemm_epilogue_t<EPI, MI, NI, dbg_nostore>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
@@ -1187,6 +1261,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
     if (tr) main_loop(std::true_type{});
     else main_loop(std::false_type{});
 
+    if constexpr (EPI == EPI_F32) {
+        if (!tr && !(g.variant & 0x8000)) {
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int q = 0; q < NJ; ++q)
+                gemm_epilogue_f32_staged<MI>(g, acc[q], reinterpret_cast<float*>(smem) + wave * 2048, m0 + wm * TM, n0 + wn * TN + q * 64, lane);
+            return;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < NJ; ++q) {
         if (tr) gemm_epilogue_t<EPI, MI, 2>(g, acc[q], m0 + wm * TM, n0 + wn * TN + q * 64, half, l31);
@@ -1214,6 +1297,7 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
     constexpr int LDS = NS * ((BM + BN) * BK * 2 + (FP8 == 3 ? BM * 4 : 0));
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
+    static_assert(EPI != EPI_F32 || BN / WN != 64 || LDS >= WM * WN * 8192, "the staged fp32 epilogue needs 8 KiB of LDS per wave");
     auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG, FP8>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     GemmArgs b = a;

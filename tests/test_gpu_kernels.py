@@ -49,7 +49,10 @@ def test_cast_bf16(dev):
 LEGACY = 0x1000     # variant bit 12: un-swapped MFMA operands (lane = channel) and the epilogue that goes with it
 
 # the shipped tile configurations (gemm_bf16.hip: launch_epi), the LDS-DMA ones in both accumulator orientations
+FP32_T = 0x2000     # bit 13: transposed orientation for the fp32-output epilogue as well (default there: un-swapped + LDS-staged)
+DIRECT = 0x8000     # bit 15: the direct dword fp32 epilogue instead of the LDS-staged one
 GEMM_VARIANTS = [1, 5, 15, 16, 22, 26, 30, 15 | LEGACY, 16 | LEGACY, 22 | LEGACY, 26 | LEGACY, 30 | LEGACY]
+GEMM_F32_VARIANTS = GEMM_VARIANTS + [15 | FP32_T, 22 | FP32_T, 26 | FP32_T, 15 | DIRECT, 16 | DIRECT, 22 | DIRECT, 26 | DIRECT, 30 | DIRECT]
 
 
 def _skip_tile(variant, n, k):
@@ -62,7 +65,7 @@ def _skip_tile(variant, n, k):
         pytest.skip("the deep-prefetch variants need K >= stages * BK")
 
 
-@pytest.mark.parametrize("variant", GEMM_VARIANTS)
+@pytest.mark.parametrize("variant", GEMM_F32_VARIANTS)
 @pytest.mark.parametrize("m,n,k", [(2050, 1536, 1536), (130, 256, 128), (1, 512, 64), (257, 768, 6144)])
 def test_gemm_f32(dev, variant, m, n, k):
     _skip_tile(variant, n, k)

@@ -57,15 +57,21 @@ def gemm_bench():
                 print(f"data {label:10s} v{v} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
         return
     if os.environ.get("PROBE_QUANT"):
-        shapes = [("256 tiles", 2048, 8192, 1536), ("384 tiles", 2048, 12288, 1536), ("432 tiles", 2050, 12288, 1536), ("512 tiles", 2048, 16384, 1536),
-                  ("128 tiles", 2048, 4096, 1536), ("162 tiles", 2050, 4608, 1536)]
-        for name, m, n, k in shapes:
+        # tile quantisation: how the time of one launch depends on the number of workgroups (256 CUs), and what the near-empty
+        # tiles of the 2 leftover rows of M = 2050 cost
+        shapes = [("256 tiles", 2048, 8192, 1536, 22), ("384 tiles", 2048, 12288, 1536, 22), ("432 tiles (2050)", 2050, 12288, 1536, 22),
+                  ("512 tiles", 2048, 16384, 1536, 22), ("288 tiles (2050)", 2050, 8192, 1536, 22), ("128 tiles", 2048, 4096, 1536, 22),
+                  ("v15 192 tiles", 2048, 1536, 6144, 15), ("v15 204 tiles (2050)", 2050, 1536, 6144, 15), ("v15 256 tiles", 2048, 2048, 6144, 15),
+                  ("v15 272 tiles (2050)", 2050, 2048, 6144, 15), ("v15 192 tiles K1536", 2048, 1536, 1536, 15), ("v15 256 tiles K1536", 2048, 2048, 1536, 15),
+                  ("v30 192 tiles", 2048, 4608, 1536, 30), ("v30 216 tiles (2050)", 2050, 4608, 1536, 30), ("v30 256 tiles", 2048, 6144, 1536, 30),
+                  ("v16 192 tiles", 1024, 1536, 1536, 16), ("v16 216 tiles (1025)", 1025, 1536, 1536, 16), ("v16 256 tiles", 1024, 2048, 1536, 16)]
+        for name, m, n, k, v in shapes:
             a = torch.randn(m, k, device=dev).to(torch.bfloat16)
             w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
             c = torch.zeros(m, n, device=dev)
-            f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 0, 22, _hip.stream()))
-            ms = timeit(f)
-            print(f"quant {name:10s} M={m} N={n}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
+            f = lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 1, v, _hip.stream()))
+            ms = min(timeit(f) for _ in range(3))
+            print(f"quant {name:22s} M={m} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*m*n*k/ms/1e9:8.1f} TFLOP/s", flush=True)
         return
     shapes = [("ff_in(swiglu)", 2050, 12288, 1536), ("ff_out", 2050, 1536, 6144), ("qkv", 2050, 4608, 1536), ("proj", 2050, 1536, 1536),
               ("cross q/out", 1025, 1536, 1536), ("ff_in B8", 16400, 12288, 1536), ("ff_out B8", 16400, 1536, 6144)]
@@ -134,6 +140,24 @@ def epi_ab():
         ab(f"heads {name} {b*s_len}x{3*d}x{d} (+memsets)", lambda flag: (lambda: _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(inv_freq), _hip.ptr(q), _hip.ptr(kk),
                                                                                                           _hip.ptr(vt), _hip.ptr(scratch), b, s_len, s_pad, d, v | flag,
                                                                                                           _hip.stream()))), 2.0 * b * s_len * 3 * d * d)
+
+
+def f32_epi_ab():
+    """fp32 residual epilogue: LDS-staged 16-byte coalesced (default) vs direct dword (bit 15) vs transposed 16-byte (bit 13)."""
+    import statistics
+    for name, m, n, k, v in [("to_out B1 v15", 2050, 1536, 1536, 15), ("ff_out B1 v15", 2050, 1536, 6144, 15), ("cross B1 v16", 1025, 1536, 1536, 16),
+                             ("to_out B8 v26", 16400, 1536, 1536, 26), ("ff_out B8 v26", 16400, 1536, 6144, 26), ("ff_out B8 v22", 16400, 1536, 6144, 22)]:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        c = torch.zeros(m, n, device=dev)
+        bias = torch.randn(n, device=dev)
+        mk = lambda flag: (lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(c), m, n, k, 1, v | flag, _hip.stream())))
+        fs = {"staged": mk(0), "direct": mk(0x8000), "transposed": mk(0x2000)}
+        res = {kk: [] for kk in fs}
+        for _ in range(5):
+            for kk, f in fs.items():
+                res[kk].append(timeit(f, iters=10, warm=2))
+        print(f"f32+resid {name:16s} " + "  ".join(f"{kk}: {statistics.median(vv)*1e3:6.1f} us" for kk, vv in res.items()), flush=True)
 
 
 def ablate():
@@ -263,6 +287,8 @@ if __name__ == "__main__":
         section("gemm", gemm_bench)
     if "epi" in which:
         section("epilogue A/B", epi_ab)
+    if "f32epi" in which:
+        section("fp32 epilogue A/B", f32_epi_ab)
     if "ablate" in which:
         section("ablation", ablate)
     if "gemm_pmc" in which:
