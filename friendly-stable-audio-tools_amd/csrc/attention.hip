@@ -2,46 +2,75 @@
 // non-causal, no mask, GQA by head index (models/transformer.py:496-536; the reference's
 // CPU branch is einsum + softmax(fp32) + einsum, :525-536; GQA repeat_interleave :512-515).
 //
-// gfx950 design.  One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns
-// 32 queries.  K and V^T tiles of 64 keys are staged through LDS (register-staged double
-// buffer, one barrier per tile, XOR-swizzled rows -> conflict-free ds_read_b128) and shared
-// by the 4 waves.  Both products are computed TRANSPOSED so that everything that belongs
-// to one query lives in one lane (plus its lane+32 partner):
+// gfx950 design.  One workgroup = 8 waves = 128 queries of one (batch, head) x 2 key ranges: waves 0-3 ("group 0") walk the first
+// half of the KV tiles, waves 4-7 the second half, for the SAME 4 x 32 queries; the two partial results (running max, row sum,
+// un-normalised output) are merged once through LDS.  At S = 1025 this doubles the number of waves in flight (432 workgroups of
+// 8 waves, two per CU = 4 waves per SIMD) and halves the length of every wave's dependent tile chain.
+//
+// K and V^T tiles of 64 keys are copied to LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) into a
+// 2-stage ring per group, one raw s_barrier per tile, the copy of tile i+1 in flight while tile i is consumed.  LDS rows are 128 B
+// with the 16-byte chunk index XORed by (row >> 1) & 7 (conflict-free ds_read_b128 fragments); the swizzle is folded into the
+// per-lane SOURCE address because LDS-DMA writes lane-linear.
+//
+// Both products are computed TRANSPOSED so that everything that belongs to one query lives in one lane (plus its lane+32 partner):
 //     S^T[key, q] = K[key, :] . Q[q, :]          (A = K fragment from LDS, B = Q in registers)
 //     O^T[d,  q] = V^T[d, key] . P^T[key, q]     (A = V^T fragment from LDS, B = P in registers)
-// With v_mfma_f32_32x32x16_bf16 the C/D layout is col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5):
-// a lane's 16 S^T registers are 16 keys of ITS query, and they are exactly the k-operand
-// elements (k = 8*(lane>>5)+j) the second MFMA wants for the key order
-//     key(kb,u,half,j) = 32*kb + 16*u + 8*(j>>2) + 4*half + (j&3)
-// so P never moves between lanes; V^T is laid out in LDS in that key order (bits 2 and 3
-// of the key index swapped) when it is staged.  Row max needs ONE wavefront shuffle
-// (lane <-> lane+32) per tile, row sums one at the end; the O rescale is lane-local.
-// V^T ([B,KVH,64,Spad]) is produced directly by the QKV GEMM epilogue (gemm_bf16.hip).
+// With v_mfma_f32_32x32x16_bf16 the C/D layout is col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5): a lane's 16 S^T registers
+// are 16 keys of ITS query, and they are exactly the k-operand elements the second MFMA wants if V^T stores every aligned group of
+// 16 keys as [0-3, 8-11, 4-7, 12-15] (vt_pos, sat_common.h) -- which is how the QKV GEMM epilogue writes it.  P never moves between
+// lanes; the row max needs one exchange between the wave halves per 32 keys, the row sum one at the end; the O rescale is lane-local.
+// The online softmax advances in steps of 32 keys (one S^T accumulator block): 16 score registers live instead of 32, which is
+// what lets the kernel run at 4 waves per SIMD (<= 128 VGPRs).
+#include <stdlib.h>
+
 #include "sat_common.h"
 
 namespace {
 
 constexpr int KV_TILE = 64;
 constexpr int Q_BLOCK = 128;
+constexpr int STAGE_BYTES = 2 * KV_TILE * 128;            // K tile + V^T tile
+constexpr int GROUP_BYTES = 2 * STAGE_BYTES;              // 2-stage ring per KV group
+constexpr int ATT_LDS = 2 * GROUP_BYTES;                  // 64 KiB: two workgroups per CU
+
+__device__ __forceinline__ float half_max(float v) {     // max over the lane pair (l, l ^ 32), in both lanes
+    unsigned a = __float_as_uint(v), b = a;
+    u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+    unsigned a = __float_as_uint(v), b = a;
+    u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_halves(unsigned& lo_run, unsigned& hi_run) {
+    u32x2 r = __builtin_amdgcn_permlane32_swap(lo_run, hi_run, false, false);
+    lo_run = r[0];
+    hi_run = r[1];
+}
 
 // MX8: fp8_gemm mode -- the output is the A operand of the to_out GEMM and is written as MXFP8 (e4m3 bytes at `out`, one E8M0
 // scale per 32 channels = half a head at `out_scales` [B*Sq][H*2]) instead of bf16
-template <bool MX8>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                        const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
-                                                        unsigned char* __restrict__ out_scales,
-                                                        int H, int KVH, int Sq, int Sk, int Sq_pad, int Sk_pad,
-                                                        float scale_log2) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_TILE * 128];   // [stage][K | Vt][64 rows * 128 B]
+// DBG (experiments build only, wrong results): 1 no exp / max / sum (P = bf16(S)); 2 no LDS-DMA in the loop; 3 no MFMA; 4 = 2 + no
+// barrier; 5 = 4 + K / V^T fragments read from LDS once
+template <bool MX8, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+                                                           unsigned char* __restrict__ out_scales,
+                                                           int H, int KVH, int Sq, int Sk, int Sq_pad, int Sk_pad,
+                                                           float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;            // KV group
+    const int wq = wave & 3;              // query sub-block of this wave
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
     const int kvh = h / (H / KVH);
-    const int qi = blockIdx.x * Q_BLOCK + wave * 32 + l31;   // < Sq_pad
+    const int qi = blockIdx.x * Q_BLOCK + wq * 32 + l31;   // < Sq_pad
 
     // Q fragments (B operand of S^T): Q[qi][16t + 8*half .. +8]
     bf16x8 qf[4];
@@ -51,37 +80,38 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(qp + t * 16);
     }
 
+    // K rows / V^T columns of sequence b start at ob = (b*Sk) & 3 (see EPI_HEADS in gemm_bf16.hip)
+    const int ob = (b * Sk) & 3;
+    const int k_end = ob + Sk;
+    const int n_tiles = (k_end + KV_TILE - 1) / KV_TILE;
+    const int n0 = (n_tiles + 1) >> 1;                     // group 0: tiles [0, n0), group 1: [n0, n_tiles)
+    const int t_first = grp ? n0 : 0;
+    const int t_count = grp ? n_tiles - n0 : n0;
+    const int n_iter = n0;                                 // >= the other group's count: both groups pass the same barriers
+
+    // LDS-DMA pieces of this wave: 1 KiB = 8 rows of 128 B; wave wq of the group copies pieces wq and wq + 4 of the K tile and of the
+    // V^T tile.  Lane l lands at row 8p + l/8, position l%8, so it fetches logical chunk (l%8) ^ ((row >> 1) & 7) of that row.
     const bf16_t* kbase = k + (size_t)(b * KVH + kvh) * Sk_pad * 64;
     const bf16_t* vbase = vt + (size_t)(b * KVH + kvh) * 64 * Sk_pad;
-
-    // staging coordinates: 512 16-B chunks per operand per tile, 2 per thread
-    int srow[2], schk[2];
+    const bf16_t* ksrc[2];
+    const bf16_t* vsrc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int id = i * 256 + tid;
-        srow[i] = id >> 3;
-        schk[i] = id & 7;
+        const int row = (wq + 4 * i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        ksrc[i] = kbase + (size_t)row * 64 + c * 8;                 // + tile * 64 rows
+        vsrc[i] = vbase + (size_t)row * Sk_pad + c * 8;             // + tile * 64 keys
     }
-    u32x4 rk[2], rv[2];
-    auto gload = [&](int tile) {
-        const int key0 = tile * KV_TILE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            rk[i] = *reinterpret_cast<const u32x4*>(kbase + (size_t)(key0 + srow[i]) * 64 + schk[i] * 8);
-            rv[i] = *reinterpret_cast<const u32x4*>(vbase + (size_t)srow[i] * Sk_pad + key0 + schk[i] * 8);
-        }
-    };
-    auto lstore = [&](int stage) {
-        char* sk = smem + stage * (2 * KV_TILE * 128);
+    char* ring = smem + grp * GROUP_BYTES;
+    auto stage_in = [&](int tile, int stage) {
+        char* sk = ring + stage * STAGE_BYTES;
         char* sv = sk + KV_TILE * 128;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<u32x4*>(sk + lds_tile_off(srow[i], schk[i])) = rk[i];
-            // keys 8c..8c+3 -> chunk 2*(c>>1), keys 8c+4..8c+7 -> chunk 2*(c>>1)+1, byte 8*(c&1)
-            const int c = schk[i];
-            const int c0 = (c >> 1) * 2;
-            *reinterpret_cast<u32x2*>(sv + lds_tile_off(srow[i], c0) + 8 * (c & 1)) = u32x2{rv[i][0], rv[i][1]};
-            *reinterpret_cast<u32x2*>(sv + lds_tile_off(srow[i], c0 + 1) + 8 * (c & 1)) = u32x2{rv[i][2], rv[i][3]};
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc[i] + (size_t)tile * KV_TILE * 64),
+                                             (__attribute__((address_space(3))) void*)(sk + (wq + 4 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc[i] + (size_t)tile * KV_TILE),
+                                             (__attribute__((address_space(3))) void*)(sv + (wq + 4 * i) * 1024), 16, 0, 0);
         }
     };
 
@@ -91,107 +121,126 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = -1e30f;   // running max, in log2-scaled units
-    float l_run = 0.f;      // this lane's partial row sum (its 32 of every 64 keys)
+    float l_run = 0.f;      // this lane's partial row sum (its 16 of every 32 keys)
 
-    // K rows / V^T columns of sequence b start at ob = (b*Sk) & 3 (see EPI_HEADS in gemm_bf16.hip)
-    const int ob = (b * Sk) & 3;
-    const int k_end = ob + Sk;
-    const int n_tiles = (k_end + KV_TILE - 1) / KV_TILE;
-    // a wave whose 32 queries are all beyond Sq (tail workgroup) still stages tiles and joins the barriers,
-    // but skips the matrix and softmax work
-    const bool wave_active = __builtin_amdgcn_readfirstlane(blockIdx.x * Q_BLOCK + wave * 32) < Sq;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    // a wave whose 32 queries are all beyond Sq (tail workgroup) still copies tiles and joins the barriers, but skips the matrix and
+    // softmax work
+    const bool wave_active = __builtin_amdgcn_readfirstlane(blockIdx.x * Q_BLOCK + wq * 32) < Sq;
 
-    auto process = [&](int tile) {
-        if (!wave_active) return;
-        const int cur = tile & 1;
-        const char* sk = smem + cur * (2 * KV_TILE * 128);
+    auto process = [&](int tile, int stage) {
+        const char* sk = ring + stage * STAGE_BYTES;
         const char* sv = sk + KV_TILE * 128;
-
-        // ---- S^T = K Q^T : two 32-key blocks.  All 8 K fragments are requested up front so that the MFMAs never
-        // wait on a just-issued ds_read.
-        bf16x8 kf[2][4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                kf[kb][t] = *reinterpret_cast<const bf16x8*>(sk + lds_tile_off(kb * 32 + l31, t * 2 + half));
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 sacc[2];
+        const bool edge = (tile == 0 && ob != 0) || (tile == n_tiles - 1 && (k_end & (KV_TILE - 1)) != 0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            // ---- S^T = K Q^T for 32 keys
+            bf16x8 kf[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][t], qf[t], sacc[kb], 0, 0, 0);
-        }
-        // V^T fragments do not depend on the softmax: request them now, their LDS latency hides behind the VALU work
-        bf16x8 vf[2][4];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int ku = 0; ku < 4; ++ku)
-                vf[db][ku] = *reinterpret_cast<const bf16x8*>(sv + lds_tile_off(db * 32 + l31, ku * 2 + half));
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- mask the columns outside [ob, ob + Sk) (wave-uniform branch: first and last tile only)
-        if ((tile == 0 && ob != 0) || (tile == n_tiles - 1 && (k_end & (KV_TILE - 1)) != 0)) {
-            const int key0 = tile * KV_TILE + 4 * half;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2);
-                    if (key < ob || key >= k_end) sacc[kb][r] = -INFINITY;
-                }
-        }
-        // ---- online softmax (per query = per lane pair)
-        float mloc = sacc[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[kb][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc * scale_log2);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pb[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], scale_log2, -m_new));
-                psum += p;
-                pb[kb][r >> 3][r & 7] = f32_to_bf16(p);
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (DBG == 5) kf[t] = qf[t];
+                else kf[t] = *reinterpret_cast<const bf16x8*>(sk + lds_tile_off(kb * 32 + l31, t * 2 + half));
             }
-        l_run = l_run * alpha + psum;
-        if (!__all(alpha == 1.0f)) {
+            f32x16 sacc;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 16; ++r) sacc[r] = DBG == 3 ? (float)kf[r & 3][r >> 2] : 0.f;
+            if constexpr (DBG != 3) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-        }
-        // ---- O^T += V^T P^T
+                for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[t], sacc, 0, 0, 0);
+            }
+            // V^T fragments do not depend on the softmax: request them now, their LDS latency hides behind the VALU work
+            bf16x8 vf[2][2];
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][kb * 2 + u], pb[kb][u], oacc[db], 0, 0, 0);
+                    if constexpr (DBG == 5) vf[db][u] = qf[db * 2 + u];
+                    else vf[db][u] = *reinterpret_cast<const bf16x8*>(sv + lds_tile_off(db * 32 + l31, (kb * 2 + u) * 2 + half));
+            // ---- mask the keys outside [ob, ob + Sk) (wave-uniform branch: first and last tile only)
+            if (edge) {
+                const int key0 = tile * KV_TILE + kb * 32 + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2);
+                    if (key < ob || key >= k_end) sacc[r] = -INFINITY;
+                }
+            }
+            // ---- online softmax step (per query = per lane pair)
+            float mloc = sacc[0];
+            bf16x8 pb[2];
+            float alpha = 1.0f;
+            if constexpr (DBG == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = f32_to_bf16(sacc[r]);
+                l_run += sacc[0];
+            } else {
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+                mloc = half_max(mloc);
+                const float m_new = fmaxf(m_run, mloc * scale_log2);
+                alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_new));
+                    psum += p;
+                    pb[r >> 3][r & 7] = f32_to_bf16(p);
+                }
+                l_run = l_run * alpha + psum;
+            }
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            }
+            // ---- O^T += V^T P^T
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if constexpr (DBG == 3) oacc[db][u] += (float)vf[db][u][0] * (float)pb[u][0];
+                    else oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][u], pb[u], oacc[db], 0, 0, 0);
+                }
+        }
     };
-    for (int tile = 0; tile < n_tiles - 1; ++tile) {
-        gload(tile + 1);
-        process(tile);
-        lstore((tile + 1) & 1);
-        __syncthreads();
-    }
-    process(n_tiles - 1);
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    if (t_count > 0) stage_in(t_first, 0);
+    for (int it = 0; it < n_iter; ++it) {
+        if constexpr (DBG < 4) {
+            wait_vmcnt<0>();                          // this wave's pieces of tile `it` have landed ...
+            __builtin_amdgcn_s_barrier();             // ... everybody's have, and everybody is done with the other stage (tile it - 1)
+        }
+        if (DBG != 2 && DBG < 4 && it + 1 < t_count) stage_in(t_first + it + 1, (it + 1) & 1);
+        if (wave_active && it < t_count) process(t_first + it, it & 1);
+    }
+
+    // ---- merge the two key ranges: group 1 hands (m, l, O) to group 0 through LDS ([wave][34 values][64 lanes], conflict-free)
+    __builtin_amdgcn_s_barrier();                 // the rings are free
+    float* mg = reinterpret_cast<float*>(smem) + wq * (34 * 64) + lane;
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mg[(i * 16 + r) * 64] = oacc[i][r];
+        mg[32 * 64] = m_run;
+        mg[33 * 64] = l_run;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    {
+        const float m1 = mg[32 * 64], l1 = mg[33 * 64];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+        l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] = oacc[i][r] * a0 + mg[(i * 16 + r) * 64] * a1;
+    }
+
+    const float inv = 1.0f / half_sum(l_run);
+    // O^T registers of a lane: channels d = db*32 + 8*(r>>2) + 4*half + (r&3) of ITS query (the layout of gemm_epilogue_t)
     if constexpr (MX8) {
         // block db (32 channels of this head): this lane holds 16 of them, lane ^ 32 the other 16
 #pragma unroll
@@ -199,35 +248,51 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
             float am = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) am = fmaxf(am, fabsf(oacc[db][r] * inv));
-            am = fmaxf(am, __shfl_xor(am, 32, 64));
+            am = half_max(am);
             const float t = am * (1.0f / 448.0f);
             const unsigned tb = __float_as_uint(t);
             int e = (int)((tb >> 23) & 0xff) - 127 + ((tb & 0x7fffff) ? 1 : 0);
             e = am > 0.f ? (e < -127 ? -127 : (e > 127 ? 127 : e)) : -127;
             const float qs = inv * __uint_as_float((unsigned)(127 - e) << 23);
-            if (qi < Sq) {
-                unsigned char* op = reinterpret_cast<unsigned char*>(out) + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64 + db * 32;
+            unsigned q8[4];
 #pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    unsigned p = 0;
-                    p = __builtin_amdgcn_cvt_pk_fp8_f32(oacc[db][rq * 4] * qs, oacc[db][rq * 4 + 1] * qs, p, false);
-                    p = __builtin_amdgcn_cvt_pk_fp8_f32(oacc[db][rq * 4 + 2] * qs, oacc[db][rq * 4 + 3] * qs, p, true);
-                    *reinterpret_cast<unsigned*>(op + rq * 8 + half * 4) = p;
-                }
+            for (int rq = 0; rq < 4; ++rq) {
+                unsigned p = __builtin_amdgcn_cvt_pk_fp8_f32(oacc[db][rq * 4] * qs, oacc[db][rq * 4 + 1] * qs, 0u, false);
+                q8[rq] = __builtin_amdgcn_cvt_pk_fp8_f32(oacc[db][rq * 4 + 2] * qs, oacc[db][rq * 4 + 3] * qs, p, true);
+            }
+            swap_halves(q8[0], q8[1]);            // lanes 0-31: channels 0-7 | 16-23, lanes 32-63: 8-15 | 24-31
+            swap_halves(q8[2], q8[3]);
+            if (qi < Sq) {
+                unsigned char* op = reinterpret_cast<unsigned char*>(out) + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64 + db * 32 + 8 * half;
+                *reinterpret_cast<u32x2*>(op) = u32x2{q8[0], q8[1]};
+                *reinterpret_cast<u32x2*>(op + 16) = u32x2{q8[2], q8[3]};
                 if (half == 0) out_scales[((size_t)b * Sq + qi) * ((size_t)H * 2) + h * 2 + db] = (unsigned char)(e + 127);
             }
         }
-    } else if (qi < Sq) {
-        bf16_t* op = out + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64;
+    } else {
+        bf16_t* op = out + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64 + 8 * half;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db) {
+            unsigned pk[8];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f32_to_bf16(oacc[db][rq * 4 + e] * inv);
-                *reinterpret_cast<bf16x4*>(op + db * 32 + rq * 8 + half * 4) = o;
+                bf16x2 lo, hi;
+                lo[0] = f32_to_bf16(oacc[db][rq * 4] * inv);
+                lo[1] = f32_to_bf16(oacc[db][rq * 4 + 1] * inv);
+                hi[0] = f32_to_bf16(oacc[db][rq * 4 + 2] * inv);
+                hi[1] = f32_to_bf16(oacc[db][rq * 4 + 3] * inv);
+                pk[2 * rq] = __builtin_bit_cast(unsigned, lo);
+                pk[2 * rq + 1] = __builtin_bit_cast(unsigned, hi);
             }
+            swap_halves(pk[0], pk[2]);            // 8 consecutive channels per lane: one 16-byte store instead of two 8-byte ones
+            swap_halves(pk[1], pk[3]);
+            swap_halves(pk[4], pk[6]);
+            swap_halves(pk[5], pk[7]);
+            if (qi < Sq) {
+                *reinterpret_cast<u32x4*>(op + db * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                *reinterpret_cast<u32x4*>(op + db * 32 + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+            }
+        }
     }
 }
 
@@ -241,12 +306,31 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
     SAT_CHECK_ARG(sq_pad % Q_BLOCK == 0 && sk_pad % KV_TILE == 0, SAT_E_INVALID,
                   "attention: sq_pad %% 128 and sk_pad %% 64 must be 0 (got %d, %d)", sq_pad, sk_pad);
     SAT_CHECK_ARG(sk_pad >= sk + 3, SAT_E_INVALID, "attention: sk_pad must be >= sk + 3 (key-side shift), got %d for sk=%d", sk_pad, sk);
+    SAT_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0, SAT_E_INVALID, "attention: pointers must be 16-byte aligned");
     const float scale_log2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
     dim3 grid(cdiv(sq, Q_BLOCK), h, b);
-    if (out_scales)
-        hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
-    else
-        hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
+#ifdef SAT_GEMM_EXPERIMENTS
+    if (const char* dbg = getenv("SAT_ATTN_DBG")) {
+        auto launch = [&](auto kern) {
+            (void)sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ATT_LDS);
+            hipLaunchKernelGGL(kern, grid, dim3(512), ATT_LDS, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
+        };
+        switch (atoi(dbg)) {
+            case 1: launch(attention_kernel<false, 1>); return 0;
+            case 2: launch(attention_kernel<false, 2>); return 0;
+            case 3: launch(attention_kernel<false, 3>); return 0;
+            case 4: launch(attention_kernel<false, 4>); return 0;
+            case 5: launch(attention_kernel<false, 5>); return 0;
+        }
+    }
+#endif
+    if (out_scales) {
+        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<true>), ATT_LDS));
+        hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(512), ATT_LDS, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
+    } else {
+        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false>), ATT_LDS));
+        hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(512), ATT_LDS, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
+    }
     SAT_LAUNCH_CHECK();
     return 0;
 }

@@ -135,7 +135,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 if (kind & 1) {
                     if (mb + 3 < M && bb[0] == bb[3]) {
                         const int ob = shift ? ((bb[0] * S) & 3) : 0;
-                        const size_t base = ((size_t)(bb[0] * he.heads + head) * 64) * Spad + ss[0] + ob;
+                        const size_t hbase = ((size_t)(bb[0] * he.heads + head) * 64) * Spad;
+                        const size_t base = hbase + vt_pos(ss[0] + ob);         // aligned group of 4 keys: stays a group of 4
                         bf16x4 p0, p1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -148,8 +149,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                dst[base + e + (size_t)l31 * Spad] = p0[e];
-                                dst[base + e + (size_t)(32 + l31) * Spad] = p1[e];
+                                const size_t pe = hbase + vt_pos(ss[0] + e);
+                                dst[pe + (size_t)l31 * Spad] = p0[e];
+                                dst[pe + (size_t)(32 + l31) * Spad] = p1[e];
                             }
                         }
                     } else {
@@ -157,7 +159,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                         for (int e = 0; e < 4; ++e)
                             if (mb + e < M) {
                                 const int ob = shift ? ((bb[e] * S) & 3) : 0;
-                                const size_t base = ((size_t)(bb[e] * he.heads + head) * 64) * Spad + ss[e] + ob;
+                                const size_t base = ((size_t)(bb[e] * he.heads + head) * 64) * Spad + vt_pos(ss[e] + ob);
                                 dst[base + (size_t)l31 * Spad] = f32_to_bf16(v0[e]);
                                 dst[base + (size_t)(32 + l31) * Spad] = f32_to_bf16(v1[e]);
                             }

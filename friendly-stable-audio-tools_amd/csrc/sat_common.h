@@ -112,6 +112,12 @@ __device__ __forceinline__ int lds_tile_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// Position of key s inside V^T ([.., 64, Spad], key index contiguous): bits 2 and 3 of the index are swapped, i.e. every aligned
+// group of 16 keys is stored as [0-3, 8-11, 4-7, 12-15].  That is the order in which the second attention MFMA consumes the
+// probabilities a lane holds after the first one (attention.hip), so a V^T tile can be copied to LDS verbatim (LDS-DMA, 16-byte
+// pieces) and read as fragments without any re-arrangement.  Involution; groups of 4 consecutive keys stay together.
+__host__ __device__ __forceinline__ int vt_pos(int s) { return (s & ~12) | ((s & 4) << 1) | ((s & 8) >> 1); }
+
 // counted wait on outstanding vector-memory operations (LDS-DMA pieces included); hipcc does not see inside the asm,
 // which is the point: the compiler never drains the in-flight prefetch ring with a vmcnt(0)
 template <int N>

@@ -102,6 +102,13 @@ def test_gemm_swiglu(dev, variant, m):
     assert_close("swiglu", out, want, 4e-3)
 
 
+def _vt_perm(n):
+    """sat_common.h: vt_pos -- V^T stores every aligned group of 16 keys as [0-3, 8-11, 4-7, 12-15] (bits 2 and 3 of the key index
+    swapped; an involution), the order in which the second attention MFMA consumes a lane's probabilities."""
+    p = torch.arange(n)
+    return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)
+
+
 def _pad_heads(x, s_pad, key_side=False):
     # [B,H,S,64] -> zero-padded [B,H,s_pad,64]; key-side tensors (K, V) of sequence b start at row (b*S) & 3
     b, h, s, d = x.shape
@@ -126,7 +133,7 @@ def test_attention(dev, b, h, kvh, sq, sk):
     sk_pad = (sk + 3 + 63) // 64 * 64
     qd = _pad_heads(q, sq_pad).to(dev)
     kd = _pad_heads(k, sk_pad, key_side=True).to(dev)
-    vtd = _pad_heads(v, sk_pad, key_side=True).transpose(2, 3).contiguous().to(dev)
+    vtd = _pad_heads(v, sk_pad, key_side=True).transpose(2, 3)[..., _vt_perm(sk_pad)].contiguous().to(dev)
     out = torch.empty((b * sq, h * 64), dtype=torch.bfloat16, device=dev)
     _hip.check(lib.sat_attention_bf16(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, h, kvh, sq, sk, sq_pad, sk_pad,
                                       _hip.stream()))
@@ -158,6 +165,7 @@ def test_qkv_rope(dev, variant, s, s_pad):
     _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd),
                                      _hip.ptr(scratch), b, s, s_pad, d, variant, _hip.stream()))
     assert_close("rope q", qd[:, :, :s], q, 4e-3)
+    vtd = vtd[..., _vt_perm(s_pad).to(vtd.device)]      # undo the key permutation of the V^T layout
     for i in range(b):     # key-side tensors of sequence i start at row/column (i*s) & 3
         ob = (i * s) & 3
         assert_close("rope k", kd[i, :, ob:ob + s], k[i], 4e-3)

@@ -237,6 +237,30 @@ def attn_bench():
         print(f"attention {name:9s}: {ms*1e3:8.1f} us  {4.0*b*h*sq*sk*64/ms/1e9:8.1f} TFLOP/s", flush=True)
 
 
+def attn_ablate():
+    """experiments build: SAT_ATTN_DBG = 1 no softmax arithmetic, 2 no LDS-DMA in the loop, 3 no MFMA, 4 no loads + no barrier,
+    5 = 4 + no K / V^T fragment reads"""
+    import statistics
+    for name, b, h, kvh, sq, sk in [("self B1", 2, 24, 24, 1025, 1025), ("self B8", 16, 24, 24, 1025, 1025), ("self SA2", 2, 24, 24, 6145, 6145)]:
+        sqp, skp = (sq + 127) // 128 * 128, (sk + 3 + 63) // 64 * 64
+        q = torch.randn(b, h, sqp, 64, device=dev).to(torch.bfloat16)
+        k = torch.randn(b, kvh, skp, 64, device=dev).to(torch.bfloat16)
+        vt = torch.randn(b, kvh, 64, skp, device=dev).to(torch.bfloat16)
+        o = torch.empty(b * sq, h * 64, device=dev, dtype=torch.bfloat16)
+        f = lambda: _hip.check(lib.sat_attention_bf16(_hip.ptr(q), _hip.ptr(k), _hip.ptr(vt), _hip.ptr(o), b, h, kvh, sq, sk, sqp, skp, _hip.stream()))
+        res = {}
+        for rnd in range(3):
+            for mode in ("0", "1", "2", "3", "4", "5"):
+                if mode == "0":
+                    os.environ.pop("SAT_ATTN_DBG", None)
+                else:
+                    os.environ["SAT_ATTN_DBG"] = mode
+                res.setdefault(mode, []).append(timeit(f, iters=10, warm=2))
+        os.environ.pop("SAT_ATTN_DBG", None)
+        names = {"0": "prod", "1": "nosoftmax", "2": "noload", "3": "nomfma", "4": "noload+nobar", "5": "+nolds"}
+        print(f"attention {name:9s} (us) " + "  ".join(f"{names[m]}: {statistics.median(v)*1e3:6.1f}" for m, v in res.items()), flush=True)
+
+
 def ln_bench():
     m, d = 2050, 1536
     x = torch.randn(m, d, device=dev)
@@ -295,6 +319,8 @@ if __name__ == "__main__":
         section("gemm_pmc", gemm_pmc)
     if "attn" in which:
         section("attention", attn_bench)
+    if "attn_ablate" in which:
+        section("attention ablation", attn_ablate)
     if "ln" in which:
         section("layernorm", ln_bench)
     if "full" in which:
