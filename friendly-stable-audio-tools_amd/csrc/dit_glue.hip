@@ -477,6 +477,43 @@ extern "C" int sat_vae_sample(const float* mean_scale_dev, const float* noise_de
     return 0;
 }
 
+// NumberConditioner (models/conditioners.py:64-102) = clamp -> (x - min) / (max - min) -> NumberEmbedder (models/adp.py:1495-1514):
+// LearnedPositionalEmbedding cat(x, sin(2 pi x w), cos(2 pi x w)) (adp.py:680-694) -> Linear(2*half + 1, features).  A handful of
+// scalars per generation: one workgroup per value, the 2*half + 1 features in LDS, one output channel per thread and pass.
+__global__ __launch_bounds__(256) void number_embed_kernel(const float* __restrict__ values, float vmin, float vmax,
+                                                           const float* __restrict__ w, const float* __restrict__ lw,
+                                                           const float* __restrict__ lb, float* __restrict__ out, int half_dim,
+                                                           int features) {
+    extern __shared__ float feat[];            // [2 * half_dim + 1]
+    const int b = blockIdx.x;
+    const float x = (fminf(fmaxf(values[b], vmin), vmax) - vmin) / (vmax - vmin);
+    if (threadIdx.x == 0) feat[0] = x;
+    for (int i = threadIdx.x; i < half_dim; i += 256) {
+        const float f = x * w[i] * 2.0f * 3.14159265358979323846f;      // torch: ((x * w) * 2) * pi in fp32
+        feat[1 + i] = sinf(f);
+        feat[1 + half_dim + i] = cosf(f);
+    }
+    __syncthreads();
+    const int k = 2 * half_dim + 1;
+    for (int n = threadIdx.x; n < features; n += 256) {
+        const float* wr = lw + (size_t)n * k;
+        float acc = 0.f;
+        for (int i = 0; i < k; ++i) acc = fmaf(feat[i], wr[i], acc);
+        out[(size_t)b * features + n] = acc + lb[n];
+    }
+}
+
+extern "C" int sat_number_embed(const float* values_dev, int32_t count, float min_val, float max_val, const float* pos_weights_dev,
+                                int32_t half_dim, const float* linear_w_dev, const float* linear_b_dev, int32_t features,
+                                float* out_dev, sat_stream_t stream) {
+    SAT_CHECK_ARG(values_dev && pos_weights_dev && linear_w_dev && linear_b_dev && out_dev, SAT_E_INVALID, "number_embed: null pointer");
+    SAT_CHECK_ARG(count > 0 && half_dim > 0 && half_dim <= 4096 && features > 0 && max_val > min_val, SAT_E_INVALID, "number_embed: bad dims");
+    hipLaunchKernelGGL(number_embed_kernel, dim3(count), dim3(256), (2 * half_dim + 1) * sizeof(float), (hipStream_t)stream, values_dev, min_val,
+                       max_val, pos_weights_dev, linear_w_dev, linear_b_dev, out_dev, half_dim, features);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sat_float_to_int16(const float* x_dev, int16_t* out_dev, int64_t n, int32_t maximize, void* scratch_dev,
                                   sat_stream_t stream) {
     SAT_CHECK_ARG(x_dev && out_dev && scratch_dev && n > 0, SAT_E_INVALID, "float_to_int16: bad args");

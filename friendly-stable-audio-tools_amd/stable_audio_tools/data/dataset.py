@@ -1,43 +1,36 @@
-"""``get_audio_filenames`` (reference ``data/dataset.py:24-91``): recursive directory scan."""
+"""``get_audio_filenames`` (reference ``data/dataset.py:24-91``): every audio file below a set of directories.
+
+The reference walks the tree with a hand-rolled recursive ``os.scandir``; ``os.walk`` visits directories in the same
+(directory-listing, depth-first) order and swallows unreadable entries the same way.  File filters as there: extension in
+``exts`` (case-insensitive), not a dot file, and -- only when ``keywords`` are given -- at least one keyword in the lower-cased
+name and no archive artefact (``paxheader`` / ``__macosx``) in it.
+"""
 import os
+
+_ARCHIVE_ARTEFACTS = ("paxheader", "__macosx")
+
+
+def _wanted(name, exts, keywords):
+    lowered = name.lower()
+    if name.startswith(".") or os.path.splitext(lowered)[1] not in exts:
+        return False
+    if keywords is None:
+        return True
+    return any(k in lowered for k in keywords) and not any(a in lowered for a in _ARCHIVE_ARTEFACTS)
 
 
 def fast_scandir(directory, ext, keywords=None):
-    subfolders, files = [], []
-    ext = ["." + x if x[0] != "." else x for x in ext]
-    bad_prefixes = ["."]
+    """-> (all sub-directories, all matching files) below ``directory``."""
+    exts = {e.lower() if e.startswith(".") else "." + e.lower() for e in ext}
     keywords = [k.lower() for k in keywords] if keywords else None
-    banned = ("paxheader", "__macosx")     # only consulted when keywords are given (reference quirk)
-    try:
-        for f in os.scandir(directory):
-            try:
-                if f.is_dir():
-                    subfolders.append(f.path)
-                elif f.is_file():
-                    file_ext = os.path.splitext(f.name)[1].lower()
-                    is_hidden = any(os.path.basename(f.path).startswith(p) for p in bad_prefixes)
-                    has_ext = file_ext in ext
-                    name_lower = f.name.lower()
-                    has_keyword = any(k in name_lower for k in keywords) if keywords else True
-                    has_banned = any(w in name_lower for w in banned) if keywords else False
-                    if has_ext and has_keyword and not is_hidden and not has_banned:
-                        files.append(f.path)
-            except Exception:
-                pass
-    except Exception:
-        pass
-    for d in list(subfolders):
-        sf, f = fast_scandir(d, ext, keywords)
-        subfolders.extend(sf)
-        files.extend(f)
-    return subfolders, files
+    folders, files = [], []
+    for root, dirs, names in os.walk(directory):
+        folders += [os.path.join(root, d) for d in dirs]
+        files += [os.path.join(root, n) for n in names if _wanted(n, exts, keywords)]
+    return folders, files
 
 
 def get_audio_filenames(paths, keywords=None, exts=(".wav", ".mp3", ".flac", ".ogg", ".aif", ".opus")):
-    filenames = []
     if isinstance(paths, str):
         paths = [paths]
-    for p in paths:
-        _, files = fast_scandir(p, list(exts), keywords)
-        filenames.extend(files)
-    return filenames
+    return [f for path in paths for f in fast_scandir(path, list(exts), keywords)[1]]

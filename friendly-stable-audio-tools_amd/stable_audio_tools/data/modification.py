@@ -1,38 +1,42 @@
-"""``PadCrop`` / ``Mono`` / ``Stereo`` (reference ``data/modification.py``); host-side tensor
-reshaping used by ``prepare_audio`` and ``reconstruct_audios.py``."""
+"""Channel / length normalisation of raw audio tensors ``[channels, samples]`` on the host.
+
+Counterparts of ``PadCrop``, ``Mono`` and ``Stereo`` in the reference's ``data/modification.py`` -- same call behaviour (pinned
+by tests/golden/host.npz through ``prepare_audio``), used by ``inference.utils.prepare_audio`` and ``reconstruct_audios.py``.
+"""
 import torch
 from torch import nn
+from torch.nn import functional as F
 
 
 class PadCrop(nn.Module):
-    # reference data/modification.py:11-23
-    def __init__(self, n_samples, randomize=True):
-        super().__init__()
-        self.n_samples = n_samples
-        self.randomize = randomize
+    """Exactly ``n_samples`` samples: a window of the signal (random start if ``randomize``, else the beginning), zero-padded
+    on the right when the signal is shorter."""
 
-    def __call__(self, signal):
-        n, s = signal.shape
-        start = 0 if (not self.randomize) else torch.randint(0, max(0, s - self.n_samples) + 1, []).item()
-        end = start + self.n_samples
-        output = signal.new_zeros([n, self.n_samples])
-        output[:, :min(s, self.n_samples)] = signal[:, start:end]
-        return output
+    def __init__(self, n_samples: int, randomize: bool = True):
+        super().__init__()
+        self.n_samples, self.randomize = n_samples, randomize
+
+    def forward(self, signal: torch.Tensor) -> torch.Tensor:
+        length = signal.shape[-1]
+        surplus = max(length - self.n_samples, 0)
+        first = int(torch.randint(0, surplus + 1, [])) if self.randomize else 0
+        window = signal[:, first:first + self.n_samples]
+        return F.pad(window, (0, self.n_samples - window.shape[-1]))
 
 
 class Mono(nn.Module):
-    def __call__(self, signal):
-        return torch.mean(signal, dim=0, keepdims=True) if len(signal.shape) > 1 else signal
+    """Average the channels of ``[c, s]`` into ``[1, s]``; a bare ``[s]`` signal passes through."""
+
+    def forward(self, signal: torch.Tensor) -> torch.Tensor:
+        return signal if signal.dim() < 2 else signal.mean(dim=0, keepdim=True)
 
 
 class Stereo(nn.Module):
-    def __call__(self, signal):
-        shape = signal.shape
-        if len(shape) == 1:      # s -> 2, s
-            signal = signal.unsqueeze(0).repeat(2, 1)
-        elif len(shape) == 2:
-            if shape[0] == 1:    # 1, s -> 2, s
-                signal = signal.repeat(2, 1)
-            elif shape[0] > 2:   # ?, s -> 2, s
-                signal = signal[:2, :]
+    """Two channels: duplicate a mono signal (``[s]`` or ``[1, s]``), keep the first two channels of anything wider."""
+
+    def forward(self, signal: torch.Tensor) -> torch.Tensor:
+        if signal.dim() == 1:
+            signal = signal[None]
+        if signal.dim() == 2 and signal.shape[0] != 2:
+            signal = signal.expand(2, -1).clone() if signal.shape[0] == 1 else signal[:2]
         return signal

@@ -69,39 +69,36 @@ class ConditionedDiffusionModelWrapper(nn.Module):
         self.min_input_length = min_input_length
 
     def get_conditioning_inputs(self, conditioning_tensors: tp.Dict[str, tp.Any], negative=False):
-        # reference models/diffusion.py:123-203 (tensor bookkeeping only: cat on seq / channel dims)
-        cross_attention_input = cross_attention_masks = global_cond = input_concat_cond = None
-        prepend_cond = prepend_cond_mask = None
-        if len(self.cross_attn_cond_ids) > 0:
-            ins, masks = [], []
-            for key in self.cross_attn_cond_ids:
-                cross_attn_in, cross_attn_mask = conditioning_tensors[key]
-                if len(cross_attn_in.shape) == 2:
-                    cross_attn_in = cross_attn_in.unsqueeze(1)
-                    cross_attn_mask = cross_attn_mask.unsqueeze(1)
-                ins.append(cross_attn_in)
-                masks.append(cross_attn_mask)
-            cross_attention_input = torch.cat(ins, dim=1)
-            cross_attention_masks = torch.cat(masks, dim=1)
-        if len(self.global_cond_ids) > 0:
-            global_cond = torch.cat([conditioning_tensors[key][0] for key in self.global_cond_ids], dim=-1)
-            if len(global_cond.shape) == 3:
+        """Assemble the denoiser's keyword arguments from the per-id ``(tensor, mask)`` pairs (counterpart of the reference's
+        models/diffusion.py:123-203; host-side concatenation only): cross-attention ids are joined along the token axis
+        (per-item vectors [B, C] count as one token), global ids along the channel axis (a singleton token axis is dropped),
+        input-concat ids along channels, prepend ids along tokens."""
+
+        def pairs(ids):
+            return [conditioning_tensors[i] for i in ids]
+
+        def as_tokens(tensor, mask):
+            return (tensor[:, None], mask[:, None]) if tensor.dim() == 2 else (tensor, mask)
+
+        cross = cross_mask = global_cond = concat = prepend = prepend_mask = None
+        if self.cross_attn_cond_ids:
+            tokens = [as_tokens(t, m) for t, m in pairs(self.cross_attn_cond_ids)]
+            cross = torch.cat([t for t, _ in tokens], dim=1)
+            cross_mask = torch.cat([m for _, m in tokens], dim=1)
+        if self.global_cond_ids:
+            global_cond = torch.cat([t for t, _ in pairs(self.global_cond_ids)], dim=-1)
+            if global_cond.dim() == 3:
                 global_cond = global_cond.squeeze(1)
-        if len(self.input_concat_ids) > 0:
-            input_concat_cond = torch.cat([conditioning_tensors[key][0] for key in self.input_concat_ids], dim=1)
-        if len(self.prepend_cond_ids) > 0:
-            conds, cmasks = [], []
-            for key in self.prepend_cond_ids:
-                c, m = conditioning_tensors[key]
-                conds.append(c)
-                cmasks.append(m)
-            prepend_cond = torch.cat(conds, dim=1)
-            prepend_cond_mask = torch.cat(cmasks, dim=1)
-        if negative:
-            return {"negative_cross_attn_cond": cross_attention_input, "negative_cross_attn_mask": cross_attention_masks,
-                    "negative_global_cond": global_cond, "negative_input_concat_cond": input_concat_cond}
-        return {"cross_attn_cond": cross_attention_input, "cross_attn_mask": cross_attention_masks, "global_cond": global_cond,
-                "input_concat_cond": input_concat_cond, "prepend_cond": prepend_cond, "prepend_cond_mask": prepend_cond_mask}
+        if self.input_concat_ids:
+            concat = torch.cat([t for t, _ in pairs(self.input_concat_ids)], dim=1)
+        if self.prepend_cond_ids:
+            prepend = torch.cat([t for t, _ in pairs(self.prepend_cond_ids)], dim=1)
+            prepend_mask = torch.cat([m for _, m in pairs(self.prepend_cond_ids)], dim=1)
+        if negative:       # the negative set has no prepend entries in the reference either (:186-191)
+            return {"negative_cross_attn_cond": cross, "negative_cross_attn_mask": cross_mask, "negative_global_cond": global_cond,
+                    "negative_input_concat_cond": concat}
+        return {"cross_attn_cond": cross, "cross_attn_mask": cross_mask, "global_cond": global_cond, "input_concat_cond": concat,
+                "prepend_cond": prepend, "prepend_cond_mask": prepend_mask}
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, cond: tp.Dict[str, tp.Any], **kwargs):
         return self.model(x, t, **self.get_conditioning_inputs(cond), **kwargs)
@@ -112,38 +109,26 @@ class ConditionedDiffusionModelWrapper(nn.Module):
 
 
 def create_diffusion_cond_from_config(config: tp.Dict[str, tp.Any]):
-    # reference models/diffusion.py:585-655
-    model_config = config["model"]
-    model_type = config["model_type"]
-    diffusion_config = model_config["diffusion"]
-    diffusion_model_type = diffusion_config["type"]
-    diffusion_model_config = diffusion_config["config"]
-    if diffusion_model_type != "dit":
-        raise NotImplementedError(f"diffusion model type '{diffusion_model_type}' is outside this build's hot path (DiT only)")
-    diffusion_model = DiTWrapper(**diffusion_model_config)
-
-    io_channels = model_config["io_channels"]
-    sample_rate = config["sample_rate"]
-    diffusion_objective = diffusion_config.get("diffusion_objective", "v")
-    conditioning_config = model_config.get("conditioning", None)
-    conditioner = None
-    if conditioning_config:
-        conditioner = create_multi_conditioner_from_conditioning_config(conditioning_config)
-    cross_attn_cond_ids = diffusion_config.get("cross_attention_cond_ids", [])
-    global_cond_ids = diffusion_config.get("global_cond_ids", [])
-    input_concat_ids = diffusion_config.get("input_concat_ids", [])
-    prepend_cond_ids = diffusion_config.get("prepend_cond_ids", [])
-    pretransform = model_config.get("pretransform", None)
+    """``model_type`` "diffusion_cond" / "diffusion_cond_inpaint" with a DiT denoiser (counterpart of the reference's
+    models/diffusion.py:585-655): denoiser, conditioner set and (optional) autoencoder pretransform from one config dict."""
+    if config["model_type"] not in ("diffusion_cond", "diffusion_cond_inpaint"):
+        raise NotImplementedError(f"model_type '{config['model_type']}' is outside this build's hot path")
+    model_cfg = config["model"]
+    diffusion_cfg = model_cfg["diffusion"]
+    if diffusion_cfg["type"] != "dit":
+        raise NotImplementedError(f"diffusion model type '{diffusion_cfg['type']}' is outside this build's hot path (DiT only)")
+    denoiser = DiTWrapper(**diffusion_cfg["config"])
+    conditioning = model_cfg.get("conditioning")
+    conditioner = create_multi_conditioner_from_conditioning_config(conditioning) if conditioning else None
+    pretransform = model_cfg.get("pretransform")
     if pretransform:
-        pretransform = create_pretransform_from_config(pretransform, sample_rate)
-        min_input_length = pretransform.downsampling_ratio
-    else:
-        min_input_length = 1
-    min_input_length *= diffusion_model.model.patch_size
-    if model_type not in ("diffusion_cond", "diffusion_cond_inpaint"):
-        raise NotImplementedError(f"model_type '{model_type}' is outside this build's hot path")
-    return ConditionedDiffusionModelWrapper(diffusion_model, conditioner, min_input_length=min_input_length,
-                                            sample_rate=sample_rate, cross_attn_cond_ids=cross_attn_cond_ids,
-                                            global_cond_ids=global_cond_ids, input_concat_ids=input_concat_ids,
-                                            prepend_cond_ids=prepend_cond_ids, pretransform=pretransform, io_channels=io_channels,
-                                            diffusion_objective=diffusion_objective)
+        pretransform = create_pretransform_from_config(pretransform, config["sample_rate"])
+    # shortest input the model accepts: one latent frame (x patch size)
+    min_input_length = (pretransform.downsampling_ratio if pretransform else 1) * denoiser.model.patch_size
+    id_lists = {name: diffusion_cfg.get(key, []) for name, key in (("cross_attn_cond_ids", "cross_attention_cond_ids"),
+                                                                    ("global_cond_ids", "global_cond_ids"),
+                                                                    ("input_concat_ids", "input_concat_ids"),
+                                                                    ("prepend_cond_ids", "prepend_cond_ids"))}
+    return ConditionedDiffusionModelWrapper(denoiser, conditioner, io_channels=model_cfg["io_channels"], sample_rate=config["sample_rate"],
+                                            min_input_length=min_input_length, pretransform=pretransform,
+                                            diffusion_objective=diffusion_cfg.get("diffusion_objective", "v"), **id_lists)

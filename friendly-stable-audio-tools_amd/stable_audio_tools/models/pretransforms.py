@@ -1,51 +1,54 @@
-"""``AutoencoderPretransform`` (reference ``models/pretransforms.py:6-91``)."""
+"""The autoencoder pretransform of a latent diffusion model: audio <-> latents through the HIP Oobleck codec.
+
+Counterpart of the reference's ``models/pretransforms.py:6-91`` (``Pretransform`` / ``AutoencoderPretransform``): same class
+names, constructor arguments and attributes, because ``create_pretransform_from_config``, ``generate_diffusion_cond`` and
+reference checkpoints (key prefix ``pretransform.model.``) rely on them.  The fp16 switch (``model_half``) of the reference has
+no counterpart: the codec kernels store activations in bf16 on their own.
+"""
 from torch import nn
 
 
 class Pretransform(nn.Module):
+    """What a diffusion wrapper needs to know about its pretransform (filled in by the subclass)."""
+
+    encoded_channels = None      # latent channels
+    downsampling_ratio = None    # audio samples per latent frame
+
     def __init__(self, enable_grad: bool, io_channels: int, is_discrete: bool):
         super().__init__()
-        self.is_discrete = is_discrete
-        self.io_channels = io_channels
-        self.encoded_channels = None
-        self.downsampling_ratio = None
-        self.enable_grad = enable_grad
+        self.enable_grad, self.io_channels, self.is_discrete = enable_grad, io_channels, is_discrete
 
     def encode(self, x):
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__} does not encode")
 
     def decode(self, z):
-        raise NotImplementedError
+        raise NotImplementedError(f"{type(self).__name__} does not decode")
 
 
 class AutoencoderPretransform(Pretransform):
+    """Wraps an ``AudioAutoencoder``.  ``scale`` divides the latents on the way in and multiplies them on the way out
+    (pretransforms.py:62, :65); ``chunked`` / ``iterate_batch`` are forwarded to the codec's ``encode_audio`` / ``decode_audio``."""
+
     def __init__(self, model, scale=1.0, model_half=False, iterate_batch=False, chunked=False):
-        super().__init__(enable_grad=False, io_channels=model.io_channels,
-                         is_discrete=model.bottleneck is not None and model.bottleneck.is_discrete)
         if model_half:
             raise NotImplementedError("model_half: the HIP codec already stores activations in bf16; fp16 mode is not provided")
-        self.model = model
-        self.model.requires_grad_(False).eval()
-        self.scale = scale
-        self.downsampling_ratio = model.downsampling_ratio
-        self.io_channels = model.io_channels
-        self.sample_rate = model.sample_rate
-        self.model_half = model_half
-        self.iterate_batch = iterate_batch
-        self.encoded_channels = model.latent_dim
-        self.chunked = chunked
-        self.num_quantizers = None
-        self.codebook_size = None
+        bottleneck = model.bottleneck
+        super().__init__(enable_grad=False, io_channels=model.io_channels, is_discrete=bool(bottleneck is not None and bottleneck.is_discrete))
+        self.model = model.requires_grad_(False).eval()
+        self.scale, self.model_half, self.iterate_batch, self.chunked = scale, False, iterate_batch, chunked
+        for attr, value in (("downsampling_ratio", model.downsampling_ratio), ("sample_rate", model.sample_rate),
+                            ("encoded_channels", model.latent_dim), ("num_quantizers", None), ("codebook_size", None)):
+            setattr(self, attr, value)
+
+    def _codec_options(self, extra):
+        return dict(extra, chunked=self.chunked, iterate_batch=self.iterate_batch)
 
     def encode(self, x, **kwargs):
-        # pretransforms.py:51-62
-        encoded = self.model.encode_audio(x, chunked=self.chunked, iterate_batch=self.iterate_batch, **kwargs)
-        return encoded / self.scale
+        return self.model.encode_audio(x, **self._codec_options(kwargs)) / self.scale
 
     def decode(self, z, **kwargs):
-        # pretransforms.py:64-76
-        z = z * self.scale
-        return self.model.decode_audio(z, chunked=self.chunked, iterate_batch=self.iterate_batch, **kwargs)
+        return self.model.decode_audio(z * self.scale, **self._codec_options(kwargs))
 
     def load_state_dict(self, state_dict, strict=True):
-        self.model.load_state_dict(state_dict, strict=strict)
+        # the checkpoint of a pretransform is the checkpoint of its autoencoder (pretransforms.py:90-91)
+        return self.model.load_state_dict(state_dict, strict=strict)

@@ -270,6 +270,15 @@ int sat_qkv_rope_bf16(const void* a_bf16_dev, const void* w_bf16_dev, const floa
 int sat_snake_beta(const float* x_dev, const float* alpha_dev, const float* beta_dev, float* y_dev,
                    int32_t b, int32_t c, int32_t t, sat_stream_t stream);
 
+/* NumberConditioner.forward (models/conditioners.py:64-102) with its NumberEmbedder (models/adp.py:1495-1514, 680-694):
+ *   x = (clamp(v, min_val, max_val) - min_val) / (max_val - min_val)
+ *   out[b] = Linear(cat(x, sin(2 pi x w), cos(2 pi x w)))     w = embedder.embedding.0.weights [half_dim],
+ *   linear_w = embedder.embedding.1.weight [features, 2*half_dim + 1], linear_b = ...bias [features]
+ * values_dev [count] -> out_dev [count, features] (the caller adds the singleton token axis and the all-ones mask). */
+int sat_number_embed(const float* values_dev, int32_t count, float min_val, float max_val, const float* pos_weights_dev,
+                     int32_t half_dim, const float* linear_w_dev, const float* linear_b_dev, int32_t features, float* out_dev,
+                     sat_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,28 @@ def test_snake_vae_int16(dev):
         assert torch.equal(got, gold[key].to(torch.int16)), f"{key}: differs from the reference's int16 output"
 
 
+def test_number_conditioner_hip(dev):
+    """NumberConditioner on the C ABI (sat_number_embed: clamp, normalise, Fourier features, Linear) against the REFERENCE's output
+    (tests/golden/ops.npz: number_cond, conditioners.py:64-102 run in the build container) and against the oracle on other values."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    from oracle import conditioners as ocond
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.models.conditioners import NumberConditioner
+    nc = NumberConditioner(768, min_val=0, max_val=512)
+    sd = synthetic.synth_state_dict(nc.state_dict(), 1)
+    nc.load_state_dict(sd)
+    nc = nc.to(dev)
+    gold = cases.load("ops")
+    emb, mask = nc([0.0, 47.5, 600.0, -3.0])
+    assert emb.shape == (4, 1, 768) and emb.device.type == "cuda"
+    assert_close("number conditioner vs reference", emb, gold["number_cond"], 1e-5)
+    assert torch.equal(mask.cpu(), gold["number_mask"])
+    vals = [1.25, 511.9, 300.0, 47.0, 0.001]
+    assert_close("number conditioner vs oracle", nc(vals)[0], ocond.number_conditioner(sd, "", vals, 0, 512)[0], 1e-5)
+
+
 def test_cfg_combine_and_sampler_update(dev):
     from oracle import sampler as osamp
     _hip, lib = _lib()

@@ -91,13 +91,20 @@ def test_unsupported_configs_fail_loudly():
 
 
 def test_number_conditioner_and_conditioning_inputs_match_reference():
+    """The oracle's NumberConditioner restatement against the reference's own outputs (ops.npz), and the product's
+    ``get_conditioning_inputs`` (host-side concatenation) fed with oracle-computed conditioner tensors against the reference's
+    (host.npz).  The product's NumberConditioner itself runs on the HIP C ABI: its parity test is
+    tests/test_gpu_kernels.py::test_number_conditioner_hip."""
+    from oracle import conditioners as ocond
     g_ops = cases.load("ops")
     from stable_audio_tools.models.conditioners import NumberConditioner
     nc = NumberConditioner(768, min_val=0, max_val=512)
-    nc.load_state_dict(synthetic.synth_state_dict(nc.state_dict(), 1))
-    emb, mask = nc([0.0, 47.5, 600.0, -3.0])
+    sd = synthetic.synth_state_dict(nc.state_dict(), 1)
+    emb, mask = ocond.number_conditioner(sd, "", [0.0, 47.5, 600.0, -3.0], 0, 512)
     assert rel_l2(emb, g_ops["number_cond"]) < 1e-6 and torch.equal(mask, g_ops["number_mask"])
     assert torch.equal(emb[0], emb[3]), "values are clamped to [min_val, max_val]"
+    with pytest.raises(Exception):          # no CPU path in the product
+        nc([1.0])
 
     g = cases.load("host")
     cfg = MC.stable_audio_open_1_0()
@@ -106,9 +113,10 @@ def test_number_conditioner_and_conditioning_inputs_match_reference():
     cfg["model"]["pretransform"]["config"]["decoder"]["config"]["channels"] = 8
     # the codec is only instantiated here (channels=8 is outside the kernels' supported set; the plan is never built)
     model = S.create_model_from_config(cfg)
-    model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), 4))
+    msd = synthetic.synth_state_dict(model.state_dict(), 4)
     assert model.conditioner.external_ids == []
-    cond = model.conditioner([{"seconds_start": 0, "seconds_total": 47}, {"seconds_start": 3.5, "seconds_total": 700}])
+    meta = [{"seconds_start": 0, "seconds_total": 47}, {"seconds_start": 3.5, "seconds_total": 700}]
+    cond = ocond.multi_conditioner(msd, "conditioner.", ["seconds_start", "seconds_total"], meta)
     cond["prompt"] = [synthetic.synth_input("prompt", (2, 128, 768), 5), torch.ones(2, 128)]
     cond = {k: cond[k] for k in ("prompt", "seconds_start", "seconds_total")}
     ci = model.get_conditioning_inputs(cond)
@@ -119,7 +127,7 @@ def test_number_conditioner_and_conditioning_inputs_match_reference():
     neg = model.get_conditioning_inputs(cond, negative=True)
     assert set(neg) == {"negative_cross_attn_cond", "negative_cross_attn_mask", "negative_global_cond", "negative_input_concat_cond"}
     with pytest.raises(ValueError):
-        model.conditioner([{"seconds_start": 0}])
+        model.conditioner([{"seconds_total": 5}])        # the first conditioner (seconds_start) finds no entry
     full = S.create_model_from_config(MC.reduced(MC.stable_audio_open_1_0(with_text_encoder=True)))
     assert full.conditioner.external_ids == ["prompt"]
 

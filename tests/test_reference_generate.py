@@ -38,10 +38,16 @@ def _model(dev=None):
     return cfg, model.eval(), sd
 
 
-def _cond(cfg, model, dev="cpu"):
+def _cond(cfg, model, dev="cpu", sd=None):
+    """CPU: the oracle's number conditioners over the state dict; GPU: the product's (HIP) conditioner."""
     dc = cfg["model"]["diffusion"]["config"]
     b = 2
-    cond = model.conditioner([{"seconds_start": 0, "seconds_total": 10 + i} for i in range(b)])
+    meta = [{"seconds_start": 0, "seconds_total": 10 + i} for i in range(b)]
+    if str(dev) == "cpu":
+        from oracle import conditioners as ocond
+        cond = ocond.multi_conditioner(sd, "conditioner.", ["seconds_start", "seconds_total"], meta)
+    else:
+        cond = model.conditioner(meta)
     cond["prompt"] = [synthetic.synth_input("prompt", (b, 128, dc["cond_token_dim"]), 31).to(dev), torch.ones(b, 128, device=dev)]
     return {k: cond[k] for k in ("prompt", "seconds_start", "seconds_total")}
 
@@ -64,7 +70,7 @@ def test_oracle_generate_matches_reference(name):
     from oracle import generate as ogen
     gold = cases.load("generate")
     cfg, model, sd = _model()
-    ci = model.get_conditioning_inputs(_cond(cfg, model))
+    ci = model.get_conditioning_inputs(_cond(cfg, model, sd=sd))
     kw = dict(cases.GEN["calls"][name])
     ratio = cfg["model"]["pretransform"]["config"]["downsampling_ratio"]
     like = _draws(gold, name, "randn_like")
@@ -88,7 +94,7 @@ def test_oracle_sample_k_matches_reference(name):
     gold = cases.load("generate")
     cfg, model, sd = _model()
     dc = cfg["model"]["diffusion"]["config"]
-    ci = model.get_conditioning_inputs(_cond(cfg, model))
+    ci = model.get_conditioning_inputs(_cond(cfg, model, sd=sd))
     kw = dict(cases.GEN["sample_k"][name])
     b, t_len = 2, cases.GEN["t_len"]
     noise = synthetic.synth_input("noise_" + name, (b, 64, t_len), 63)
