@@ -477,6 +477,45 @@ extern "C" int sat_vae_sample(const float* mean_scale_dev, const float* noise_de
     return 0;
 }
 
+// Overlap-add of the chunked codec (models/autoencoders.py:476-497, 548-571, 622-645): chunk i of length L starts at i * hop; its
+// first `ov` samples are faded in (window[0 .. ov)) unless it is the first chunk, its last `ov` samples faded out (window[ov .. 2 ov))
+// unless it is the last one; contributions are summed in chunk order.  One thread per output sample, gather form (no atomics).
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ pieces, const float* __restrict__ window,
+                                                          float* __restrict__ out, int n_chunk, int C, int L, int hop, int ov, int total,
+                                                          int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int t = (int)(idx % total);
+    const int64_t bc = idx / total;
+    const int c = (int)(bc % C);
+    const int64_t b = bc / C;
+    int i_hi = t / hop;
+    if (i_hi > n_chunk - 1) i_hi = n_chunk - 1;
+    int i_lo = t - L + 1 <= 0 ? 0 : (t - L + hop) / hop;           // ceil((t - L + 1) / hop)
+    float acc = 0.f;
+    for (int i = i_lo; i <= i_hi; ++i) {
+        const int off = t - i * hop;
+        if (off < 0 || off >= L) continue;
+        float v = pieces[((b * n_chunk + i) * C + c) * (int64_t)L + off];
+        if (i != 0 && off < ov) v *= window[off];
+        if (i != n_chunk - 1 && off >= L - ov) v *= window[ov + off - (L - ov)];
+        acc += v;
+    }
+    out[idx] = acc;
+}
+
+extern "C" int sat_overlap_add(const float* pieces_dev, const float* window_dev, float* out_dev, int32_t batch, int32_t n_chunk,
+                               int32_t channels, int32_t chunk_len, int32_t hop, int32_t overlap, int32_t total_len, sat_stream_t stream) {
+    SAT_CHECK_ARG(pieces_dev && window_dev && out_dev, SAT_E_INVALID, "overlap_add: null pointer");
+    SAT_CHECK_ARG(batch > 0 && n_chunk > 0 && channels > 0 && chunk_len > 0 && hop > 0 && overlap >= 0 && overlap <= chunk_len && total_len > 0,
+                  SAT_E_INVALID, "overlap_add: bad dims");
+    const int64_t n = (int64_t)batch * channels * total_len;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, pieces_dev, window_dev, out_dev, n_chunk, channels,
+                       chunk_len, hop, overlap, total_len, n);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 // NumberConditioner (models/conditioners.py:64-102) = clamp -> (x - min) / (max - min) -> NumberEmbedder (models/adp.py:1495-1514):
 // LearnedPositionalEmbedding cat(x, sin(2 pi x w), cos(2 pi x w)) (adp.py:680-694) -> Linear(2*half + 1, features).  A handful of
 // scalars per generation: one workgroup per value, the 2*half + 1 features in LDS, one output channel per thread and pass.

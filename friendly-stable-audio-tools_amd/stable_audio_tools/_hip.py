@@ -79,6 +79,7 @@ _SIGNATURES = {
     "sat_qkv_rope_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                     c_int32, c_int32, c_int32, c_void_p]),
     "sat_snake_beta": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "sat_overlap_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "sat_number_embed": (c_int32, [c_void_p, c_int32, c_float, c_float, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
 }
 

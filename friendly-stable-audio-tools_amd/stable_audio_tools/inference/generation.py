@@ -11,6 +11,31 @@ from .sampling import sample_k, sample_rf
 from .utils import prepare_audio
 
 
+def _init_latents(model, init_audio, audio_length, num_sample, device):
+    """(sample_rate, waveform) -> init tensor in the domain the denoiser works in, one copy per batch item (generation.py:170-188).
+    With a pretransform this samples the VAE bottleneck once: the second Gaussian draw after the initial noise."""
+    in_sr, waveform = init_audio
+    channels = model.pretransform.io_channels if model.pretransform else model.io_channels
+    init = prepare_audio(waveform, in_sr=in_sr, target_sr=model.sample_rate, target_length=audio_length, target_channels=channels,
+                         device=device)
+    if model.pretransform:
+        init = model.pretransform.encode(init)
+    return init.repeat(num_sample, 1, 1)
+
+
+def _cut_and_paste(init, mask_args, length):
+    """Out-painting layout (generation.py:195-209): the span of the init data that starts at ``cropfrom`` % is pasted at
+    ``pastefrom`` % .. ``pasteto`` % of an otherwise empty canvas (shortened if it would run past the end of the source)."""
+    crop_from = math.floor(mask_args["cropfrom"] / 100.0 * length)
+    paste_from = math.floor(mask_args["pastefrom"] / 100.0 * length)
+    paste_to = math.ceil(mask_args["pasteto"] / 100.0 * length)
+    assert paste_from < paste_to, "Paste From should be less than Paste To"
+    span = min(paste_to - paste_from, length - crop_from)
+    canvas = torch.zeros_like(init)
+    canvas[:, :, paste_from:paste_from + span] = init[:, :, crop_from:crop_from + span]
+    return canvas
+
+
 @torch.no_grad()
 def generate_diffusion_cond(model, steps: int = 250, cfg_scale: float = 6, conditioning: tp.Optional[tp.List[dict]] = None,
                             conditioning_tensors: tp.Optional[dict] = None, negative_conditioning: tp.Optional[tp.List[dict]] = None,
@@ -18,73 +43,46 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale: float = 6, condi
                             device: str = "cuda", init_audio: tp.Optional[tp.Tuple[int, torch.Tensor]] = None,
                             init_noise_level: float = 1.0, mask_args: dict = None, return_latents: bool = False,
                             disable_tqdm: bool = False, noise: tp.Optional[torch.Tensor] = None, **sampler_kwargs) -> torch.Tensor:
-    """``noise=`` (build extension) overrides the initial Gaussian draw, for parity tests."""
+    """Same arguments, Gaussian-draw order (seed -> initial noise -> VAE noise of the init audio -> sampler draws) and return value
+    as the reference's generation.py:95-261: audio ``[B, channels, sample_size]`` (or latents with ``return_latents``).
+    ``noise=`` (build extension) overrides the initial draw, for parity tests.  Pinned against the reference's own runs by
+    tests/test_reference_generate.py."""
     if model.conditioner is not None:
         model.conditioner.set_device(device)
-    audio_sample_size = sample_size
-    if model.pretransform:
-        sample_size //= model.pretransform.downsampling_ratio          # generation.py:139-140
-
     assert conditioning or conditioning_tensors, "Must provide either conditioning or conditioning_tensors"
-    if conditioning_tensors is None:
-        conditioning_tensors = model.conditioner(conditioning)
-    conditioning_inputs = model.get_conditioning_inputs(conditioning_tensors)
-
     if negative_conditioning or negative_conditioning_tensors:
         # The reference overwrites negative_conditioning_tensors with {} before testing it
         # (generation.py:148-155), so negative prompts raise KeyError there; refuse loudly instead.
         raise NotImplementedError("negative conditioning is broken in the reference API (generation.py:148-155) and not offered here")
+    if conditioning_tensors is None:
+        conditioning_tensors = model.conditioner(conditioning)
+    cond_inputs = {k: (None if v is None else v.float()) for k, v in model.get_conditioning_inputs(conditioning_tensors).items()}
+    num_sample = next(iter(conditioning_tensors.values()))[0].shape[0]           # batch size = that of the first conditioning tensor
 
-    num_sample = list(conditioning_tensors.values())[0][0].shape[0]    # generation.py:158
+    ratio = model.pretransform.downsampling_ratio if model.pretransform else 1
+    length = sample_size // ratio                                                # what the denoiser sees (latent frames)
 
-    seed = seed if seed != -1 else np.random.randint(0, 2**32 - 1, dtype=np.uint32)
-    torch.manual_seed(int(seed))
-    if noise is None:
-        noise = torch.randn([num_sample, model.io_channels, sample_size], device=device)
-    else:
-        noise = noise.to(device)
+    torch.manual_seed(int(seed if seed != -1 else np.random.randint(0, 2**32 - 1, dtype=np.uint32)))
+    noise = torch.randn([num_sample, model.io_channels, length], device=device) if noise is None else noise.to(device)
 
+    init, mask = None, None
     if init_audio is not None:
-        in_sr, init_audio = init_audio
-        io_channels = model.pretransform.io_channels if model.pretransform else model.io_channels
-        init_audio = prepare_audio(init_audio, in_sr=in_sr, target_sr=model.sample_rate, target_length=audio_sample_size,
-                                   target_channels=io_channels, device=device)
-        if model.pretransform:
-            init_audio = model.pretransform.encode(init_audio)         # samples the VAE (SURVEY F12)
-        init_audio = init_audio.repeat(num_sample, 1, 1)
-    else:
-        init_audio = None
-        init_noise_level = None
-        mask_args = None
+        init = _init_latents(model, init_audio, sample_size, num_sample, device)
+        if mask_args is not None:                       # in-/out-painting: generation.py:195-213
+            init = _cut_and_paste(init, mask_args, length)
+            mask = build_mask(length, mask_args).to(device)
+        else:                                           # variation: start from init + noise at init_noise_level (generation.py:214-217)
+            sampler_kwargs["sigma_max"] = init_noise_level
 
-    mask = None
-    if init_audio is not None and mask_args is not None:
-        # inpainting / outpainting (generation.py:195-213), in latent units: cut & paste the init latents, then the soft mask
-        cropfrom = math.floor(mask_args["cropfrom"] / 100.0 * sample_size)
-        pastefrom = math.floor(mask_args["pastefrom"] / 100.0 * sample_size)
-        pasteto = math.ceil(mask_args["pasteto"] / 100.0 * sample_size)
-        assert pastefrom < pasteto, "Paste From should be less than Paste To"
-        croplen = min(pasteto - pastefrom, sample_size - cropfrom)
-        cutpaste = init_audio.new_zeros(init_audio.shape)
-        cutpaste[:, :, pastefrom:pastefrom + croplen] = init_audio[:, :, cropfrom:cropfrom + croplen]
-        init_audio = cutpaste
-        mask = build_mask(sample_size, mask_args).to(device)
-    elif init_audio is not None:
-        sampler_kwargs["sigma_max"] = init_noise_level                 # variations: generation.py:214-217
-
-    conditioning_inputs = {k: (v.float() if v is not None else v) for k, v in conditioning_inputs.items()}
-
+    shared = dict(cfg_scale=cfg_scale, batch_cfg=True, rescale_cfg=True, device=device, disable_tqdm=disable_tqdm)
     if model.diffusion_objective == "v":
-        sampled = sample_k(model.model, noise, init_audio, mask, steps, **sampler_kwargs, **conditioning_inputs, cfg_scale=cfg_scale,
-                           batch_cfg=True, rescale_cfg=True, device=device, disable_tqdm=disable_tqdm)
+        sampled = sample_k(model.model, noise, init, mask, steps, **sampler_kwargs, **cond_inputs, **shared)
     elif model.diffusion_objective == "rectified_flow":                # generation.py:235-244
-        sampler_kwargs.pop("sigma_min", None)
-        sampler_kwargs.pop("sampler_type", None)
-        sampled = sample_rf(model.model, noise, init_data=init_audio, steps=steps, **sampler_kwargs, **conditioning_inputs,
-                            cfg_scale=cfg_scale, batch_cfg=True, rescale_cfg=True, device=device, disable_tqdm=disable_tqdm)
+        for k_diffusion_only in ("sigma_min", "sampler_type"):
+            sampler_kwargs.pop(k_diffusion_only, None)
+        sampled = sample_rf(model.model, noise, init_data=init, steps=steps, **sampler_kwargs, **cond_inputs, **shared)
     else:
         raise ValueError(f"unknown diffusion objective {model.diffusion_objective}")
-
     if model.pretransform and not return_latents:
         sampled = model.pretransform.decode(sampled)
     return sampled

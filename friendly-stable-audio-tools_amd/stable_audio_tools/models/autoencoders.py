@@ -282,91 +282,70 @@ class AudioAutoencoder(nn.Module):
                              target_channels=self.in_channels, device=a.device).squeeze(0) for a in new_audio]
         return torch.stack(out)
 
-    # autoencoders.py:410-497
+    # ------------------------------------------------------------------ chunked paths (autoencoders.py:410-645)
+    # The reference spells chunking + cross-fade out three times (encode_audio, decode_audio, reconstruct_audio).  Here they share
+    # one driver: cut the (padded) input into overlapping chunks, run the codec on batches of at most `max_batch_size` chunks,
+    # overlap-add the results with a Bartlett cross-fade (one HIP kernel, sat_overlap_add) and crop.
+    def _run_chunked(self, x, fn, in_chunk, in_hop, n_chunk, out_hop, out_overlap, max_batch_size, keep):
+        bs, channels = x.shape[0], x.shape[1]
+        chunks = torch.stack([x[..., i * in_hop: i * in_hop + in_chunk] for i in range(n_chunk)], dim=1)
+        chunks = chunks.reshape(bs * n_chunk, channels, in_chunk)
+        pieces = torch.cat([fn(chunks[i: i + max_batch_size]) for i in range(0, chunks.shape[0], max_batch_size)], dim=0)
+        out_ch, out_chunk = pieces.shape[1], pieces.shape[2]
+        pieces = pieces.reshape(bs, n_chunk, out_ch, out_chunk).float().contiguous()
+        total = out_hop * (n_chunk - 1) + out_chunk
+        window = torch.bartlett_window(max(out_overlap, 1) * 2, device=x.device).float().contiguous()     # (unused when overlap == 0)
+        out = torch.empty((bs, out_ch, total), dtype=torch.float32, device=x.device)
+        _hip.check(_hip.lib().sat_overlap_add(_hip.ptr(pieces), _hip.ptr(window), _hip.ptr(out), bs, n_chunk, out_ch, out_chunk, out_hop,
+                                              out_overlap, total, _hip.stream()))
+        return out[..., :keep]
+
+    @staticmethod
+    def _n_chunks(length, chunk, hop):
+        return int(math.ceil((length - chunk) / hop)) + 1
+
     def encode_audio(self, audio, chunked=False, chunk_size=128, overlap=4, max_batch_size=1, **kwargs):
-        bs, n_ch, sample_length = audio.shape
+        """Audio [B, C, L] (L a multiple of the compression ratio) -> latents; ``chunked``: windows of ``chunk_size`` latent frames
+        overlapping by ``overlap`` frames, zero-padded at the end, cross-faded in the latent domain."""
+        _, n_ch, length = audio.shape
         ratio = self.downsampling_ratio
         assert n_ch == self.in_channels
-        assert sample_length % ratio == 0, "The audio length must be a multiple of compression ratio."
+        assert length % ratio == 0, "The audio length must be a multiple of compression ratio."
         if not chunked:
             return self.encode(audio, **kwargs)
-        latent_length = sample_length // ratio
-        chunk_l, overlap_l, hop_l = chunk_size, overlap, chunk_size - overlap
-        win = torch.bartlett_window(overlap * 2, device=audio.device)
         chunk_s, hop_s = chunk_size * ratio, (chunk_size - overlap) * ratio
-        n_chunk = int(math.ceil((sample_length - chunk_s) / hop_s)) + 1
-        pad_len = chunk_s + hop_s * (n_chunk - 1) - sample_length
-        audio = F.pad(audio, (0, pad_len))
-        chunks = torch.stack([audio[..., i * hop_s: i * hop_s + chunk_s] for i in range(n_chunk)], dim=1)
-        chunks = chunks.reshape(bs * n_chunk, n_ch, chunk_s)
-        zs = torch.cat([self.encode(chunks[i: i + max_batch_size]) for i in range(0, chunks.shape[0], max_batch_size)], dim=0)
-        zs = zs.reshape(bs, n_chunk, zs.shape[1], zs.shape[2])
-        latents = torch.zeros((bs, self.latent_dim, audio.shape[-1] // ratio), device=audio.device)
-        for i in range(n_chunk):
-            z_ = zs[:, i]
-            if i != 0:
-                z_[:, :, :overlap_l] *= win[None, None, :overlap_l]
-            if i != n_chunk - 1:
-                z_[:, :, -overlap_l:] *= win[None, None, -overlap_l:]
-            latents[..., i * hop_l: i * hop_l + chunk_l] += z_
-        return latents[..., :latent_length]
+        n_chunk = self._n_chunks(length, chunk_s, hop_s)
+        audio = F.pad(audio, (0, chunk_s + hop_s * (n_chunk - 1) - length))
+        return self._run_chunked(audio, self.encode, chunk_s, hop_s, n_chunk, chunk_size - overlap, overlap, max_batch_size, length // ratio)
 
-    # autoencoders.py:499-571
     def decode_audio(self, latents, chunked=False, chunk_size=128, overlap=4, max_batch_size=1, **kwargs):
-        bs, latent_dim, latent_length = latents.shape
+        """Latents [B, latent_dim, T] -> audio; ``chunked``: the latents are reflect-padded to a whole number of hops and the decoded
+        windows cross-faded over ``overlap`` frames' worth of samples."""
+        _, latent_dim, t_len = latents.shape
         ratio = self.downsampling_ratio
         assert latent_dim == self.latent_dim
         if not chunked:
             return self.decode(latents, **kwargs)
         hop = chunk_size - overlap
-        chunk_s, overlap_s, hop_s = chunk_size * ratio, overlap * ratio, hop * ratio
-        win = torch.bartlett_window(overlap_s * 2, device=latents.device)
-        n_chunk = int(math.ceil((latent_length - chunk_size) / hop)) + 1
-        pad_len = chunk_size + hop * (n_chunk - 1) - latent_length
-        latents = F.pad(latents, (0, pad_len), mode="reflect")
-        chunks = torch.stack([latents[..., i * hop: i * hop + chunk_size] for i in range(n_chunk)], dim=1)
-        chunks = chunks.reshape(bs * n_chunk, latent_dim, chunk_size)
-        xs = torch.cat([self.decode(chunks[i: i + max_batch_size]) for i in range(0, chunks.shape[0], max_batch_size)], dim=0)
-        xs = xs.reshape(bs, n_chunk, xs.shape[1], xs.shape[2])
-        audios = torch.zeros((bs, xs.shape[2], latents.shape[-1] * ratio), device=latents.device)
-        for i in range(n_chunk):
-            x_ = xs[:, i]
-            if i != 0:
-                x_[:, :, :overlap_s] *= win[None, None, :overlap_s]
-            if i != n_chunk - 1:
-                x_[:, :, -overlap_s:] *= win[None, None, -overlap_s:]
-            audios[..., i * hop_s: i * hop_s + chunk_s] += x_
-        return audios[..., :latent_length * ratio]
+        n_chunk = self._n_chunks(t_len, chunk_size, hop)
+        latents = F.pad(latents, (0, chunk_size + hop * (n_chunk - 1) - t_len), mode="reflect")
+        return self._run_chunked(latents, self.decode, chunk_size, hop, n_chunk, hop * ratio, overlap * ratio, max_batch_size, t_len * ratio)
 
-    # autoencoders.py:573-645 (pad_len uses n_chunk, not n_chunk-1: reference quirk kept, :604)
     @torch.no_grad()
     def reconstruct_audio(self, audio, chunked=True, chunk_size=128, overlap=4, max_batch_size=1, **kwargs):
-        bs, n_ch, sample_length = audio.shape
+        """encode -> decode per window, cross-faded in the audio domain.  The reference pads with one hop more than the windows
+        it then takes (``hop * n_chunk``, autoencoders.py:604); the crop below makes that invisible and it is kept as is."""
+        _, n_ch, length = audio.shape
         ratio = self.downsampling_ratio
         assert n_ch == self.in_channels
         if not chunked:
             return self.decode(self.encode(audio, **kwargs), **kwargs)
-        overlap_s = overlap * ratio
-        win = torch.bartlett_window(overlap_s * 2, device=audio.device)
-        chunk_s = chunk_size * ratio
+        chunk_s, overlap_s = chunk_size * ratio, overlap * ratio
         hop_s = chunk_s - overlap_s
-        n_chunk = int(math.ceil((sample_length - chunk_s) / hop_s)) + 1
-        pad_len = chunk_s + hop_s * n_chunk - sample_length
-        audio = F.pad(audio, (0, pad_len))
-        chunks = torch.stack([audio[..., i * hop_s: i * hop_s + chunk_s] for i in range(n_chunk)], dim=1)
-        chunks = chunks.reshape(bs * n_chunk, n_ch, chunk_s)
-        xs = torch.cat([self.decode(self.encode(chunks[i: i + max_batch_size], **kwargs))
-                        for i in range(0, chunks.shape[0], max_batch_size)], dim=0)
-        xs = xs.reshape(bs, n_chunk, xs.shape[1], xs.shape[2])
-        rec = torch.zeros((bs, xs.shape[2], audio.shape[-1]), device=audio.device)
-        for i in range(n_chunk):
-            x_ = xs[:, i]
-            if i != 0:
-                x_[:, :, :overlap_s] *= win[None, None, :overlap_s]
-            if i != n_chunk - 1:
-                x_[:, :, -overlap_s:] *= win[None, None, -overlap_s:]
-            rec[:, :, i * hop_s: i * hop_s + chunk_s] += x_
-        return rec[..., :sample_length]
+        n_chunk = self._n_chunks(length, chunk_s, hop_s)
+        audio = F.pad(audio, (0, chunk_s + hop_s * n_chunk - length))
+        codec = lambda chunk: self.decode(self.encode(chunk, **kwargs))
+        return self._run_chunked(audio, codec, chunk_s, hop_s, n_chunk, hop_s, overlap_s, max_batch_size, length)
 
 
 # ---------------------------------------------------------------------------------- factories (autoencoders.py:695-787)

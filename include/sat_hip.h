@@ -270,6 +270,13 @@ int sat_qkv_rope_bf16(const void* a_bf16_dev, const void* w_bf16_dev, const floa
 int sat_snake_beta(const float* x_dev, const float* alpha_dev, const float* beta_dev, float* y_dev,
                    int32_t b, int32_t c, int32_t t, sat_stream_t stream);
 
+/* Windowed overlap-add of the chunked codec paths, AudioAutoencoder.encode_audio / decode_audio / reconstruct_audio
+ * (models/autoencoders.py:476-497, 548-571, 622-645): pieces_dev [batch, n_chunk, channels, chunk_len], chunk i placed at i * hop,
+ * faded in / out over `overlap` samples with window_dev [2 * overlap] (torch.bartlett_window(2 * overlap)) except at the outer
+ * edges of the first / last chunk -> out_dev [batch, channels, total_len] (every sample written). */
+int sat_overlap_add(const float* pieces_dev, const float* window_dev, float* out_dev, int32_t batch, int32_t n_chunk, int32_t channels,
+                    int32_t chunk_len, int32_t hop, int32_t overlap, int32_t total_len, sat_stream_t stream);
+
 /* NumberConditioner.forward (models/conditioners.py:64-102) with its NumberEmbedder (models/adp.py:1495-1514, 680-694):
  *   x = (clamp(v, min_val, max_val) - min_val) / (max_val - min_val)
  *   out[b] = Linear(cat(x, sin(2 pi x w), cos(2 pi x w)))     w = embedder.embedding.0.weights [half_dim],
