@@ -73,7 +73,7 @@ __global__ void fold_in_kernel(const float* __restrict__ Win, const float* __res
     int n = i / C, c = i - n * C;
     float acc = Win[i];
     for (int j = 0; j < C; ++j) acc += Win[n * C + j] * Wpre[j * C + c];
-    Weff[i] = acc;
+    Weff[(size_t)c * D + n] = acc;          // stored transposed, [C][D]: the input projection reads it with lane = n
 }
 // WeffT[n][c] = Wout[c][n] + sum_j Wpost[c][j] * Wout[j][n]   ((I + postprocess_conv) o project_out), stored [D][C]
 __global__ void fold_out_kernel(const float* __restrict__ Wout, const float* __restrict__ Wpost, float* __restrict__ WeffT, int D, int C) {
@@ -99,8 +99,10 @@ __global__ __launch_bounds__(256) void adaln_finish_kernel(float* __restrict__ s
 
 // (S - T = number of prepended rows: 1 for global_cond_type 'prepend', 0 for 'adaLN')
 // X[b, (S-T)+t, n] = xscale * sum_c Weff[n][c] * x[b % xB][c][t]       (C <= 64)
+// Lane = output channel n; the folded weight is read TRANSPOSED (WeffT[c][n], built once per plan): consecutive lanes read
+// consecutive floats.  16 tokens per workgroup share one pass over the weights; stores are row-contiguous.
 constexpr int IP_TT = 8;
-__global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ Weff,
+__global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ WeffT,
                                                          float* __restrict__ X, int xB, int C, int T, int S, int D, float xscale) {
     __shared__ float xs[64][IP_TT];
     const int b = blockIdx.y;
@@ -116,11 +118,20 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
         float acc[IP_TT];
 #pragma unroll
         for (int tt = 0; tt < IP_TT; ++tt) acc[tt] = 0.f;
-        const float* wr = Weff + (size_t)n * C;
-        for (int c = 0; c < C; ++c) {
-            float w = wr[c];
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            float w[16];                                   // 16 independent coalesced loads in flight
 #pragma unroll
-            for (int tt = 0; tt < IP_TT; ++tt) acc[tt] += w * xs[c][tt];
+            for (int u = 0; u < 16; ++u) w[u] = (c0 + u < C) ? WeffT[(size_t)(c0 + u) * D + n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int q = 0; q < IP_TT / 4; ++q) {
+                    const float4 xv = *reinterpret_cast<const float4*>(&xs[(c0 + u) & 63][q * 4]);      // LDS broadcast
+                    acc[q * 4] += w[u] * xv.x;
+                    acc[q * 4 + 1] += w[u] * xv.y;
+                    acc[q * 4 + 2] += w[u] * xv.z;
+                    acc[q * 4 + 3] += w[u] * xv.w;
+                }
         }
 #pragma unroll
         for (int tt = 0; tt < IP_TT; ++tt) {
@@ -130,56 +141,59 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
     }
 }
 
-// out[b][c][t] = sum_n WeffT[n][c] * X[b, 1+t, n].  Lane = output channel (C <= 64): the weight row WeffT[n][:] is one
-// coalesced 256-B read shared by the whole workgroup through L1, x[n] is an LDS broadcast; OP_ROWS rows per wave.
-constexpr int OP_ROWS = 1;
-__global__ __launch_bounds__(256) void output_proj_kernel(const float* __restrict__ X, const float* __restrict__ WeffT,
+// out[b][c][t] = sum_n WeffT[n][c] * X[b, (S-T)+t, n].  16 tokens per workgroup: their rows of X are staged in LDS once, the four
+// waves split the D input channels (each streams a quarter of the weights, lane = output channel: coalesced 256-byte rows, 4 rows in
+// flight), partial sums meet in LDS and are written with 16 consecutive time steps per channel (64-byte runs of out[b][c][:]).
+constexpr int OP_TOK = 16;
+__global__ __launch_bounds__(512) void output_proj_kernel(const float* __restrict__ X, const float* __restrict__ WeffT,
                                                           float* __restrict__ out, int Bf, int C, int T, int S, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem_op[];
-    float* xs = reinterpret_cast<float*>(smem_op);          // [4 waves * OP_ROWS][D]
+    float* xs = reinterpret_cast<float*>(smem_op);          // [OP_TOK][D]
+    float* red = xs + (size_t)OP_TOK * D;                   // [8 waves][OP_TOK][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * 4 + wave) * OP_ROWS;
+    const int tok0 = blockIdx.x * OP_TOK;                   // token index b * T + t
     const int total = Bf * T;
-    float* xw = xs + (size_t)wave * OP_ROWS * D;
-#pragma unroll
-    for (int r = 0; r < OP_ROWS; ++r) {
-        int row = row0 + r;
+    for (int i = threadIdx.x; i < OP_TOK * (D / 4); i += 512) {
+        const int tk = i / (D / 4), q = i - tk * (D / 4);
+        int row = tok0 + tk;
         row = row < total ? row : total - 1;
         const int b = row / T, t = row - b * T;
-        const float4* src = reinterpret_cast<const float4*>(X + ((size_t)b * S + (S - T) + t) * D);
-        float4* dst = reinterpret_cast<float4*>(xw + (size_t)r * D);
-        for (int i = lane; i < D / 4; i += 64) dst[i] = src[i];
+        reinterpret_cast<float4*>(xs + (size_t)tk * D)[q] = reinterpret_cast<const float4*>(X + ((size_t)b * S + (S - T) + t) * D)[q];
     }
     __syncthreads();
     const int c = lane < C ? lane : C - 1;
-    float acc[OP_ROWS];
+    float acc[OP_TOK];
 #pragma unroll
-    for (int r = 0; r < OP_ROWS; ++r) acc[r] = 0.f;
-    // 16 independent weight loads in flight per lane (the loop is L2-latency bound otherwise)
-    for (int n = 0; n < D; n += 16) {
-        float w[16];
+    for (int tk = 0; tk < OP_TOK; ++tk) acc[tk] = 0.f;
+    const int nq = D / 8;                                   // input channels per wave (D % 128 == 0)
+    for (int n0 = wave * nq; n0 < (wave + 1) * nq; n0 += 16) {
+        float w[16];                                        // 16 weight rows (coalesced 256-byte reads) in flight
 #pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = WeffT[(size_t)(n + u) * C + c];
+        for (int u = 0; u < 16; ++u) w[u] = WeffT[(size_t)(n0 + u) * C + c];
 #pragma unroll
-        for (int r = 0; r < OP_ROWS; ++r) {
+        for (int u4 = 0; u4 < 4; ++u4)
 #pragma unroll
-            for (int u4 = 0; u4 < 4; ++u4) {
-                float4 xv = *reinterpret_cast<const float4*>(xw + (size_t)r * D + n + u4 * 4);
-                acc[r] += (w[u4 * 4] * xv.x + w[u4 * 4 + 1] * xv.y) + (w[u4 * 4 + 2] * xv.z + w[u4 * 4 + 3] * xv.w);
+            for (int tk = 0; tk < OP_TOK; ++tk) {
+                const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)tk * D + n0 + u4 * 4);
+                acc[tk] += (w[u4 * 4] * xv.x + w[u4 * 4 + 1] * xv.y) + (w[u4 * 4 + 2] * xv.z + w[u4 * 4 + 3] * xv.w);
             }
-        }
     }
-    if (lane < C) {
 #pragma unroll
-        for (int r = 0; r < OP_ROWS; ++r) {
-            int row = row0 + r;
-            if (row < total) {
-                const int b = row / T, t = row - b * T;
-                out[((size_t)b * C + lane) * T + t] = acc[r];
-            }
+    for (int tk = 0; tk < OP_TOK; ++tk) red[(wave * OP_TOK + tk) * 64 + lane] = acc[tk];
+    __syncthreads();
+    for (int i = threadIdx.x; i < OP_TOK * 64; i += 512) {
+        const int ch = i / OP_TOK, tk = i - ch * OP_TOK;    // 16 consecutive threads = 16 consecutive time steps of one channel
+        const int row = tok0 + tk;
+        if (ch < C && row < total) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) v += red[(wv * OP_TOK + tk) * 64 + ch];
+            const int b = row / T, t = row - b * T;
+            out[((size_t)b * C + ch) * T + t] = v;
         }
     }
 }
+
 
 // CFG combine (models/dit.py:338-339) + VDenoiser without the std rescale: pure elementwise, one thread per element
 __global__ __launch_bounds__(256) void cfg_denoise_ew_kernel(const float* __restrict__ mo, const float* __restrict__ x,
@@ -351,9 +365,10 @@ int glue_input_proj(const float* x, const float* Weff, float* X, int Bf, int xB,
 
 int glue_output_proj(const float* X, const float* WeffT, float* out, int Bf, int C, int T, int S, int D, hipStream_t s) {
     SAT_CHECK_ARG(C <= 64 && D % 16 == 0, SAT_E_UNSUPPORTED, "output_proj: C=%d D=%d unsupported", C, D);
-    const int lds = 4 * OP_ROWS * D * 4;
+    const int lds = (OP_TOK * D + 8 * OP_TOK * 64) * 4;
+    SAT_CHECK_ARG(lds <= 160 * 1024 && D % 128 == 0, SAT_E_UNSUPPORTED, "output_proj: embed_dim %d unsupported (multiple of 128, <= 2048)", D);
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(output_proj_kernel), 160 * 1024));
-    hipLaunchKernelGGL(output_proj_kernel, dim3(cdiv((int64_t)Bf * T, 4 * OP_ROWS)), dim3(256), lds, s, X, WeffT, out, Bf, C, T, S, D);
+    hipLaunchKernelGGL(output_proj_kernel, dim3(cdiv((int64_t)Bf * T, OP_TOK)), dim3(512), lds, s, X, WeffT, out, Bf, C, T, S, D);
     SAT_LAUNCH_CHECK();
     return 0;
 }

@@ -1087,213 +1087,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe2_kernel(GemmArgs g) {
-    [[maybe_unused]] constexpr int NT = WM * WN * 64;
-    constexpr int TM = BM / WM;
-    constexpr int TN = BN / WN;
-    static_assert(TN % 64 == 0, "wave tile is TM x (NJ*64)");
-    constexpr int MI = TM / 32;
-    constexpr int NJ = TN / 64;                    // 64-column spans per wave (one head / one value+gate pair each)
-    constexpr int NI = 2 * NJ;
-    constexpr int CPR = BK / 8;                    // 16-B chunks per row
-    // One LDS-DMA instruction of one wave moves 64 chunks = 1 KiB.  A stage holds WL_A + WL_B of them (A rows first, then
-    // W rows, contiguous); wave w issues wave-loads w, w+NW, w+2NW, ...  When NW does not divide WL (256x192 on 12 waves:
-    // 56 wave-loads) the first WL%NW waves carry one more than the rest, and the counted vmcnt wait is per wave.
-    constexpr int NW = WM * WN;
-    constexpr int WL_A = BM * CPR / 64;
-    constexpr int WL = (BM + BN) * CPR / 64;
-    constexpr int LPT = (WL + NW - 1) / NW;        // max LDS-DMA instructions per tile per wave
-    constexpr int N_FULL = WL - (LPT - 1) * NW;    // waves [0, N_FULL) issue LPT, the others LPT-1
-    constexpr bool UNIFORM = (WL % NW) == 0;
-    constexpr int ROWB = BK * 2;
-    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-    constexpr int D = NS - 1;                      // prefetch distance
-    static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN;
-    const int wn = wave % WN;
-    const int half = lane >> 5;
-    const int l31 = lane & 31;
-
-    const int M = g.M, N = g.N, K = g.K;
-    const int tiles_m = (M + BM - 1) / BM;
-    const int tiles_n = N / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    // grouped rasterisation: bands of GM row-tiles swept across N, m fastest inside the band, so the 32 workgroups
-    // an XCD runs concurrently form an 8 x 4 patch that shares 8 A panels + 4 W panels through its L2
-    constexpr int GM = 8;
-    const int band = bid / (GM * tiles_n);
-    const int first_m = band * GM;
-    const int gm_rows = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int local = bid - band * (GM * tiles_n);
-    const int tn = local / gm_rows;
-    const int tm = first_m + (local - tn * gm_rows);
-    const int m0 = tm * BM;
-    const int n0 = tn * BN;
-
-    constexpr bool dbg_same = false, dbg_noload = false, dbg_nomfma = false;
-    const bf16_t* ld_ptr[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        const int L = i * NW + wave;               // wave-uniform
-        const bool is_a = L < WL_A;
-        int q = (is_a ? L : L - WL_A) * 64 + lane;
-        int row = q / CPR, pos = q % CPR;
-        int c = (BK == 128) ? (pos ^ (row & 15)) : (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
-        int gm = (dbg_same ? 0 : m0) + row;
-        gm = gm < M ? gm : M - 1;
-        int gn = (dbg_same ? 0 : n0) + row;
-        gn = gn < N ? gn : N - 1;                  // only reachable by the unused slot of a short wave
-        ld_ptr[i] = is_a ? g.A + (size_t)gm * K + c * 8 : g.W + (size_t)gn * K + c * 8;
-    }
-    const bool wave_full = UNIFORM || wave < N_FULL;
-
-    f32x16 acc[NJ][MI][2];
-#pragma unroll
-    for (int q = 0; q < NJ; ++q)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
-
-    auto stage_in = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i)
-            if (UNIFORM || i + 1 < LPT || wave_full)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[i] + kt * BK),
-                                                 (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024), 16, 0, 0);
-    };
-    // tiles k+1..k+D-1 may stay in flight: this wave issued LPT (or LPT-1) loads for each of them
-    [[maybe_unused]] auto wait_steady = [&]() {
-        if constexpr (UNIFORM || D == 1) {
-            wait_vmcnt<(D - 1) * LPT>();
-        } else {
-            if (wave_full) wait_vmcnt<(D - 1) * LPT>();
-            else wait_vmcnt<(D - 1) * (LPT - 1)>();
-        }
-    };
-    // Fragments are double-buffered across the k-steps AND across K-tiles: the ds_reads of the next step are issued
-    // interleaved with the MFMAs of the current one (pinned with sched_group_barrier), and the last step of tile k
-    // prefetches step 0 of tile k+1, so no MFMA ever waits on LDS latency right after a barrier.
-    constexpr int KS = BK / 16;
-    static_assert(KS % 2 == 0, "fragment buffer parity must wrap");
-    bf16x8 af[2][MI], bfr[2][NI];
-    auto frag = [&](int stage, int ks, int buf) {
-        const char* sa = smem + stage * STAGE_BYTES;
-        const char* sb = sa + BM * ROWB;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-            af[buf][i] = *reinterpret_cast<const bf16x8*>(sa + lds_off_bk<BK>(wm * TM + i * 32 + l31, ks * 2 + half));
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-            bfr[buf][j] = *reinterpret_cast<const bf16x8*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
-    };
-    auto compute = [&](int stage, int next_stage, bool has_next, auto trc) {
-        constexpr bool TRc = decltype(trc)::value;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bool pre = (ks + 1 < KS) || has_next;
-            if (ks + 1 < KS) frag(stage, ks + 1, (ks + 1) & 1);
-            else if (has_next) frag(next_stage, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[j >> 1][i][j & 1] =
-                        TRc ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[j >> 1][i][j & 1], 0, 0, 0)
-                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[j >> 1][i][j & 1], 0, 0, 0);
-            if (pre) {
-#pragma unroll
-                for (int r = 0; r < MI + NI; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x8, MI * NI - (MI + NI), 0);
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
-            }
-        }
-    };
-
-    const int nk = K / BK;
-    // prologue: tiles 0..D-1 in flight (nk >= NS is guaranteed by the launcher)
-#pragma unroll
-    for (int s = 0; s < D; ++s) stage_in(s, s);
-    wait_vmcnt<(D - 1) * LPT>();                 // tile 0 landed (own part) ...
-    __builtin_amdgcn_s_barrier();                // ... and everybody's
-    frag(0, 0, 0);
-    int rd = 0;          // stage of tile k
-    int wr = D;          // stage that receives tile k+D (== stage of tile k-1)
-    // steady state.  Top of iteration k: tile k visible, its step-0 fragments already requested.  Waiting for tile k+1
-    // here (instead of at the top of iteration k+1) is what lets the last k-step prefetch across the tile boundary.
-    // orientation: see gemm_pipe_kernel (uniform over the workgroup)
-    bool tr = !(g.variant & 0x1000) && (EPI != EPI_F32 || (g.variant & 0x2000));
-    if constexpr (EPI == EPI_HEADS) {
-        const int hp = g.heads.heads * 64;
-        tr = tr && !(g.heads.kind[(n0 + wn * TN) / hp] & 1);
-    }
-    auto main_loop = [&](auto trc) {
-        for (int k = 0; k < nk - D; ++k) {
-            wait_vmcnt<(D - 2) * LPT>();
-            __builtin_amdgcn_s_barrier();            // tile k+1 visible; everybody is done with stage wr (tile k-1)
-            if (!dbg_noload) stage_in(k + D, wr);
-            const int nx = (rd + 1 == NS) ? 0 : rd + 1;
-            if (!dbg_nomfma) compute(rd, nx, true, trc);
-            rd = nx;
-            wr = (wr + 1 == NS) ? 0 : wr + 1;
-        }
-        // drain: nothing left to issue
-        for (int k = nk - D; k < nk; ++k) {
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            const int nx = (rd + 1 == NS) ? 0 : rd + 1;
-            compute(rd, nx, k + 1 < nk, trc);
-            rd = nx;
-        }
-    };
-    if (tr) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-
-    if constexpr (EPI == EPI_F32) {
-        if (!tr && !(g.variant & 0x8000)) {
-            __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int q = 0; q < NJ; ++q)
-                gemm_epilogue_f32_staged<MI>(g, acc[q], reinterpret_cast<float*>(smem) + wave * 2048, m0 + wm * TM, n0 + wn * TN + q * 64, lane);
-            return;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NJ; ++q) {
-        if (tr) gemm_epilogue_t<EPI, MI, 2>(g, acc[q], m0 + wm * TM, n0 + wn * TN + q * 64, half, l31);
-        else gemm_epilogue<EPI, MI, 2>(g, acc[q], m0 + wm * TM, n0 + wn * TN + q * 64, half, l31);
-    }
-}
-
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI>
-int launch_pipe2(const GemmArgs& a, hipStream_t stream) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int LDS = NS * (BM + BN) * BK * 2;
-    static_assert(LDS <= 160 * 1024 && NS >= 3, "pipe2 needs a >= 3-stage ring within 160 KiB");
-    auto kern = gemm_pipe2_kernel<BM, BN, BK, WM, WN, NS, EPI>;
-    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
-    SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
-    SAT_CHECK_ARG(a.K % BK == 0 && a.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
-    int tiles = cdiv(a.M, BM) * (a.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, a);
-    SAT_LAUNCH_CHECK();
-    return 0;
-}
-
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int FP8 = 0>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
@@ -1335,8 +1128,9 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 //    5  128x128, 4 waves, LDS-DMA double buffer            (K < 192: too short for a 3-stage ring)
 //   15  128x128x64, 8 waves, 3-stage LDS-DMA ring          (to_out / FF-out at 1 prompt)
 //   16  128x64x64,  4 waves, 3-stage ring                  (cross-attention projections, M = 1025)
-//   22  256x256x64, 16 waves, 2-stage ring                 (FF-in at 1 prompt)
-//   26  256x256x32, 16 waves, 4-stage ring, cross-tile fragment prefetch, grouped raster   (everything at >= 4 prompts)
+//   22  256x256x64, 16 waves, 2-stage ring                 (FF-in at 1 prompt; every GEMM from 4 prompts on.  The 4-stage BK = 32
+//       variant with cross-tile fragment prefetch and grouped raster of round 1 measured within 2 % of it at 8 prompts after the
+//       epilogue rewrite -- profiles/r02_b8_tiles.txt -- and was removed)
 //   30  256x192x64, 12 waves, 2-stage ring                 (to_qkv at 1 prompt)
 // fp8 (e4m3) operands: 15 / 16 / 22 / 30 in three flavours (plain fp8 MFMA, 2x-rate block-scaled MFMA, MXFP8 A operand).
 // Bit 12 of the variant asks for the legacy accumulator orientation (lane = channel) instead of the transposed one.
@@ -1418,7 +1212,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             const double best = s256 > s192 ? (s256 > s128 ? s256 : s128) : (s192 > s128 ? s192 : s128);
             if (best == 0.0 && s64 == 0.0) v = 15;      // N is not a tile multiple: let the launcher report it
             else if (s64 > best) v = 16;
-            else if (best == s256) v = (cdiv(a.M, 256) > 16) ? 26 : 22;   // 26: grouped raster + 4-stage ring (large M)
+            else if (best == s256) v = 22;
             else if (best == s192) v = 30;
             else v = 15;
         } else {
@@ -1431,7 +1225,6 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);
         case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI>(a, stream);
-        case 26: return launch_pipe2<256, 256, 32, 4, 4, 4, EPI>(a, stream);
         case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
 #ifdef SAT_GEMM_EXPERIMENTS
         case 2: return launch_cfg<256, 128, 4, 2, EPI>(a, stream);
@@ -1440,8 +1233,6 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 10: return launch_pipe<128, 128, 64, 2, 2, 3, EPI>(a, stream);
         case 12: return launch_pipe<256, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 13: return launch_pipe<256, 256, 32, 2, 4, 3, EPI>(a, stream);
-        case 24: return launch_pipe2<256, 256, 32, 2, 4, 3, EPI>(a, stream);
-        case 27: return launch_pipe2<128, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 39: return launch_pipe<128, 128, 128, 4, 2, 2, EPI>(a, stream);       // 256-B rows: half the barriers per k
         case 41: return launch_pipe<256, 128, 32, 4, 2, 3, EPI>(a, stream);        // 72 KiB, <= 128 VGPRs: two workgroups per CU
 #endif

@@ -142,6 +142,44 @@ def epi_ab():
                                                                                                           _hip.stream()))), 2.0 * b * s_len * 3 * d * d)
 
 
+def b8_tiles():
+    """8 prompts per GPU (M = 16400): the 2-stage 256x256x64 tile (22) against the 4-stage 256x256x32 one with cross-tile fragment
+    prefetch and grouped raster (26), every GEMM of the block."""
+    import statistics
+    m = 16400
+    def ab(label, mk):
+        res = {22: [], 26: []}
+        for _ in range(4):
+            for v in res:
+                res[v].append(timeit(mk(v), iters=5, warm=2))
+        print(f"B8 {label:10s} tile22 {statistics.median(res[22])*1e3:7.1f} us   tile26 {statistics.median(res[26])*1e3:7.1f} us", flush=True)
+    for name, n, k in [("to_out", 1536, 1536), ("ff_out", 1536, 6144)]:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        c = torch.zeros(m, n, device=dev)
+        ab(name, lambda v: (lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), None, _hip.ptr(c), m, n, k, 1, v, _hip.stream()))))
+    n, k = 12288, 1536
+    a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+    w = torch.randn(n, k, device=dev) * 0.05
+    bias = torch.randn(n, device=dev) * 0.1
+    wp = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
+    bp = torch.empty((n,), dtype=torch.float32, device=dev)
+    out = torch.empty((m, n // 2), dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m, n, k, 22, _hip.stream()))
+    ab("ff_in", lambda v: (lambda: _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m, n, k,
+                                                                      v | 0x4000, _hip.stream()))))
+    b, s_len, s_pad, d = 16, 1025, 1152, 1536
+    a = torch.randn(b * s_len, d, device=dev).to(torch.bfloat16)
+    w = (torch.randn(3 * d, d, device=dev) * 0.05).to(torch.bfloat16)
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+    q = torch.empty((b, 24, s_pad, 64), dtype=torch.bfloat16, device=dev)
+    kk = torch.empty_like(q)
+    vt = torch.empty((b, 24, 64, s_pad), dtype=torch.bfloat16, device=dev)
+    scratch = torch.empty((2 * s_len * 16,), dtype=torch.float32, device=dev)
+    ab("qkv", lambda v: (lambda: _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(inv_freq), _hip.ptr(q), _hip.ptr(kk), _hip.ptr(vt),
+                                                                  _hip.ptr(scratch), b, s_len, s_pad, d, v, _hip.stream()))))
+
+
 def f32_epi_ab():
     """fp32 residual epilogue: LDS-staged 16-byte coalesced (default) vs direct dword (bit 15) vs transposed 16-byte (bit 13)."""
     import statistics
@@ -311,6 +349,8 @@ if __name__ == "__main__":
         section("gemm", gemm_bench)
     if "epi" in which:
         section("epilogue A/B", epi_ab)
+    if "b8tiles" in which:
+        section("8 prompts: tile 22 vs 26", b8_tiles)
     if "f32epi" in which:
         section("fp32 epilogue A/B", f32_epi_ab)
     if "ablate" in which:
