@@ -726,7 +726,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     [[maybe_unused]] f32x4 resid[PRE_RESID ? 8 : 1];
     if constexpr (PRE_RESID) {
         // (exactly the condition under which the staged epilogue runs, see the end of the kernel)
+#ifdef SAT_GEMM_EXPERIMENTS
         const bool staged = !(!MXA && !(g.variant & 0x1000) && (g.variant & 0x2000)) && !(g.variant & 0x8000);
+#else
+        const bool staged = true;
+#endif
         const bool want = g.accumulate != 0 && wave_rows_valid && staged;
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
@@ -980,12 +984,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         for (int j = 0; j < NI; ++j) fb0[j] = *reinterpret_cast<const bf16x8*>(smem + BM * ROWB + lds_off_bk<BK>(wn * TN + j * 32 + l31, half));
     }
     // Orientation (uniform over the workgroup: tiles never straddle a q / k / v part): transposed accumulators everywhere except
-    // for a V^T destination (token-contiguous stores want lane = channel), the MXFP8 A operand, the ablation modes, and when the
-    // caller asks for the legacy orientation (variant bit 12; A/B measurements and tests of the un-swapped epilogue).
+    // for a V^T destination (token-contiguous stores want lane = channel), the MXFP8 A operand and the fp32 output.
     // Measured (profiles/r02_epilogue_ab.txt): bf16 outputs gain 3-4 % (SwiGLU) / 13 % (heads) from the transposed orientation, the
     // fp32 residual epilogue LOSES 6-10 % at 8 prompts (a lane-per-token store instruction touches 32 cache lines; in the legacy
-    // orientation every store instruction writes two full 128-byte lines) -> fp32 output stays un-swapped unless bit 13 asks for it.
+    // orientation every store instruction writes two full 128-byte lines) -> fp32 output stays un-swapped.
+    // The shipped build fixes the orientation at compile time wherever it can (ORI 0: un-swapped only -- fp32 output, MXFP8 A
+    // operand; 1: transposed only -- SwiGLU; 2: per workgroup -- heads: q / k transposed, V^T un-swapped): one main loop instead of
+    // two keeps the 128-VGPR kernels (16 waves, e4m3 fragments) out of scratch.  The experiments build keeps both behind variant
+    // bits 12 (force un-swapped), 13 (transposed fp32 epilogue) and 15 (direct dword fp32 epilogue) for A/B measurements.
+#ifdef SAT_GEMM_EXPERIMENTS
+    constexpr int ORI = MXA ? 0 : 2;
     bool tr = !MXA && !(g.variant & 0x1000) && (EPI != EPI_F32 || (g.variant & 0x2000));
+    const bool direct_f32 = (g.variant & 0x8000) != 0;
+#else
+    constexpr int ORI = (MXA || EPI == EPI_F32) ? 0 : (EPI == EPI_SWIGLU ? 1 : 2);
+    bool tr = ORI != 0;
+    constexpr bool direct_f32 = false;
+#endif
     if constexpr (EPI == EPI_HEADS) {
         const int hp = g.heads.heads * 64;
         tr = tr && !(g.heads.kind[(n0 + wn * TN) / hp] & 1);
@@ -1019,8 +1034,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             rd = (rd + 1 == NS) ? 0 : rd + 1;
         }
     };
-    if constexpr (MXA) {
+    if constexpr (ORI == 0) {
         main_loop(std::false_type{});
+    } else if constexpr (ORI == 1) {
+        main_loop(std::true_type{});
     } else {
         if (tr) main_loop(std::true_type{});
         else main_loop(std::false_type{});
@@ -1066,7 +1083,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         }
     }
     if constexpr (EPI == EPI_F32 && NI == 2 && DBG == 0) {
-        if (!tr && !(g.variant & 0x8000)) {     // (bit 15: the direct dword epilogue, for A/B measurements)
+        if (!tr && !direct_f32) {
             __builtin_amdgcn_s_barrier();       // every wave is done reading the ring: it becomes the staging area
             if (wave_rows_valid) {
                 if constexpr (PRE_RESID)
@@ -1133,7 +1150,6 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 //       epilogue rewrite -- profiles/r02_b8_tiles.txt -- and was removed)
 //   30  256x192x64, 12 waves, 2-stage ring                 (to_qkv at 1 prompt)
 // fp8 (e4m3) operands: 15 / 16 / 22 / 30 in three flavours (plain fp8 MFMA, 2x-rate block-scaled MFMA, MXFP8 A operand).
-// Bit 12 of the variant asks for the legacy accumulator orientation (lane = channel) instead of the transposed one.
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
 #ifdef SAT_GEMM_EXPERIMENTS

@@ -46,13 +46,9 @@ def test_cast_bf16(dev):
     assert torch.equal(y.cpu(), x.to(torch.bfloat16))
 
 
-LEGACY = 0x1000     # variant bit 12: un-swapped MFMA operands (lane = channel) and the epilogue that goes with it
-
-# the shipped tile configurations (gemm_bf16.hip: launch_epi), the LDS-DMA ones in both accumulator orientations
-FP32_T = 0x2000     # bit 13: transposed orientation for the fp32-output epilogue as well (default there: un-swapped + LDS-staged)
-DIRECT = 0x8000     # bit 15: the direct dword fp32 epilogue instead of the LDS-staged one
-GEMM_VARIANTS = [1, 5, 15, 16, 22, 30, 15 | LEGACY, 16 | LEGACY, 22 | LEGACY, 30 | LEGACY]
-GEMM_F32_VARIANTS = GEMM_VARIANTS + [15 | FP32_T, 22 | FP32_T, 15 | DIRECT, 16 | DIRECT, 22 | DIRECT, 30 | DIRECT]
+# the shipped tile configurations (gemm_bf16.hip: launch_epi); 0 = the launcher's own choice
+GEMM_VARIANTS = [1, 5, 15, 16, 22, 30]
+GEMM_F32_VARIANTS = GEMM_VARIANTS
 
 
 def _skip_tile(variant, n, k):
@@ -320,7 +316,7 @@ def test_fp8_quant_and_layernorm(dev):
 
 
 @pytest.mark.parametrize("plain", [0, 256])
-@pytest.mark.parametrize("variant", [0, 15, 16, 22, 30, 22 | LEGACY, 15 | LEGACY])
+@pytest.mark.parametrize("variant", [0, 15, 16, 22, 30])
 @pytest.mark.parametrize("m,n,k", [(2050, 1536, 1536), (257, 768, 6144), (130, 256, 384), (1, 768, 256)])
 def test_gemm_fp8(dev, variant, m, n, k, plain):
     """e4m3 x e4m3 -> fp32 GEMM with per-row scales on both operands against an fp32 matmul of the de-quantised operands
