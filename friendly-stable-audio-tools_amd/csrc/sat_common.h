@@ -65,15 +65,41 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }   /
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide reductions without LDS traffic: four DPP steps reduce every row of 16 lanes (quad xor 1, quad xor 2, row_half_mirror,
+// row_mirror), row_bcast:15 / row_bcast:31 fold the four rows into lane 63, v_readlane broadcasts the result through an SGPR.
+// 7 VALU instructions instead of six ds_bpermute round trips (__shfl_xor).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move_masked(float v) {      // lanes outside ROW_MASK receive 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_move(float v) {
+    const int i = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_row_move<0xB1>(v);                    // quad_perm [1,0,3,2]
+    v += dpp_row_move<0x4E>(v);                    // quad_perm [2,3,0,1]
+    v += dpp_row_move<0x141>(v);                   // row_half_mirror
+    v += dpp_row_move<0x140>(v);                   // row_mirror: every lane of a row holds the row sum
+    v += dpp_move_masked<0x142, 0xA>(v);           // row_bcast:15 into rows 1 and 3
+    v += dpp_move_masked<0x143, 0xC>(v);           // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {   // for non-negative inputs or any inputs: the masked moves use v itself as filler
+    v = fmaxf(v, dpp_row_move<0xB1>(v));
+    v = fmaxf(v, dpp_row_move<0x4E>(v));
+    v = fmaxf(v, dpp_row_move<0x141>(v));
+    v = fmaxf(v, dpp_row_move<0x140>(v));
+    {
+        const int i = __float_as_int(v);
+        v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x142, 0xA, 0xf, false)));
+    }
+    {
+        const int i = __float_as_int(v);
+        v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x143, 0xC, 0xf, false)));
+    }
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // max over the 32 lanes of a wave half (lanes 0-31 / 32-63), result in every lane: four DPP steps (quad xor 1, quad xor 2,

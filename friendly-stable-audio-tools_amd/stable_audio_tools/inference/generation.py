@@ -50,13 +50,17 @@ def generate_diffusion_cond(model, steps: int = 250, cfg_scale: float = 6, condi
     if model.conditioner is not None:
         model.conditioner.set_device(device)
     assert conditioning or conditioning_tensors, "Must provide either conditioning or conditioning_tensors"
-    if negative_conditioning or negative_conditioning_tensors:
-        # The reference overwrites negative_conditioning_tensors with {} before testing it
-        # (generation.py:148-155), so negative prompts raise KeyError there; refuse loudly instead.
-        raise NotImplementedError("negative conditioning is broken in the reference API (generation.py:148-155) and not offered here")
     if conditioning_tensors is None:
         conditioning_tensors = model.conditioner(conditioning)
     cond_inputs = {k: (None if v is None else v.float()) for k, v in model.get_conditioning_inputs(conditioning_tensors).items()}
+    # Negative prompts.  The reference resets `negative_conditioning_tensors` to {} before looking at it (generation.py:148-155), so
+    # its own call ends in a KeyError; what it evidently means to do -- hand the negative set to the denoiser, where the
+    # unconditional CFG half attends to it instead of the null embed (dit.py:294-300) -- is what happens here.
+    if negative_conditioning_tensors is None and negative_conditioning:
+        negative_conditioning_tensors = model.conditioner(negative_conditioning)
+    if negative_conditioning_tensors:
+        negative = model.get_conditioning_inputs(negative_conditioning_tensors, negative=True)
+        cond_inputs.update({k: (None if v is None else v.float()) for k, v in negative.items()})
     num_sample = next(iter(conditioning_tensors.values()))[0].shape[0]           # batch size = that of the first conditioning tensor
 
     ratio = model.pretransform.downsampling_ratio if model.pretransform else 1

@@ -247,12 +247,16 @@ def dit_inner_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads,
 
 # models/dit.py:228-364 (DiffusionTransformer.forward: batched CFG :270-349)
 def dit_forward(sd, x, t, cross_attn_cond, global_embed, depth, num_heads, cfg_scale=1.0, scale_phi=0.0,
-                negative_cross_attn_cond=None, rnd=None, adaln=False):
+                negative_cross_attn_cond=None, rnd=None, adaln=False, negative_cross_attn_mask=None):
     if cfg_scale != 1.0 and cross_attn_cond is not None:
         bx = torch.cat([x, x], dim=0)
         bt = torch.cat([t, t], dim=0)
         bg = None if global_embed is None else torch.cat([global_embed, global_embed], dim=0)
-        null = torch.zeros_like(cross_attn_cond) if negative_cross_attn_cond is None else negative_cross_attn_cond
+        null = torch.zeros_like(cross_attn_cond)
+        if negative_cross_attn_cond is not None:                                         # dit.py:294-300
+            if negative_cross_attn_mask is not None:
+                negative_cross_attn_cond = torch.where(negative_cross_attn_mask.to(torch.bool).unsqueeze(2), negative_cross_attn_cond, null)
+            null = negative_cross_attn_cond
         bc = torch.cat([cross_attn_cond, null], dim=0)
         out = dit_inner_forward(sd, bx, bt, bc, bg, depth, num_heads, rnd, adaln=adaln)
         cond, uncond = torch.chunk(out, 2, dim=0)

@@ -99,6 +99,13 @@ def gen_small():
     x, t, c, g = cases.dit_inputs(2, 64, 128, 96, 1)
     out["cfg7_phi04_T64"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=7.0, scale_phi=0.4)
     out["zero_ctx_T64"] = m(x, t, cross_attn_cond=torch.zeros_like(c), global_embed=g, cfg_scale=1.0)
+    # negative prompt (dit.py:294-300): the unconditional half attends to a second context, masked tokens fall back to the null embed
+    c_neg = synthetic.synth_input("c_neg", tuple(c.shape), 77)
+    neg_mask = torch.ones(c.shape[0], c.shape[1])
+    neg_mask[1, 40:] = 0
+    out["cfg7_negative_T64"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=7.0, negative_cross_attn_cond=c_neg)
+    out["cfg7_negative_masked_T64"] = m(x, t, cross_attn_cond=c, global_embed=g, cfg_scale=7.0, negative_cross_attn_cond=c_neg,
+                                        negative_cross_attn_mask=neg_mask)
     # DiTWrapper path incl. the 0.5 scaling convention is exercised through get_conditioning_inputs below
     save("dit_small", **out)
 

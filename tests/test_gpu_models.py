@@ -96,6 +96,77 @@ def test_dit_forward_cfg_and_denoise(dev, small_dit):
     assert_close("zero-context forward", got1, want1, 3e-3)
 
 
+def test_negative_prompt_vs_reference_golden(dev):
+    """Negative prompts: the unconditional CFG half attends to a second context instead of the null embed
+    (dit.py:294-300), optionally token-masked.  DiffusionTransformer.forward against the REFERENCE's outputs
+    (tests/golden/dit_small.npz: cfg7_negative*), and generate_diffusion_cond(negative_conditioning_tensors=...) -- which the
+    reference's own generate_diffusion_cond cannot run (generation.py:148-155 resets the argument and ends in a KeyError) --
+    against the matched-rounding oracle trajectory."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    from oracle import dit as odit, sampler as osamp
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.models import _init
+    from stable_audio_tools.models.dit import DiffusionTransformer
+    gold = cases.load("dit_small")
+    with _init.skip_init():
+        dit = DiffusionTransformer(**cases.SMALL_DIT)
+    sd = synthetic.synth_state_dict(dit.state_dict(), 0)
+    dit.load_state_dict(sd)
+    dit = dit.to(dev).eval()
+    x, t, c, g = cases.dit_inputs(2, 64, 128, 96, 1)
+    c_neg = synthetic.synth_input("c_neg", tuple(c.shape), 77)
+    neg_mask = torch.ones(c.shape[0], c.shape[1])
+    neg_mask[1, 40:] = 0
+    got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0, negative_cross_attn_cond=c_neg.to(dev))
+    e1 = assert_close("negative prompt vs reference", got, gold["cfg7_negative_T64"], 1.6e-2)          # measured 7.9e-3
+    got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0, negative_cross_attn_cond=c_neg.to(dev),
+              negative_cross_attn_mask=neg_mask.to(dev))
+    e2 = assert_close("masked negative prompt vs reference", got, gold["cfg7_negative_masked_T64"], 1.6e-2)   # measured 8.2e-3
+    want_m = odit.dit_forward(sd, x, t, c, g, 3, 4, cfg_scale=7.0, negative_cross_attn_cond=c_neg, negative_cross_attn_mask=neg_mask, rnd=bf16_round)
+    assert_close("masked negative prompt vs matched oracle", got, want_m, 1e-2)
+    print(f"\n[negative prompt] rel-L2 vs the reference {e1:.2e}, masked {e2:.2e}")
+
+
+def test_generate_with_negative_conditioning(dev, small_dit):
+    from oracle import dit as odit, sampler as osamp
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.inference.generation import generate_diffusion_cond
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dsd = _sub(sd, "model.model.")
+    b, steps, t_len = 2, 4, 24
+    ratio = cfg["model"]["pretransform"]["config"]["downsampling_ratio"]
+
+    def cond_of(seed, seconds):
+        cond = model.conditioner([{"seconds_start": 0, "seconds_total": seconds + i} for i in range(b)])
+        cond["prompt"] = (synthetic.synth_input("prompt", (b, 128, dc["cond_token_dim"]), seed).to(dev), torch.ones(b, 128, device=dev))
+        return {k: cond[k] for k in ("prompt", "seconds_start", "seconds_total")}
+
+    pos, neg = cond_of(31, 10), cond_of(33, 20)
+    noise = synthetic.synth_input("noise", (b, 64, t_len), 32)
+    step_noise = [synthetic.synth_input(f"sn{i}", (b, 64, t_len), 40 + i) for i in range(steps)]
+    it = iter(step_noise)
+    lat = generate_diffusion_cond(model, steps=steps, cfg_scale=7.0, conditioning_tensors=pos, negative_conditioning_tensors=neg,
+                                  sample_size=t_len * ratio, seed=5, device=str(dev), sampler_type="dpmpp-3m-sde", sigma_min=0.3, sigma_max=500,
+                                  return_latents=True, noise=noise, noise_sampler=lambda s, sn: next(it).to(dev))
+    ci, ni = model.get_conditioning_inputs(pos), model.get_conditioning_inputs(neg, negative=True)
+    cac, gc = ci["cross_attn_cond"].cpu().float(), ci["global_cond"].cpu().float()
+    nc = ni["negative_cross_attn_cond"].cpu().float()
+    sig = osamp.get_sigmas_polyexponential(steps, 0.3, 500.0, 1.0)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, negative_cross_attn_cond=nc,
+                                          negative_cross_attn_mask=ni["negative_cross_attn_mask"].cpu(), rnd=bf16_round)
+    want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), noise * sig[0], sig, lambda i, s, sn: step_noise[i])
+    e = assert_close("trajectory with a negative prompt vs matched oracle", lat, want, 2e-2)
+    it = iter(step_noise)
+    plain = generate_diffusion_cond(model, steps=steps, cfg_scale=7.0, conditioning_tensors=pos, sample_size=t_len * ratio, seed=5,
+                                    device=str(dev), sampler_type="dpmpp-3m-sde", sigma_min=0.3, sigma_max=500, return_latents=True, noise=noise,
+                                    noise_sampler=lambda s, sn: next(it).to(dev))
+    assert rel_l2(lat, plain) > 1e-2, "the negative prompt must change the result"
+    print(f"\n[negative conditioning] trajectory rel-L2 vs matched oracle {e:.2e}")
+
+
 def test_dit_adaln_vs_reference_golden(dev):
     """global_cond_type='adaLN' (dit.py:205-206, transformer.py:665-689): no prepend token; LayerNorm modulated by
     (1 + scale, shift) and the self-attention / FF branch outputs gated by sigmoid(1 - gate), all from one stacked

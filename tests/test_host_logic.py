@@ -156,7 +156,8 @@ def test_generate_rejects_what_the_reference_api_cannot_do():
         generate_diffusion_cond(model, steps=2, device="cpu")
     cond = {"prompt": (torch.zeros(1, 128, 128), torch.ones(1, 128)), "seconds_start": (torch.zeros(1, 1, 128), torch.ones(1, 1)),
             "seconds_total": (torch.zeros(1, 1, 128), torch.ones(1, 1))}
-    with pytest.raises(NotImplementedError, match="negative"):
+    # a negative prompt given as raw metadata needs a conditioner for every id: the number conditioners find no entry here
+    with pytest.raises(ValueError, match="not found"):
         generate_diffusion_cond(model, steps=2, conditioning_tensors=cond, negative_conditioning=[{"prompt": "x"}], device="cpu")
     with pytest.raises(NotImplementedError, match="sampler_type"):
         sample_k(model.model, torch.zeros(1, 64, 8), sampler_type="k-euler-nonexistent")

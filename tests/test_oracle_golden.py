@@ -60,6 +60,13 @@ def test_dit_small_forward(small_dit_sd):
         assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=7.0), g[f"cfg7_T{t_len}"]) < TOL
     x, t, c, gl = cases.dit_inputs(2, 64, 128, 96, 1)
     assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=7.0, scale_phi=0.4), g["cfg7_phi04_T64"]) < TOL
+    # negative prompt (dit.py:294-300), with and without a token mask
+    c_neg = synthetic.synth_input("c_neg", tuple(c.shape), 77)
+    neg_mask = torch.ones(c.shape[0], c.shape[1])
+    neg_mask[1, 40:] = 0
+    assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=7.0, negative_cross_attn_cond=c_neg), g["cfg7_negative_T64"]) < TOL
+    assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=7.0, negative_cross_attn_cond=c_neg, negative_cross_attn_mask=neg_mask),
+                  g["cfg7_negative_masked_T64"]) < TOL
     zero = odit.dit_forward(sd, x, t, torch.zeros_like(c), gl, 3, 4)
     assert rel_l2(zero, g["zero_ctx_T64"]) < TOL
     # an all-zero context contributes exactly nothing (no-bias to_cond_embed / to_kv / to_out): same as no cross-attention
