@@ -58,6 +58,9 @@ struct LayerW {
     bf16_t *w_qkv, *w_o, *w_cq, *w_ckv, *w_co, *w_ff1, *w_ff2;
     float *b_ff1, *b_ff2;
     float *s_qkv, *s_cq, *s_ff1, *s_ff2, *s_o, *s_co;      // fp8_gemm: per-output-channel scales (the weights above then hold e4m3 bytes)
+    // LayerNorm folded into the GEMM behind it (plan->ln_fold): the weights above are bf16(gamma (.) W); GemmArgs::ln_c1 / ln_c2
+    float *c1_qkv, *c2_qkv, *c1_cq, *c2_cq, *c1_ff1, *c2_ff1;
+    bool fold_qkv;      // false for layer 0: its pre_norm reads rows written by the input projection, not by a GEMM epilogue
 };
 
 }  // namespace
@@ -74,6 +77,7 @@ struct sat_dit_plan {
     float *ce0_w, *ce2_w, *ge0_w, *ge2_w;
     float *win_eff, *wout_eff;
     float *rope_cos, *rope_sin, *inv_freq;
+    bool ln_fold = false;           // cfg.ln_fold, bf16 operands, "prepend" conditioning: LayerNorms run inside the GEMM epilogues
     int fp8_mode = 2;               // 2: v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, 2x rate); 1: v_mfma_f32_32x32x16_fp8_fp8
     float* ssg_w = nullptr;         // adaLN: [depth * 6D, D] stacked to_scale_shift_gate weights
     // per-generation context (sat_dit_prepare_context)
@@ -121,6 +125,19 @@ int pack_w(sat_dit_plan* p, Arena& ar, const std::string& name, int n, int k, in
     const float* src;
     SAT_TRY(get_tensor(p, name, (int64_t)n * k, &src));
     return sat_launch_pack_rows_bf16(src, *dst, n, k, interleave, s);
+}
+
+// LayerNorm fold: bf16(gamma (.) W) + the two correction vectors of GemmArgs::ln_c1 / ln_c2 (bias folded into c2)
+int pack_w_ln(sat_dit_plan* p, Arena& ar, const std::string& name, const float* gamma, const float* beta, const std::string& bias_name, int n,
+              int k, int interleave, bf16_t** dst, float** c1, float** c2, hipStream_t s) {
+    *dst = (bf16_t*)ar.take((size_t)n * k * 2);
+    *c1 = (float*)ar.take((size_t)n * 4);
+    *c2 = (float*)ar.take((size_t)n * 4);
+    if (ar.dry) return 0;
+    const float *src, *bias = nullptr;
+    SAT_TRY(get_tensor(p, name, (int64_t)n * k, &src));
+    if (!bias_name.empty()) SAT_TRY(get_tensor(p, bias_name, n, &bias));
+    return sat_launch_pack_rows_ln(src, gamma, beta, bias, *dst, *c1, *c2, n, k, interleave, s);
 }
 
 // fp8_gemm: e4m3 bytes + one scale per output channel instead of bf16
@@ -199,7 +216,10 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
             SAT_TRY(copy_f32(p, ar, pf + "ff.ff.2.bias", D, &L.b_ff2, s));
             continue;
         }
+        const bool lf = p->ln_fold;
+        L.fold_qkv = lf && l > 0;
         if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, &L.s_qkv, s));
+        else if (L.fold_qkv) SAT_TRY(pack_w_ln(p, ar, pf + "self_attn.to_qkv.weight", L.pre_g, L.pre_b, "", 3 * D, D, 0, &L.w_qkv, &L.c1_qkv, &L.c2_qkv, s));
         else SAT_TRY(pack_w(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, s));
         if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, &L.s_o, s));
         else SAT_TRY(pack_w(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, s));
@@ -207,12 +227,15 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
             SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.gamma", D, &L.cross_g, s));
             SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.beta", D, &L.cross_b, s));
             if (f8) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, &L.s_cq, s));
+            else if (lf) SAT_TRY(pack_w_ln(p, ar, pf + "cross_attn.to_q.weight", L.cross_g, L.cross_b, "", D, D, 0, &L.w_cq, &L.c1_cq, &L.c2_cq, s));
             else SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, s));
             SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_kv.weight", 2 * Dc, Dc, 0, &L.w_ckv, s));
             if (f8) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, &L.s_co, s));
             else SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, s));
         }
         if (f8) SAT_TRY(pack_w8(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, &L.s_ff1, s));
+        else if (lf) SAT_TRY(pack_w_ln(p, ar, pf + "ff.ff.0.proj.weight", L.ff_g, L.ff_b, pf + "ff.ff.0.proj.bias", 2 * inner, D, 1, &L.w_ff1, &L.c1_ff1,
+                                       &L.c2_ff1, s));
         else SAT_TRY(pack_w(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, s));
         L.b_ff1 = (float*)ar.take((size_t)2 * inner * 4);
         if (!ar.dry) {
@@ -235,6 +258,7 @@ struct Workspace {
     unsigned char* Hs;      // fp8_gemm: E8M0 block scales of the MXFP8 hidden activation in Hh, [M][inner / 32]
     unsigned char* AOs;     // fp8_gemm: E8M0 block scales of the MXFP8 attention output in AO, [M][D / 32]
     float *gsum, *ssg;      // adaLN: silu(global + timestep embed) [bf, D]; per-layer modulation [bf, depth, 6, D]
+    float* ln_part = nullptr;    // ln_fold: [M][D / 64][2] partial (sum, sum of squares) of the bf16 image of X kept in A
     float* f32_wide = nullptr;   // fp32 verification mode: [M, max(3D, 2 inner)] GEMM output before the head split / SwiGLU
     size_t qkv_bytes;
     size_t total;
@@ -288,6 +312,7 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     w.AOs = c.fp8_gemm == 1 ? (unsigned char*)take(M * (size_t)(D / 32)) : nullptr;
     w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
     w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
+    w.ln_part = p->ln_fold ? (float*)take(M * (size_t)(D / 64) * 2 * 4) : nullptr;
     w.total = off;
     return w;
 }
@@ -359,10 +384,20 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         const LayerW& L = p->layers[l];
         // ---- self-attention branch (transformer.py:692)
         const float* mod = adaln ? w.ssg + (size_t)l * 6 * D : nullptr;     // + {0..5} * D: scale1p/shift/gate self, then ff
+        // ln_fold: from the first to_out on, A holds bf16(X) and ln_part its row statistics, both written by the epilogue of the
+        // GEMM that last updated X; the LayerNorms (transformer.py:692, 695, 700) are finished in the epilogues of their consumers
+        const bool lf = p->ln_fold;
+        auto fold_in = [&](GemmArgs& ga, const float* c1, const float* c2) {
+            ga.ln_part = w.ln_part; ga.ln_c1 = c1; ga.ln_c2 = c2; ga.ln_eps = 1e-5f;
+        };
+        auto fold_out = [&](GemmArgs& ga) {
+            if (lf) { ga.xb = w.A; ga.ln_part_out = w.ln_part; }
+        };
         if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.pre_g, L.pre_b, w.A, w.As, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
-        else SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
+        else if (!L.fold_qkv) SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_qkv; g.M = M; g.N = 3 * D; g.K = D;
+        if (L.fold_qkv) fold_in(g, L.c1_qkv, L.c2_qkv);
         if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_qkv; }
         g.heads.out[0] = w.Q; g.heads.out[1] = w.K; g.heads.out[2] = w.Vt;
         g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
@@ -374,6 +409,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
+        fold_out(g);
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
         // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
         // unconditional CFG half, dit.py:294-300) get k = v = 0 from the bias-free to_cond_embed / to_kv, hence an
@@ -384,9 +420,10 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             const int Mc = bc * S;
             if (bc > 0) {
                 if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.cross_g, L.cross_b, w.A, w.As, Mc, D, nullptr, nullptr, 1, 0, s));
-                else SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s));
+                else if (!lf) SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s));
                 g = GemmArgs{};
                 g.A = w.A; g.W = L.w_cq; g.M = Mc; g.N = D; g.K = D;
+                if (lf) fold_in(g, L.c1_cq, L.c2_cq);
                 if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_cq; }
                 g.heads.out[0] = w.Q; g.heads.kind[0] = 0; g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
                 SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
@@ -396,16 +433,18 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 g = GemmArgs{};
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
                 if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
+                fold_out(g);
                 SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
             }
         }
         // ---- feed-forward branch (transformer.py:700)
         if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.ff_g, L.ff_b, w.A, w.As, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr,
                                                  S, ssg_ld, s));
-        else SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
-                                              ssg_ld, s));
+        else if (!lf) SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
+                                                       ssg_ld, s));
         g = GemmArgs{};
         g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
+        if (lf) { g.bias = nullptr; fold_in(g, L.c1_ff1, L.c2_ff1); }
         if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_ff1; g.H8 = (unsigned char*)w.Hh; g.Hs = w.Hs; }
         const bool prof = p->prof_on && l == c.depth / 2 && p->prof_n < kProfMaxPairs;
         if (prof) {
@@ -428,6 +467,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.Hs; g.w_scale = L.s_ff2; }
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
+        if (l + 1 < c.depth) fold_out(g);       // nobody normalises the output of the last block
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
     }
     // project_out + drop prepend + postprocess_conv + residual (transformer.py:807, dit.py:219-224)
@@ -461,6 +501,9 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
     SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_plan_create: out of host memory");
     p->cfg = *cfg;
     p->kvh_cross = cfg->cond_token_dim > 0 ? cfg->cond_embed_dim / 64 : 0;
+    // the fold lives in the bf16 pipelined GEMM tiles (K >= 192); adaLN modulates between LayerNorm and GEMM per sequence, the e4m3
+    // path quantises the LayerNorm output per token: both keep the standalone kernels
+    p->ln_fold = cfg->ln_fold != 0 && cfg->fp8_gemm == 0 && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
     return 0;
 }
@@ -725,6 +768,54 @@ extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_
     g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
     g.heads.parts = 3; g.heads.heads = H; g.heads.S = s_len; g.heads.Spad = s_pad;
     g.heads.rope_cos = cs; g.heads.rope_sin = sn;
+    return sat_launch_gemm(EPI_HEADS, g, s);
+}
+
+// ---- LayerNorm folded into the neighbouring GEMMs (sat_dit_cfg.ln_fold), one entry per role
+extern "C" int sat_gemm_resid_ln_bf16(const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
+                                      int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
+    SAT_CHECK_ARG(c && xb && ln_part, SAT_E_INVALID, "gemm_resid_ln: null output");
+    GemmArgs g{};
+    g.A = (const bf16_t*)a; g.W = (const bf16_t*)w; g.bias = bias; g.M = m; g.N = n; g.K = k;
+    g.C = c; g.ldc = n; g.accumulate = 1; g.variant = variant; g.xb = (bf16_t*)xb; g.ln_part_out = ln_part;
+    return sat_launch_gemm(EPI_RESID, g, (hipStream_t)stream);
+}
+
+extern "C" int sat_gemm_swiglu_ln_bf16(const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
+                                       const float* bias_f32, void* wpack, float* c12, void* h, int32_t m, int32_t n, int32_t k,
+                                       int32_t variant, sat_stream_t stream) {
+    SAT_CHECK_ARG(xb && ln_part && w_f32 && gamma && beta && wpack && c12 && h, SAT_E_INVALID, "gemm_swiglu_ln: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, bias_f32, (bf16_t*)wpack, c12, c12 + n, n, k, 1, s));
+    GemmArgs g{};
+    g.A = (const bf16_t*)xb; g.W = (const bf16_t*)wpack; g.M = m; g.N = n; g.K = k; g.H = (bf16_t*)h; g.variant = variant;
+    g.ln_part = ln_part; g.ln_c1 = c12; g.ln_c2 = c12 + n; g.ln_eps = 1e-5f;
+    return sat_launch_gemm(EPI_SWIGLU, g, s);
+}
+
+extern "C" int sat_qkv_rope_ln_bf16(const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
+                                    void* wpack, float* c12, const float* inv_freq, void* q, void* k, void* vt, float* rope_scratch,
+                                    int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant, sat_stream_t stream) {
+    SAT_CHECK_ARG(xb && ln_part && w_f32 && gamma && beta && wpack && c12 && inv_freq && q && k && vt && rope_scratch, SAT_E_INVALID,
+                  "qkv_rope_ln: null pointer");
+    SAT_CHECK_ARG(d % 64 == 0 && s_pad >= s_len + 3 && s_pad % 128 == 0, SAT_E_INVALID, "qkv_rope_ln: bad dims (s_pad >= s + 3, %% 128)");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = d / 64;
+    const size_t bytes = (size_t)b * H * s_pad * 64 * 2;
+    SAT_HIP(hipMemsetAsync(q, 0, bytes, s));
+    SAT_HIP(hipMemsetAsync(k, 0, bytes, s));
+    SAT_HIP(hipMemsetAsync(vt, 0, bytes, s));
+    float* cs = rope_scratch;
+    float* sn = rope_scratch + (size_t)s_len * 16;
+    SAT_TRY(sat_launch_rope_table(inv_freq, cs, sn, s_len, s));
+    SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, nullptr, (bf16_t*)wpack, c12, c12 + 3 * d, 3 * d, d, 0, s));
+    GemmArgs g{};
+    g.A = (const bf16_t*)xb; g.W = (const bf16_t*)wpack; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant;
+    g.heads.out[0] = (bf16_t*)q; g.heads.out[1] = (bf16_t*)k; g.heads.out[2] = (bf16_t*)vt;
+    g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
+    g.heads.parts = 3; g.heads.heads = H; g.heads.S = s_len; g.heads.Spad = s_pad;
+    g.heads.rope_cos = cs; g.heads.rope_sin = sn;
+    g.ln_part = ln_part; g.ln_c1 = c12; g.ln_c2 = c12 + 3 * d; g.ln_eps = 1e-5f;
     return sat_launch_gemm(EPI_HEADS, g, s);
 }
 

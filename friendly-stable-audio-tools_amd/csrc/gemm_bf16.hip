@@ -17,9 +17,13 @@
 
 namespace {
 
-template <int EPI, int MI, int NI>
+template <int EPI, int MI, int NI, bool LNC = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
-                                              const int l31) {
+                                              const int l31, const float2* ln = nullptr, const float* lc1 = nullptr,
+                                              const float* lc2 = nullptr) {
+    // LNC (bf16 pipelined kernels, EPI_HEADS / EPI_SWIGLU): out = rstd * (acc - mean * c1) + c2 with (mean, rstd) of the wave's TM
+    // token rows at `ln` and the wave's 64 channel constants at lc1 / lc2, all in LDS -- the LayerNorm fold of GemmArgs, or
+    // (0, 1), 0, bias without it
     const int M = g.M, N = g.N;
     (void)N;
     // acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31   (guide section 3)
@@ -109,6 +113,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         // tokens a lane holds (rows 4q..4q+3 of the GEMM) land on an 8-byte aligned V^T span: one dwordx2 store
         // instead of four 2-byte scatters.  The attention kernel applies the same shift to its key index.
         const bool shift = (kind & 4) != 0;
+        float c1a = 0.f, c1b = 0.f, c2a = 0.f, c2b = 0.f;
+        if constexpr (LNC) {
+            c1a = lc1[l31];
+            c1b = lc1[32 + l31];
+            c2a = lc2[l31];
+            c2b = lc2[32 + l31];
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -116,6 +127,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 const int mb = mw + i * 32 + 8 * rq + 4 * half;          // first of 4 consecutive rows, multiple of 4
                 float v0[4], v1[4];
                 int bb[4], ss[4];
+                f32x4 st01 = {0.f, 1.f, 0.f, 1.f}, st23 = {0.f, 1.f, 0.f, 1.f};      // (mean, rstd) of rows e = 0,1 / 2,3
+                if constexpr (LNC) {
+                    const f32x4* sp = reinterpret_cast<const f32x4*>(ln + i * 32 + 8 * rq + 4 * half);
+                    st01 = sp[0];
+                    st23 = sp[1];
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = rq * 4 + e;
@@ -125,6 +142,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                     ss[e] = mm - bb[e] * S;
                     v0[e] = acc[i][0][r];
                     v1[e] = acc[i][1][r];
+                    if constexpr (LNC) {
+                        const float mean = e < 2 ? st01[2 * e] : st23[2 * e - 4];
+                        const float rstd = e < 2 ? st01[2 * e + 1] : st23[2 * e - 3];
+                        v0[e] = rstd * (v0[e] - mean * c1a) + c2a;
+                        v1[e] = rstd * (v1[e] - mean * c1b) + c2b;
+                    }
                     if (kind & 2) {   // wave-uniform: partial RoPE on d < 32 (pairs d, d^16)
                         float p = __shfl_xor(v0[e], 16, 64);
                         int jf = l31 & 15;
@@ -205,9 +228,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int EPI, int MI, int NI, bool NOSTORE = false>
+template <int EPI, int MI, int NI, bool NOSTORE = false, bool LNC = false>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
-                                                const int l31) {
+                                                const int l31, const float2* ln = nullptr, const float* lc1 = nullptr,
+                                                const float* lc2 = nullptr) {
     // NOSTORE (ablation builds only): all the arithmetic, stores behind a never-true runtime test
     const int M = NOSTORE ? (g.K < 0 ? g.M : 0) : g.M, N = g.N;
     (void)N;
@@ -241,21 +265,39 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
         static_assert(NI == 2, "value block + gate block");
         const int ldh = N >> 1;
         const int hc0 = nw >> 1;                       // first hidden column of this wave's 32
-        f32x4 bv[4], bg[4];
+        [[maybe_unused]] f32x4 bv[LNC ? 1 : 4], bg[LNC ? 1 : 4];
+        if constexpr (!LNC) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bv[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nw + 4 * half + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
-            bg[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nw + 32 + 4 * half + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 4; ++q) {
+                bv[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nw + 4 * half + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bg[q] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + nw + 32 + 4 * half + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = mw + i * 32 + l31;
             float hv[16];
+            if constexpr (LNC) {      // LayerNorm fold: finish the normalisation of token row m (bias is part of ln_c2)
+                const float2 st = ln[i * 32 + l31];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[i][0][r] + bv[r >> 2][r & 3];
-                const float gt = acc[i][1][r] + bg[r >> 2][r & 3];
-                hv[r] = m < M ? v * silu_f(gt) : 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 4 * half + q * 8;
+                    const f32x4 c1v = *reinterpret_cast<const f32x4*>(lc1 + c), c1g = *reinterpret_cast<const f32x4*>(lc1 + c + 32);
+                    const f32x4 c2v = *reinterpret_cast<const f32x4*>(lc2 + c), c2g = *reinterpret_cast<const f32x4*>(lc2 + c + 32);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = st.y * (acc[i][0][4 * q + e] - st.x * c1v[e]) + c2v[e];
+                        const float gt = st.y * (acc[i][1][4 * q + e] - st.x * c1g[e]) + c2g[e];
+                        hv[4 * q + e] = m < M ? v * silu_f(gt) : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][0][r] + bv[r >> 2][r & 3];
+                    const float gt = acc[i][1][r] + bg[r >> 2][r & 3];
+                    hv[r] = m < M ? v * silu_f(gt) : 0.f;
+                }
             }
             if (g.H8) {
                 // MXFP8: the 32 hidden columns of this wave are ONE block of row m, held by the lane pair (l31, l31 + 32)
@@ -320,6 +362,18 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
             const int b = mc / S;
             const int s = mc - b * S;
             const int ob = (kind & 4) ? ((b * S) & 3) : 0;
+            if constexpr (LNC) {         // LayerNorm fold (before the rotation: both are linear, this one is per channel)
+                const float2 st = ln[i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(lc1 + j * 32 + q * 8 + 4 * half);
+                        const f32x4 c2 = *reinterpret_cast<const f32x4*>(lc2 + j * 32 + q * 8 + 4 * half);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = st.y * (acc[i][j][4 * q + e] - st.x * c1[e]) + c2[e];
+                    }
+            }
             if (kind & 2) {   // partial RoPE on d < 32 (block j = 0): partner of d < 16 is d + 16 = register r + 8 of this lane
                 const f32x4 cs0 = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 4 * half);
                 const f32x4 cs1 = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 8 + 4 * half);
@@ -394,9 +448,28 @@ __device__ __forceinline__ void gemm_epilogue_f32_staged(const GemmArgs& g, f32x
                 const int row = (grp * 4 + p4) * 4 + prow;
                 const int m = mw + i * 32 + row;
                 f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 64 + c4) + bia;
-                if (m < M) {
-                    if (g.gate) v *= *reinterpret_cast<const f32x4*>(g.gate + (size_t)(m / g.gate_rows) * g.gate_ld + nw + c4);
-                    *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + nw + c4) = v + old[p4];
+                if (m < M && g.gate) v *= *reinterpret_cast<const f32x4*>(g.gate + (size_t)(m / g.gate_rows) * g.gate_ld + nw + c4);
+                v += old[p4];
+                if (m < M) *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + nw + c4) = v;
+                if (g.xb) {
+                    // LayerNorm fold, producer side (wave-uniform test): bf16 image of the updated row piece + the statistics of the
+                    // ROUNDED values over this wave's 64-column block (the 16 lanes of a DPP row hold one row of the pass)
+                    bf16x4 xr;
+                    float sum = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xr[e] = f32_to_bf16(v[e]);
+                        const float f = bf16_to_f32(xr[e]);
+                        sum += f;
+                        sq += f * f;
+                    }
+                    sum = row16_sum(sum);
+                    sq = row16_sum(sq);
+                    if (m < M) {
+                        *reinterpret_cast<bf16x4*>(g.xb + (size_t)m * g.N + nw + c4) = xr;
+                        if ((lane & 15) == 0)
+                            *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (g.N >> 6) + (nw >> 6)) * 2) = make_float2(sum, sq);
+                    }
                 }
             }
         }
@@ -740,6 +813,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         }
     }
 
+    // LayerNorm fold, consumer side: mean and 1/std of the BM rows of this tile from the producer's per-block partial sums, into
+    // LDS behind the ring (filled right after the prologue's LDS-DMA below, read by the epilogue).
+    constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && FP8 == 0 && DBG == 0;
+    // LDS behind the ring: (mean, 1/std) of the BM rows, then the BN (c1, c2) pairs of this tile's output channels
+    [[maybe_unused]] float2* lnst = reinterpret_cast<float2*>(smem + NS * STAGE_BYTES);
+    [[maybe_unused]] float* lnc = reinterpret_cast<float*>(smem + NS * STAGE_BYTES + BM * 8);      // c1[BN] then c2[BN]
     constexpr bool dbg_same = DBG == 1;
     constexpr bool dbg_noload = DBG == 2 || (DBG >= 4 && DBG != 8);      // 8: production main loop, stores suppressed
     constexpr bool dbg_noepi = DBG == 6;
@@ -971,6 +1050,51 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // prologue: tiles 0..D-1 in flight (nk >= D is guaranteed by the launcher)
 #pragma unroll
     for (int s = 0; s < D; ++s) stage_in(s, s);
+    // (after the prologue's LDS-DMA: the constants' global-memory round trip overlaps the first tiles' instead of preceding it; the
+    // K loop's barriers order these LDS writes before the epilogue's reads)
+    if constexpr (LN_CONS) {
+        // Without the fold the same epilogue runs on (mean, rstd) = (0, 1), c1 = 0, c2 = bias.
+        const bool ln_fold = g.ln_part != nullptr;
+        // TPR threads per row, each summing every TPR-th partial pair (independent loads, one round trip), combined with DPP
+        constexpr int TPR = (NT / BM >= 4) ? 4 : (NT / BM >= 2 ? 2 : 1);
+        const int np = K >> 6;
+        const int r = tid / TPR, sub = tid % TPR;
+        float sum = 0.f, sq = 0.f;
+        if (ln_fold && r < BM) {
+            int m = m0 + r;
+            m = m < M ? m : M - 1;
+            const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np;
+#pragma unroll 6
+            for (int i = sub; i < np; i += TPR) {
+                const float2 v = pp[i];
+                sum += v.x;
+                sq += v.y;
+            }
+        }
+        if constexpr (TPR >= 2) {
+            sum += dpp_move<0xB1>(sum);
+            sq += dpp_move<0xB1>(sq);
+        }
+        if constexpr (TPR >= 4) {
+            sum += dpp_move<0x4E>(sum);
+            sq += dpp_move<0x4E>(sq);
+        }
+        if (r < BM && sub == 0) {
+            const float inv_k = 1.0f / (float)K;
+            const float mean = sum * inv_k;
+            const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
+            lnst[r] = ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, 1.f);
+        }
+        // the last 2 BN / 4 threads bring in the channel constants, 16 bytes each
+        const int ct = NT - 1 - tid;
+        if (ct < BN / 2) {
+            const bool first = ct < BN / 4;
+            const float* src = ln_fold ? (first ? g.ln_c1 + n0 + ct * 4 : g.ln_c2 + n0 + (ct - BN / 4) * 4)
+                                       : ((first || !g.bias) ? nullptr : g.bias + n0 + (ct - BN / 4) * 4);
+            *reinterpret_cast<f32x4*>(lnc + ct * 4) = src ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
     int rd = 0;          // stage of tile k
     int wr = D;          // stage that receives tile k+D (== stage of tile k-1)
     // steady state: tiles k+1..k+D-1 stay in flight across the barrier
@@ -1096,8 +1220,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
     if (wave_rows_valid) {
         if constexpr (NI == 2 || EPI == EPI_F32) {
-            if (tr) gemm_epilogue_t<EPI, MI, NI, dbg_nostore>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
-            else gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
+            if (tr) gemm_epilogue_t<EPI, MI, NI, dbg_nostore, LN_CONS>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31, lnst + wm * TM, lnc + wn * TN, lnc + BN + wn * TN);
+            else gemm_epilogue<EPI, MI, NI, LN_CONS>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31, lnst + wm * TM, lnc + wn * TN, lnc + BN + wn * TN);
         } else {
             gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
         }
@@ -1107,8 +1231,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int FP8 = 0>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
-    constexpr int LDS = NS * ((BM + BN) * BK * 2 + (FP8 == 3 ? BM * 4 : 0));
+    constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && FP8 == 0 && DBG == 0;
+    constexpr int LDS = NS * ((BM + BN) * BK * 2 + (FP8 == 3 ? BM * 4 : 0)) + (LN_CONS ? (BM + BN) * 8 : 0);     // + (mean, rstd) per row, (c1, c2) per column
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
+    SAT_CHECK_ARG(LN_CONS || !a.ln_part, SAT_E_UNSUPPORTED, "gemm: LayerNorm fold needs bf16 operands and a SwiGLU / heads epilogue");
+    SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (EPI == EPI_F32 && BN / WN == 64 && FP8 == 0 && a.xb && a.ln_part_out), SAT_E_UNSUPPORTED,
+                  "gemm: the bf16 image / row statistics come from the bf16 fp32-output tiles with 64-column wave tiles");
     static_assert(EPI != EPI_F32 || BN / WN != 64 || LDS >= WM * WN * 8192, "the staged fp32 epilogue needs 8 KiB of LDS per wave");
     auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG, FP8>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
@@ -1130,6 +1258,7 @@ template <int BM, int BN, int WM, int WN, int EPI, bool GLDS = false>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
+    SAT_CHECK_ARG(!a.ln_part && !a.xb && !a.ln_part_out, SAT_E_UNSUPPORTED, "gemm: LayerNorm fold is built into the pipelined tiles only (K >= 192)");
     auto kern = GLDS ? gemm_glds_kernel<BM, BN, WM, WN, EPI> : gemm_kernel<BM, BN, WM, WN, EPI>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", a.N, BN);
@@ -1269,6 +1398,10 @@ int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG((((uintptr_t)a.bias | (uintptr_t)a.C | (uintptr_t)a.H | (uintptr_t)a.gate | (uintptr_t)a.w_scale) & 15) == 0 && a.ldc % 4 == 0 &&
                       a.gate_ld % 4 == 0,
                   SAT_E_INVALID, "gemm: bias / output / gate / scale pointers must be 16-byte aligned and ldc a multiple of 4");
+    SAT_CHECK_ARG(!a.ln_part || (a.ln_c1 && a.ln_c2 && a.ln_eps > 0.f && !a.bias && !a.fp8 && a.K % 64 == 0 &&
+                                 (((uintptr_t)a.ln_part | (uintptr_t)a.ln_c1 | (uintptr_t)a.ln_c2) & 15) == 0),
+                  SAT_E_INVALID, "gemm: LayerNorm fold needs ln_c1 / ln_c2 / ln_eps, no separate bias (it is part of ln_c2), 16-byte aligned vectors");
+    SAT_CHECK_ARG((((uintptr_t)a.xb | (uintptr_t)a.ln_part_out) & 15) == 0, SAT_E_INVALID, "gemm: xb / ln_part_out must be 16-byte aligned");
     switch (epi) {
         case EPI_F32:
         case EPI_RESID: return launch_epi<EPI_F32>(a, stream);

@@ -150,6 +150,49 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     }
 }
 
+// Weights of a GEMM that absorbs the LayerNorm in front of it (GemmArgs::ln_*): out[n'][k] = bf16(gamma[k] * w[src(n')][k]),
+// c1[n'] = sum_k float(out[n'][k]) (the sum of what the MFMA will actually multiply), c2[n'] = sum_k beta[k] * w[src][k] + bias.
+// One workgroup per output row, same row permutation as pack_rows_kernel.
+__global__ __launch_bounds__(256) void pack_rows_ln_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ bias,
+                                                           bf16_t* __restrict__ out, float* __restrict__ c1, float* __restrict__ c2, int n, int k,
+                                                           int interleave) {
+    __shared__ float red[2][4];
+    const int row = blockIdx.x;
+    int src = row;
+    if (interleave) {
+        int g = row >> 6, c = row & 63;
+        src = (c < 32) ? (g * 32 + c) : (n / 2 + g * 32 + (c - 32));
+    }
+    const float* wr = w + (size_t)src * k;
+    bf16_t* o = out + (size_t)row * k;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x * 4; i < k; i += 256 * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(wr + i);
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + i);
+        const float4 bt = *reinterpret_cast<const float4*>(beta + i);
+        bf16x4 p;
+        p[0] = f32_to_bf16(v.x * gm.x);
+        p[1] = f32_to_bf16(v.y * gm.y);
+        p[2] = f32_to_bf16(v.z * gm.z);
+        p[3] = f32_to_bf16(v.w * gm.w);
+        *reinterpret_cast<bf16x4*>(o + i) = p;
+        s1 += (bf16_to_f32(p[0]) + bf16_to_f32(p[1])) + (bf16_to_f32(p[2]) + bf16_to_f32(p[3]));
+        s2 += (v.x * bt.x + v.y * bt.y) + (v.z * bt.z + v.w * bt.w);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s1;
+        red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c1[row] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        c2[row] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + (bias ? bias[src] : 0.f);
+    }
+}
+
 // one workgroup per output row: amax -> scale = amax / 448 -> e4m3 bytes (4 per thread per pass); same row permutation as
 // pack_rows_kernel for the SwiGLU weight
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const float* __restrict__ w, unsigned char* __restrict__ out,
@@ -292,6 +335,15 @@ int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swi
     SAT_CHECK_ARG(w && out && n > 0 && k > 0 && k % 4 == 0, SAT_E_INVALID, "pack_rows: bad args");
     SAT_CHECK_ARG(!swiglu_interleave || n % 128 == 0, SAT_E_UNSUPPORTED, "pack_rows: swiglu needs n %% 128 == 0");
     hipLaunchKernelGGL(pack_rows_kernel, dim3(n), dim3(256), 0, s, w, out, n, k, swiglu_interleave);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
+int sat_launch_pack_rows_ln(const float* w, const float* gamma, const float* beta, const float* bias, bf16_t* out, float* c1, float* c2,
+                            int n, int k, int swiglu_interleave, hipStream_t s) {
+    SAT_CHECK_ARG(w && gamma && beta && out && c1 && c2 && n > 0 && k > 0 && k % 4 == 0, SAT_E_INVALID, "pack_rows_ln: bad args");
+    SAT_CHECK_ARG(!swiglu_interleave || n % 128 == 0, SAT_E_UNSUPPORTED, "pack_rows_ln: swiglu needs n %% 128 == 0");
+    hipLaunchKernelGGL(pack_rows_ln_kernel, dim3(n), dim3(256), 0, s, w, gamma, beta, bias, out, c1, c2, n, k, swiglu_interleave);
     SAT_LAUNCH_CHECK();
     return 0;
 }

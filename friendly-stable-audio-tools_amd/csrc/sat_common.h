@@ -118,6 +118,15 @@ __device__ __forceinline__ float half32_max(float v) {
     return fmaxf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)));   // lane ^ 16
 }
 
+// sum over each aligned group of 16 lanes (one DPP row), result in all 16 lanes
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return v;
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids
 // land on the same XCD (hardware places block b on XCD b % 8), so neighbouring tiles share
 // one L2.  Speed only -- never correctness.
@@ -196,6 +205,17 @@ struct GemmArgs {
     bf16_t* H;           // [M, N/2]
     // EPI_HEADS
     HeadsEpi heads;
+    // ---- LayerNorm folded into the GEMMs either side of the residual stream (bf16 operands, pipelined tiles only).
+    // LN(x) W^T = rstd * (x (gamma (.) W)^T - mean * rowsum(gamma (.) W)) + beta W^T: the GEMM that UPDATES the residual stream
+    // (EPI_RESID, the "producer") also writes the bf16 image of the new rows and, per row and 64-column block, the sum and the
+    // sum of squares of those rounded values; the GEMM that CONSUMES the normalised rows (EPI_SWIGLU / EPI_HEADS) takes the bf16
+    // image as its A operand, gamma-scaled weights, and finishes the normalisation on its fp32 accumulators.
+    bf16_t* xb;                // producer: [M, N] bf16(C after the update), or nullptr
+    float* ln_part_out;        // producer: [M][N / 64][2]
+    const float* ln_part;      // consumer: [M][K / 64][2] partial (sum, sum of squares) of A's rows, or nullptr (no fold)
+    const float* ln_c1;        // consumer: [N] sum_k bf16(gamma_k W_nk), epilogue channel order
+    const float* ln_c2;        // consumer: [N] sum_k beta_k W_nk (+ bias_n)
+    float ln_eps;
 };
 
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream);
@@ -225,4 +245,8 @@ int sat_launch_attention_f32(const float* q, const float* k, const float* v, flo
 int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
 int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swiglu_interleave, hipStream_t s);
 int sat_launch_pack_bias(const float* b, float* out, int n, int swiglu_interleave, hipStream_t s);
+// weights of a GEMM that absorbs the LayerNorm in front of it: out = bf16(gamma (.) w) (rows permuted like pack_rows),
+// c1[n] = sum_k float(out[n][k]), c2[n] = sum_k beta[k] w[n][k] (+ bias[n])
+int sat_launch_pack_rows_ln(const float* w, const float* gamma, const float* beta, const float* bias, bf16_t* out, float* c1, float* c2,
+                            int n, int k, int swiglu_interleave, hipStream_t s);
 int sat_launch_rope_table(const float* inv_freq, float* cos_t, float* sin_t, int s_len, hipStream_t s);

@@ -21,7 +21,7 @@ class SatError(RuntimeError):
 class SatDitCfg(Structure):
     _fields_ = [("io_channels", c_int32), ("embed_dim", c_int32), ("depth", c_int32), ("num_heads", c_int32),
                 ("cond_token_dim", c_int32), ("cond_embed_dim", c_int32), ("global_cond_dim", c_int32),
-                ("max_seq_len", c_int32), ("adaln", c_int32), ("fp8_gemm", c_int32)]
+                ("max_seq_len", c_int32), ("adaln", c_int32), ("fp8_gemm", c_int32), ("ln_fold", c_int32)]
 
 
 class SatOobleckCfg(Structure):
@@ -78,6 +78,10 @@ _SIGNATURES = {
                                      c_int32, c_int32, c_void_p]),
     "sat_qkv_rope_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                     c_int32, c_int32, c_int32, c_void_p]),
+    "sat_gemm_resid_ln_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p]),
+    "sat_gemm_swiglu_ln_bf16": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "sat_qkv_rope_ln_bf16": (c_int32, [c_void_p] * 12 + [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "sat_snake_beta": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "sat_overlap_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "sat_number_embed": (c_int32, [c_void_p, c_int32, c_float, c_float, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),

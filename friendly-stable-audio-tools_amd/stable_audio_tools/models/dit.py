@@ -69,6 +69,15 @@ class DiffusionTransformer(nn.Module):
         self._ws = None
         self._ctx_key = None
         self.gemm_dtype = "bf16"
+        self.layernorm_fusion = True
+
+    def set_layernorm_fusion(self, on: bool):
+        """Build extension: run the LayerNorms of the blocks (transformer.py:692-700) inside the epilogues of the GEMMs either side of
+        them (``sat_dit_cfg.ln_fold``; bf16 / "prepend" models) or as standalone kernels.  Rebuilds the plan on next use."""
+        if bool(on) != self.layernorm_fusion:
+            self.layernorm_fusion = bool(on)
+            self._plan_version = None
+        return self
 
     def set_gemm_dtype(self, dtype: str):
         """Build extension: "bf16" (default), "fp8" (BASELINE config 5: OCP e4m3 / MXFP8 operands for the block GEMMs) or "fp32x" --
@@ -102,7 +111,8 @@ class DiffusionTransformer(nn.Module):
             self._plan = None
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
                              self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
-                             1 if self.global_cond_type == "adaLN" else 0, {"bf16": 0, "fp8": 1, "fp32x": 2}[self.gemm_dtype])
+                             1 if self.global_cond_type == "adaLN" else 0, {"bf16": 0, "fp8": 1, "fp32x": 2}[self.gemm_dtype],
+                             1 if self.layernorm_fusion else 0)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
         keep = []

@@ -77,6 +77,13 @@ typedef struct sat_dit_cfg {
                                   2: fp32 VERIFICATION mode -- every contraction of the blocks on the exact fp32 MFMA
                                   (v_mfma_f32_32x32x2_f32), fp32 LayerNorm output, fp32 q / k / v / P, fp32 weights: same plan, data flow
                                   and index arithmetic, no operand rounding (~20x slower; meets 1e-3 vs the reference's outputs) */
+    int32_t ln_fold;           /* 1 (fp8_gemm == 0, adaln == 0, embed_dim >= 256; ignored otherwise): no standalone LayerNorm launches
+                                  after the first one.  LN(x) W^T = rstd (x (gamma.W)^T - mean rowsum(gamma.W)) + beta W^T: the GEMM
+                                  that updates the residual stream (to_out, FF-out; transformer.py:692-700) also writes bf16(x) and
+                                  per-row partial sums, the GEMM behind the LayerNorm (to_qkv, to_q, FF-in) multiplies bf16(x) with
+                                  bf16(gamma.W) and finishes the normalisation on its fp32 accumulators.  Same arithmetic up to WHERE
+                                  the one bf16 rounding of the activation happens (before instead of after the normalisation);
+                                  0: three LayerNorm kernels per block */
 } sat_dit_cfg;
 
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
@@ -266,6 +273,25 @@ int sat_attention_bf16(const void* q_dev, const void* k_dev, const void* vt_dev,
 int sat_qkv_rope_bf16(const void* a_bf16_dev, const void* w_bf16_dev, const float* inv_freq_dev,
                       void* q_dev, void* k_dev, void* vt_dev, float* rope_scratch_dev,
                       int32_t b, int32_t s, int32_t s_pad, int32_t d, int32_t variant, sat_stream_t stream);
+/* LayerNorm folded into the GEMMs either side of it (sat_dit_cfg.ln_fold; models/transformer.py:692-700: x + f(LayerNorm(x))).
+ * Producer = the GEMM that updates the residual stream (to_out, FF-out; transformer.py:319, 270):
+ *   c [m, n] fp32 += a [m, k] . w [n, k]^T + bias; xb [m, n] bf16 = bf16(c); ln_part [m][n / 64][2] fp32 = per 64-column block
+ *   (sum, sum of squares) of the rounded row.  n % 128 == 0, k % 64 == 0, k >= 192. */
+int sat_gemm_resid_ln_bf16(const void* a_bf16_dev, const void* w_bf16_dev, const float* bias_dev, float* c_dev, void* xb_dev,
+                           float* ln_part_dev, int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream);
+/* Consumers: xb / ln_part as written by the producer (k = its n).  SwiGLU FF-in (transformer.py:222, 232-235) of LayerNorm(x):
+ * w_f32 [n, k], gamma / beta [k], bias [n] fp32 (reference layout: value rows then gate rows) -> h [m, n / 2] bf16.
+ * wpack [n, k] bf16 and c12 [2 n] fp32 receive the re-packed operands: bf16(gamma (.) w) (value / gate rows interleaved by 32),
+ * c1 = its row sums, c2 = w beta + bias; the epilogue computes rstd (acc - mean c1) + c2 before value * silu(gate). */
+int sat_gemm_swiglu_ln_bf16(const void* xb_dev, const float* ln_part_dev, const float* w_f32_dev, const float* gamma_dev,
+                            const float* beta_dev, const float* bias_f32_dev, void* wpack_dev, float* c12_dev, void* h_dev, int32_t m,
+                            int32_t n, int32_t k, int32_t variant, sat_stream_t stream);
+/* to_qkv + partial RoPE + head split of LayerNorm(x) (transformer.py:314, 430-452); outputs as sat_qkv_rope_bf16.
+ * w_f32 [3d, d]; wpack [3d, d] bf16 and c12 [6 d] fp32 receive the re-packed operands. */
+int sat_qkv_rope_ln_bf16(const void* xb_dev, const float* ln_part_dev, const float* w_f32_dev, const float* gamma_dev,
+                         const float* beta_dev, void* wpack_dev, float* c12_dev, const float* inv_freq_dev, void* q_dev, void* k_dev,
+                         void* vt_dev, float* rope_scratch_dev, int32_t b, int32_t s, int32_t s_pad, int32_t d, int32_t variant,
+                         sat_stream_t stream);
 /* SnakeBeta (models/blocks.py:318-319): y = x + sin^2(x*exp(alpha_c)) / (exp(beta_c)+1e-9); x,y [b,c,t] fp32 */
 int sat_snake_beta(const float* x_dev, const float* alpha_dev, const float* beta_dev, float* y_dev,
                    int32_t b, int32_t c, int32_t t, sat_stream_t stream);

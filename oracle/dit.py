@@ -69,6 +69,50 @@ class Fp8Rounding:
     weight_o = staticmethod(fp8_rows)         # to_out weights (self and cross), per output channel
 
 
+class _Folded:
+    """Un-normalised rows + the affine parameters of the LayerNorm in front of a Linear (LnFoldRounding only)."""
+
+    def __init__(self, x, gamma, beta):
+        self.x, self.gamma, self.beta = x, gamma, beta
+
+
+class LnFoldRounding:
+    """Matched-rounding hook of ``sat_dit_cfg.ln_fold`` (the default plan for bf16 / "prepend" models): bf16 at the same points as
+    ``bf16_round``, except that a LayerNorm and the Linear behind it (to_qkv from the second block on, cross to_q, FF-in) are
+    evaluated the way the fused kernels do it -- the activation is rounded to bf16 BEFORE the normalisation, the statistics are
+    those of the rounded rows, gamma is folded into the bf16 weights, beta and the bias into a per-channel constant:
+        LN(x) W^T + b  =  rstd (bf16(x) bf16(gamma . W)^T  -  mean rowsum(bf16(gamma . W)))  +  (W beta + b)."""
+
+    ln_fold = True
+
+    def __call__(self, x):
+        return bf16_round(x)
+
+    @staticmethod
+    def folded_linear(h, w, bias=None):
+        xb = bf16_round(h.x)
+        mean = xb.mean(dim=-1, keepdim=True)
+        var = ((xb * xb).mean(dim=-1, keepdim=True) - mean * mean).clamp_min(0.0)
+        rstd = torch.rsqrt(var + 1e-5)
+        wp = bf16_round(h.gamma * w)
+        c2 = F.linear(h.beta, w) if bias is None else F.linear(h.beta, w) + bias
+        return rstd * (F.linear(xb, wp) - mean * wp.sum(dim=-1)) + c2
+
+
+def _norm_for_gemm(rnd, x, gamma, beta, fold=True):
+    """LayerNorm whose output feeds a GEMM (transformer.py:692, 695, 700), with the operand rounding of ``rnd``."""
+    if fold and getattr(rnd, "ln_fold", False):
+        return _Folded(x, gamma, beta)
+    return _ra(rnd, layer_norm(x, gamma, beta))
+
+
+def _lin(rnd, h, w, bias=None):
+    """The Linear behind a LayerNorm."""
+    if isinstance(h, _Folded):
+        return rnd.folded_linear(h, w, bias)
+    return F.linear(h, _rw(rnd, w), bias)
+
+
 def _ra(rnd, x):      # a LayerNorm output that feeds a GEMM
     return rnd.act(x) if hasattr(rnd, "act") else _r(rnd, x)
 
@@ -134,8 +178,7 @@ def _merge(t):
 
 # models/transformer.py:407-554 (Attention.forward), self-attention branch (to_qkv)
 def self_attention(sd, pfx, x, freqs, num_heads, rnd=None):
-    w_qkv = _rw(rnd, sd[pfx + "to_qkv.weight"])
-    q, k, v = F.linear(x, w_qkv).chunk(3, dim=-1)
+    q, k, v = _lin(rnd, x, sd[pfx + "to_qkv.weight"]).chunk(3, dim=-1)
     q, k, v = (_heads(t, num_heads) for t in (q, k, v))
     q = apply_rotary(q.float(), freqs)      # transformer.py:438-452
     k = apply_rotary(k.float(), freqs)
@@ -148,7 +191,7 @@ def self_attention(sd, pfx, x, freqs, num_heads, rnd=None):
 
 # models/transformer.py:407-554, cross-attention branch (to_q / to_kv; no RoPE: :438)
 def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
-    q = _heads(F.linear(x, _rw(rnd, sd[pfx + "to_q.weight"])), num_heads)
+    q = _heads(_lin(rnd, x, sd[pfx + "to_q.weight"]), num_heads)
     kv = F.linear(context, _r(rnd, sd[pfx + "to_kv.weight"]))
     k, v = kv.chunk(2, dim=-1)
     kv_heads = k.shape[-1] // dim_heads
@@ -162,7 +205,7 @@ def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
 
 # models/transformer.py:211-287 (GLU + FeedForward; value = first half, gate = second half)
 def feed_forward(sd, pfx, x, rnd=None):
-    h = F.linear(x, _rw(rnd, sd[pfx + "ff.0.proj.weight"]), sd[pfx + "ff.0.proj.bias"])
+    h = _lin(rnd, x, sd[pfx + "ff.0.proj.weight"], sd[pfx + "ff.0.proj.bias"])
     val, gate = h.chunk(2, dim=-1)
     h = rnd.hidden(val * F.silu(gate)) if hasattr(rnd, "hidden") else _r(rnd, val * F.silu(gate))
     w2 = rnd.weight2(sd[pfx + "ff.2.weight"]) if hasattr(rnd, "weight2") else _r(rnd, sd[pfx + "ff.2.weight"])
@@ -170,7 +213,7 @@ def feed_forward(sd, pfx, x, rnd=None):
 
 
 # models/transformer.py:656-702 (TransformerBlock.forward: adaLN branch :665-689, plain branch :691-700)
-def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None, global_cond=None):
+def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None, global_cond=None, first=False):
     if global_cond is not None and (pfx + "to_scale_shift_gate.1.weight") in sd:
         ssg = F.linear(F.silu(global_cond), sd[pfx + "to_scale_shift_gate.1.weight"]).unsqueeze(1)      # :667
         scale_self, shift_self, gate_self, scale_ff, shift_ff, gate_ff = ssg.chunk(6, dim=-1)
@@ -184,12 +227,13 @@ def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None
         h = _ra(rnd, h * (1 + scale_ff) + shift_ff)                                                        # :685-686
         x = x + feed_forward(sd, pfx + "ff.", h, rnd) * torch.sigmoid(1 - gate_ff)                        # :687-689
         return x
-    h = _ra(rnd, layer_norm(x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"]))
+    # (the first block's pre_norm reads rows that no GEMM epilogue wrote: the ln_fold plan keeps it a standalone LayerNorm)
+    h = _norm_for_gemm(rnd, x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"], fold=not first)
     x = x + self_attention(sd, pfx + "self_attn.", h, freqs, num_heads, rnd)
     if context is not None:
-        h = _ra(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]))
+        h = _norm_for_gemm(rnd, x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"])
         x = x + cross_attention(sd, pfx + "cross_attn.", h, context, num_heads, dim_heads, rnd)
-    h = _ra(rnd, layer_norm(x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"]))
+    h = _norm_for_gemm(rnd, x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"])
     x = x + feed_forward(sd, pfx + "ff.", h, rnd)
     return x
 
@@ -204,7 +248,7 @@ def continuous_transformer(sd, x, prepend_embeds, context, depth, num_heads, rnd
     freqs = rotary_freqs(sd[pfx + "rotary_pos_emb.inv_freq"], x.shape[1])
     hidden = []
     for i in range(depth):
-        x = transformer_block(sd, f"{pfx}layers.{i}.", x, context, freqs, num_heads, dim_heads, rnd, global_cond)
+        x = transformer_block(sd, f"{pfx}layers.{i}.", x, context, freqs, num_heads, dim_heads, rnd, global_cond, first=i == 0)
         if return_hidden:
             hidden.append(x)
     out = F.linear(x, sd[pfx + "project_out.weight"])

@@ -171,6 +171,105 @@ def test_qkv_rope(dev, variant, s, s_pad):
     assert (qd[:, :, s:] == 0).all(), "Q pads must be zero"
 
 
+def _ln_fold_producer(dev, m, d, k, variant, seed=40):
+    """x0 + a w^T + bias through the producer entry; returns (c fp32, xb bf16, ln_part) on the device after checking them."""
+    _hip, lib = _lib()
+    a = _rand((m, k), seed).to(torch.bfloat16)
+    w = (_rand((d, k), seed + 1) * 0.05 + torch.linspace(-0.02, 0.03, d)[:, None]).to(torch.bfloat16)
+    bias = _rand((d,), seed + 2)
+    x0 = _rand((m, d), seed + 3, 2.0) + 0.3           # rows with a mean: the fold has to subtract it
+    want = a.float() @ w.float().T + bias + x0
+    ad, wd, bd, cd = a.to(dev), w.to(dev), bias.to(dev), x0.to(dev)
+    xb = torch.full((m, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    part = torch.full((m, d // 64, 2), float("nan"), dtype=torch.float32, device=dev)
+    _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), _hip.ptr(xb), _hip.ptr(part), m, d, k,
+                                          variant, _hip.stream()))
+    assert_close(f"ln-fold producer v{variant}", cd, want, 1e-3)
+    assert torch.equal(xb, cd.to(torch.bfloat16)), "xb must be the bf16 rounding of the fp32 rows just written"
+    blocks = xb.float().view(m, d // 64, 64).double()
+    assert_close("ln-fold partial sums", part[..., 0], blocks.sum(-1), 1e-5)
+    assert_close("ln-fold partial squares", part[..., 1], (blocks * blocks).sum(-1), 1e-5)
+    return cd, xb, part
+
+
+def _ln_fold_reference(xb, w, gamma, beta, bias):
+    """What the consumer computes, in fp64 on the same rounded operands: rstd (xb (gamma.w)^T - mean c1) + c2."""
+    x = xb.double().cpu()
+    mean = x.mean(-1, keepdim=True)
+    var = (x * x).mean(-1, keepdim=True) - mean * mean
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    wp = bf16_round(gamma * w).double()
+    c2 = (w.double() * beta.double()).sum(-1) + (bias.double() if bias is not None else 0.0)
+    return (rstd * (x @ wp.T - mean * wp.sum(-1)) + c2).float()
+
+
+@pytest.mark.parametrize("m", [300, 770])
+@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (0, 0)])
+def test_ln_fold_swiglu(dev, prod, cons, m):
+    """LayerNorm folded into FF-in (sat_dit_cfg.ln_fold): producer epilogue -> bf16 rows + partial sums -> SwiGLU GEMM that finishes
+    the normalisation.  Gates: 4e-3 against the same arithmetic in fp64 (one bf16 rounding of the output), 1e-2 against the plain fp32
+    LayerNorm -> Linear -> SwiGLU of the reference (transformer.py:700, 222, 232-235; adds the bf16 rounding of the operands)."""
+    _hip, lib = _lib()
+    d, inner = 768, 768
+    cd, xb, part = _ln_fold_producer(dev, m, d, 256, prod)
+    w = _rand((2 * inner, d), 50) * 0.08
+    gamma = 0.8 + 0.2 * _rand((d,), 51)
+    beta = 0.1 * _rand((d,), 52)
+    bias = 0.1 * _rand((2 * inner,), 53)
+    wd, gd, bd, bbd = w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev)
+    wp = torch.empty((2 * inner, d), dtype=torch.bfloat16, device=dev)
+    c12 = torch.empty((4 * inner,), dtype=torch.float32, device=dev)
+    out = torch.full((m, inner), float("nan"), dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(bbd), _hip.ptr(wp),
+                                           _hip.ptr(c12), _hip.ptr(out), m, 2 * inner, d, cons, _hip.stream()))
+    val, gate = _ln_fold_reference(xb, w, gamma, beta, bias).chunk(2, dim=-1)
+    assert_close("ln-fold swiglu vs same arithmetic", out, val * F.silu(gate), 4e-3)
+    val, gate = F.linear(F.layer_norm(cd.cpu(), (d,), gamma, beta, eps=1e-5), w, bias).chunk(2, dim=-1)
+    assert_close("ln-fold swiglu vs fp32 LayerNorm + Linear", out, val * F.silu(gate), 1e-2)
+
+
+@pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
+@pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (0, 0)])
+def test_ln_fold_qkv_rope(dev, prod, cons, s, s_pad):
+    """LayerNorm folded into to_qkv + RoPE + head split (transformer.py:692, 314, 430-452): q / k through the transposed epilogue,
+    V^T through the un-swapped one -- both have to apply the per-row statistics."""
+    from oracle import dit as odit
+    _hip, lib = _lib()
+    b, d = 2, 768
+    h = d // 64
+    cd, xb, part = _ln_fold_producer(dev, b * s, d, 256, prod, seed=60)
+    w = _rand((3 * d, d), 70) * 0.06
+    gamma = 0.8 + 0.2 * _rand((d,), 71)
+    beta = 0.1 * _rand((d,), 72)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    freqs = odit.rotary_freqs(inv_freq, s)
+
+    def split(qkv):
+        q, k, v = (odit._heads(t, h) for t in qkv.view(b, s, 3 * d).chunk(3, dim=-1))
+        return odit.apply_rotary(q, freqs), odit.apply_rotary(k, freqs), v
+
+    same = split(_ln_fold_reference(xb, w, gamma, beta, None))
+    plain = split(F.linear(F.layer_norm(cd.cpu(), (d,), gamma, beta, eps=1e-5), w))
+    wd, gd, bd, fd = w.to(dev), gamma.to(dev), beta.to(dev), inv_freq.to(dev)
+    wp = torch.empty((3 * d, d), dtype=torch.bfloat16, device=dev)
+    c12 = torch.empty((6 * d,), dtype=torch.float32, device=dev)
+    qd = torch.full((b, h, s_pad, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    kd = torch.full_like(qd, float("nan"))
+    vtd = torch.full((b, h, 64, s_pad), float("nan"), dtype=torch.bfloat16, device=dev)
+    scratch = torch.empty((2 * s * 16,), dtype=torch.float32, device=dev)
+    _hip.check(lib.sat_qkv_rope_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(wp), _hip.ptr(c12),
+                                        _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(scratch), b, s, s_pad, d, cons,
+                                        _hip.stream()))
+    vtd = vtd[..., _vt_perm(s_pad).to(vtd.device)]
+    for (q, k, v), tol in ((same, 4e-3), (plain, 1e-2)):
+        assert_close("ln-fold q", qd[:, :, :s], q, tol)
+        for i in range(b):
+            ob = (i * s) & 3
+            assert_close("ln-fold k", kd[i, :, ob:ob + s], k[i], tol)
+            assert_close("ln-fold v^T", vtd[i, :, :, ob:ob + s], v[i].transpose(1, 2), tol)
+    assert (qd[:, :, s:] == 0).all(), "Q pads must be zero"
+
+
 def test_snake_vae_int16(dev):
     from oracle import oobleck as oob
     _hip, lib = _lib()

@@ -30,6 +30,13 @@ def _build(cfg, seed, dev):
     return model.to(dev).eval(), sd
 
 
+def _matched():
+    """Rounding hook of the default DiT plan for bf16 / "prepend" models: bf16 operands, LayerNorms folded into the GEMMs
+    (sat_dit_cfg.ln_fold; oracle/dit.py LnFoldRounding).  With ``set_layernorm_fusion(False)`` the hook is plain ``bf16_round``."""
+    from oracle import dit as odit
+    return odit.LnFoldRounding()
+
+
 def _sub(sd, prefix):
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
@@ -50,6 +57,32 @@ def _inputs(b, t_len, cond_dim, seed=1):
     return x, c, g
 
 
+def test_layernorm_fusion_on_off(dev, small_dit):
+    """The standalone-LayerNorm plan (sat_dit_cfg.ln_fold = 0) against ITS matched oracle (plain bf16 rounding points), and the two
+    plans against each other: they differ only in where the activation is rounded (before / after the normalisation)."""
+    from oracle import dit as odit
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dsd = _sub(sd, "model.model.")
+    x, c, g = _inputs(2, 77, dc["cond_token_dim"])
+    t = torch.tensor([0.31, 0.87])
+    run = lambda: model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0).cpu()
+    fused = run()
+    try:
+        model.model.model.set_layernorm_fusion(False)
+        plain = run()
+    finally:
+        model.model.model.set_layernorm_fusion(True)
+    assert not torch.equal(fused, plain), "the switch did not change the plan"
+    want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"])
+    e_p = assert_close("standalone LayerNorm plan vs matched oracle", plain, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=bf16_round), 3e-3)
+    e_f = assert_close("fused plan vs matched oracle", fused, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=_matched()), 3e-3)
+    e_x = assert_close("fused vs standalone plan", fused, plain, 3e-3)
+    print(f"\n[ln_fold] standalone vs matched {e_p:.2e}, fused vs matched {e_f:.2e}, fused vs standalone {e_x:.2e}; "
+          f"vs fp32: standalone {rel_l2(plain, want_f):.2e}, fused {rel_l2(fused, want_f):.2e}")
+    assert rel_l2(fused, want_f) <= 2.5e-3 and rel_l2(plain, want_f) <= 2.5e-3
+
+
 @pytest.mark.parametrize("t_len", [64, 77])
 def test_dit_forward_no_cfg(dev, small_dit, t_len):
     from oracle import dit as odit
@@ -59,7 +92,7 @@ def test_dit_forward_no_cfg(dev, small_dit, t_len):
     x, c, g = _inputs(2, t_len, dc["cond_token_dim"])
     t = torch.tensor([0.31, 0.87])
     got = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0)
-    want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=bf16_round)
+    want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=_matched())
     want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"])
     e_m = assert_close("dit forward vs matched oracle", got, want_m, 3e-3)
     e_f = assert_close("dit forward vs fp32 oracle", got, want_f, 2.5e-3)
@@ -76,7 +109,7 @@ def test_dit_forward_cfg_and_denoise(dev, small_dit):
     for phi in (0.0, 0.4):
         got = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=7.0, scale_phi=phi,
                           cross_attn_mask=torch.ones(3, 130, device=dev))
-        want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, scale_phi=phi, rnd=bf16_round)
+        want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, scale_phi=phi, rnd=_matched())
         want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, scale_phi=phi)
         e_m = assert_close(f"dit cfg7 phi={phi} vs matched", got, want_m, 1e-2)
         e_f = assert_close(f"dit cfg7 phi={phi} vs fp32", got, want_f, 1.2e-2)
@@ -87,12 +120,12 @@ def test_dit_forward_cfg_and_denoise(dev, small_dit):
     dit.prepare_generation(c.to(dev), g.to(dev), 7.0)
     xs = x * sigma
     got = dit.denoise(xs.to(dev), sigma, cfg_scale=7.0)
-    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=_matched())
     want = osamp.vdenoise(fn, xs, torch.full((3,), sigma))
     assert_close("denoise_cfg vs matched oracle", got, want, 1e-2)
     # uncond half sees an all-zero context: its cross-attention must contribute exactly nothing
     got1 = model.model(x.to(dev), t.to(dev), cross_attn_cond=torch.zeros_like(c).to(dev), global_cond=g.to(dev), cfg_scale=1.0)
-    want1 = odit.dit_forward(dsd, x, t, torch.zeros_like(c), g, dc["depth"], dc["num_heads"], rnd=bf16_round)
+    want1 = odit.dit_forward(dsd, x, t, torch.zeros_like(c), g, dc["depth"], dc["num_heads"], rnd=_matched())
     assert_close("zero-context forward", got1, want1, 3e-3)
 
 
@@ -124,7 +157,7 @@ def test_negative_prompt_vs_reference_golden(dev):
     got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0, negative_cross_attn_cond=c_neg.to(dev),
               negative_cross_attn_mask=neg_mask.to(dev))
     e2 = assert_close("masked negative prompt vs reference", got, gold["cfg7_negative_masked_T64"], 1.6e-2)   # measured 8.2e-3
-    want_m = odit.dit_forward(sd, x, t, c, g, 3, 4, cfg_scale=7.0, negative_cross_attn_cond=c_neg, negative_cross_attn_mask=neg_mask, rnd=bf16_round)
+    want_m = odit.dit_forward(sd, x, t, c, g, 3, 4, cfg_scale=7.0, negative_cross_attn_cond=c_neg, negative_cross_attn_mask=neg_mask, rnd=_matched())
     assert_close("masked negative prompt vs matched oracle", got, want_m, 1e-2)
     print(f"\n[negative prompt] rel-L2 vs the reference {e1:.2e}, masked {e2:.2e}")
 
@@ -156,7 +189,7 @@ def test_generate_with_negative_conditioning(dev, small_dit):
     nc = ni["negative_cross_attn_cond"].cpu().float()
     sig = osamp.get_sigmas_polyexponential(steps, 0.3, 500.0, 1.0)
     fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, negative_cross_attn_cond=nc,
-                                          negative_cross_attn_mask=ni["negative_cross_attn_mask"].cpu(), rnd=bf16_round)
+                                          negative_cross_attn_mask=ni["negative_cross_attn_mask"].cpu(), rnd=_matched())
     want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), noise * sig[0], sig, lambda i, s, sn: step_noise[i])
     e = assert_close("trajectory with a negative prompt vs matched oracle", lat, want, 2e-2)
     it = iter(step_noise)
@@ -316,7 +349,7 @@ def test_generate_diffusion_cond_small(dev, small_dit):
     ci = model.get_conditioning_inputs(cond)
     cac, gc = ci["cross_attn_cond"].cpu().float(), ci["global_cond"].cpu().float()
     sig = osamp.get_sigmas_polyexponential(steps, 0.3, 500.0, 1.0)
-    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=_matched())
     want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), noise * sig[0], sig, lambda i, s, sn: step_noise[i])
     e = assert_close("6-step latent trajectory vs matched oracle", lat, want, 2e-2)
     print(f"\n[generate small] latent rel-L2 vs matched oracle {e:.2e}")
@@ -357,7 +390,7 @@ def test_sample_k_inpainting_and_2m(dev, small_dit, sampler_type):
                    sigma_max=80.0, device=str(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=7.0,
                    noise_sampler=lambda s_, sn_: next(it).to(dev), inpaint_noise=lambda i: renoise[i].to(dev))
     sig = osamp.get_sigmas_polyexponential(steps, 0.3, 80.0, 1.0)
-    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=_matched())
     x0, cb = osamp.inpainting_start_and_callback(init, noise * sig[0], mask, steps, lambda i: renoise[i])
     solver = osamp.sample_dpmpp_2m_sde if sampler_type == "dpmpp-2m-sde" else osamp.sample_dpmpp_3m_sde
     want = solver(lambda x, s_: osamp.vdenoise(fn, x, s_), x0.clone(), sig, lambda i, a_, b_: step_noise[i], callback=cb)
@@ -389,7 +422,7 @@ def test_sample_k_single_step_samplers(dev, small_dit, sampler_type):
                    device=str(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=7.0,
                    noise_sampler=lambda s_, sn_: next(it).to(dev), callback=lambda a: seen.append(a["i"]))
     sig = osamp.get_sigmas_polyexponential(steps, 0.3, 80.0, 1.0)
-    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=_matched())
     den = lambda x, s_: osamp.vdenoise(fn, x, s_)
     x0 = noise * sig[0]
     if sampler_type == "k-heun":
@@ -424,7 +457,7 @@ def test_sample_k_dpm_adaptive(dev, small_dit):
     info = {}
     got = sample_k(model.model, noise.to(dev), None, None, 10, sampler_type="k-dpm-adaptive", sigma_min=2.0, sigma_max=20.0,
                    device=str(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=3.0, info=info)
-    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=3.0, rnd=bf16_round)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=3.0, rnd=_matched())
     winfo = {}
     sig0 = float(osamp.get_sigmas_polyexponential(10, 2.0, 20.0, 1.0)[0])
     want = osamp.sample_dpm_adaptive(lambda x, s_: osamp.vdenoise(fn, x, s_), noise * sig0, 2.0, 20.0, info=winfo)
@@ -450,7 +483,7 @@ def test_rectified_flow_euler(dev, small_dit):
     init = synthetic.synth_input("init", (b, 64, t_len), 114)
     got = sample_rf(model.model, noise.to(dev), init_data=init.to(dev), steps=steps, sigma_max=0.8, device=str(dev),
                     cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=3.0, batch_cfg=True, rescale_cfg=True)
-    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=3.0, rnd=bf16_round)
+    fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=3.0, rnd=_matched())
     want = osamp.sample_discrete_euler(fn, init * (1 - 0.8) + noise * 0.8, steps, 0.8)
     assert_close("rectified-flow Euler trajectory", got, want, 1e-2)
 
@@ -736,7 +769,7 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
     cac, gc = ci["cross_attn_cond"].cpu().float(), ci["global_cond"].cpu().float()
     sig = osamp.get_sigmas_polyexponential(steps, 0.3, 4.0, 1.0)          # sigma_max <- init_noise_level (generation.py:214-217)
     dsd2 = _sub(sdd, "model.model.")
-    fn = lambda xin, tt: odit.dit_forward(dsd2, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=bf16_round)
+    fn = lambda xin, tt: odit.dit_forward(dsd2, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=_matched())
     want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), z0 + noise * sig[0], sig, lambda i, s, sn: step_noise[i])
     assert_close("audio-to-audio latents", lat, want, 2e-2)
 
