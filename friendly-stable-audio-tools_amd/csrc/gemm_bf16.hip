@@ -1380,6 +1380,8 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 13: return launch_pipe<256, 256, 32, 2, 4, 3, EPI>(a, stream);
         case 39: return launch_pipe<128, 128, 128, 4, 2, 2, EPI>(a, stream);       // 256-B rows: half the barriers per k
         case 41: return launch_pipe<256, 128, 32, 4, 2, 3, EPI>(a, stream);        // 72 KiB, <= 128 VGPRs: two workgroups per CU
+        case 42: return launch_pipe<128, 128, 64, 2, 2, 4, EPI>(a, stream);        // 4 waves of 64x64 (half the LDS reads per MFMA of tile 15), 4 stages
+        case 43: return launch_pipe<128, 128, 64, 2, 2, 2, EPI>(a, stream);        // same, 2 stages = 64 KiB: two workgroups per CU
 #endif
         default: break;
     }

@@ -198,6 +198,50 @@ def f32_epi_ab():
         print(f"f32+resid {name:16s} " + "  ".join(f"{kk}: {statistics.median(vv)*1e3:6.1f} us" for kk, vv in res.items()), flush=True)
 
 
+def splitk_probe():
+    """What a K-split of the narrow fp32-output GEMMs could buy: time of ONE part (fewer, bigger tiles over a fraction of K) against
+    the shipped single-pass launch.  A split launch would take about max(part) + one epilogue hand-off."""
+    import statistics
+    cases = [("ff_out  full K=6144", 2050, 1536, 6144, 15), ("ff_out  256x128 K=3072", 2050, 1536, 3072, 12), ("ff_out  256x128 K=2816", 2050, 1536, 2816, 12),
+             ("ff_out  256x192 K=2048", 2050, 1536, 2048, 30), ("ff_out  256x256 K=1536", 2050, 1536, 1536, 22),
+             ("to_out  full K=1536", 2050, 1536, 1536, 15), ("to_out  256x128 K=768", 2050, 1536, 768, 12),
+             ("cross   full K=1536 (128x64)", 1025, 1536, 1536, 16), ("cross   128x128 K=768", 1025, 1536, 768, 15)]
+    fs = {}
+    for name, m, n, k, v in cases:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        c = torch.zeros(m, n, device=dev)
+        bias = torch.randn(n, device=dev)
+        fs[name] = (lambda a=a, w=w, c=c, bias=bias, m=m, n=n, k=k, v=v: _hip.check(
+            lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(c), m, n, k, 1, v, _hip.stream())), 2.0 * m * n * k)
+    res = {kk: [] for kk in fs}
+    for _ in range(5):
+        for kk, (f, _fl) in fs.items():
+            res[kk].append(timeit(f, iters=10, warm=2))
+    for kk, (f, fl) in fs.items():
+        ms = statistics.median(res[kk])
+        print(f"splitk {kk:30s} {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
+
+
+def small_tiles():
+    """The narrow fp32-output GEMMs (to_out, FF-out, cross to_q / to_out): wave tile 32x64 on 8 waves (shipped 15) against 64x64 on 4
+    waves (10: 3 stages, 42: 4 stages, 43: 2 stages / two workgroups per CU) and BK = 128 (39)."""
+    import statistics
+    shapes = [("ff_out", 2050, 1536, 6144), ("to_out", 2050, 1536, 1536), ("cross", 1025, 1536, 1536)]
+    for name, m, n, k in shapes:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        c = torch.zeros(m, n, device=dev)
+        bias = torch.randn(n, device=dev)
+        fs = {v: (lambda v=v: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(c), m, n, k, 1, v, _hip.stream())))
+              for v in (15, 16, 10, 42, 43, 39, 12)}
+        res = {v: [] for v in fs}
+        for _ in range(5):
+            for v, f in fs.items():
+                res[v].append(timeit(f, iters=10, warm=2))
+        print(f"tiles {name:8s} " + "  ".join(f"v{v}: {statistics.median(r)*1e3:6.1f} us" for v, r in res.items()), flush=True)
+
+
 def ablate():
     """Where does the time of each shipped GEMM go?  Ablation modes of the experiments build (SAT_HIP_EXP=1): 2 = no LDS-DMA in the
     loop, 4 = + no barrier, 5 = + no ds_read (MFMA on register fragments), 6 = + no epilogue, 7 = 5 with the epilogue arithmetic but
@@ -353,6 +397,10 @@ if __name__ == "__main__":
         section("8 prompts: tile 22 vs 26", b8_tiles)
     if "f32epi" in which:
         section("fp32 epilogue A/B", f32_epi_ab)
+    if "smalltiles" in which:
+        section("small tiles", small_tiles)
+    if "splitk" in which:
+        section("split-K parts", splitk_probe)
     if "ablate" in which:
         section("ablation", ablate)
     if "gemm_pmc" in which:
