@@ -242,6 +242,36 @@ def small_tiles():
         print(f"tiles {name:8s} " + "  ".join(f"v{v}: {statistics.median(r)*1e3:6.1f} us" for v, r in res.items()), flush=True)
 
 
+def hybrid_probe():
+    """FF-in (SwiGLU) at 1 prompt is 384 full 256x256 tiles + 48 two-row tiles on 256 CUs = 1.5 rounds run as 2.  How long do the pieces
+    of a two-launch split take: N = 8192 on 256x256 tiles (one full round) + N = 4096 on smaller tiles (a second full round of less work)?"""
+    import statistics
+    k = 1536
+    cases = [("full  N=12288 v22", 2050, 12288, 22), ("A     N=8192  v22", 2050, 8192, 22), ("B     N=4096  v12 (256x128)", 2050, 4096, 12),
+             ("B     N=4096  v15 (128x128)", 2050, 4096, 15), ("B     N=4096  v22", 2050, 4096, 22), ("B     N=4096  v10 (128x128, 4 waves)", 2050, 4096, 10),
+             ("A'    N=6144  v22", 2050, 6144, 22), ("B'    N=6144  v12", 2050, 6144, 12), ("B'    N=6144  v30", 2050, 6144, 30),
+             ("M2048 N=12288 v22", 2048, 12288, 22), ("M2048 N=8192 v22", 2048, 8192, 22)]
+    fs = {}
+    for name, m, n, v in cases:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = torch.randn(n, k, device=dev) * 0.05
+        bias = torch.randn(n, device=dev)
+        wp = torch.empty(n, k, dtype=torch.bfloat16, device=dev)
+        bp = torch.empty(n, device=dev)
+        h = torch.empty(m, n // 2, dtype=torch.bfloat16, device=dev)
+        _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(h), m, n, k, v, _hip.stream()))
+        fs[name] = (lambda a=a, w=w, bias=bias, wp=wp, bp=bp, h=h, m=m, n=n, v=v: _hip.check(
+            lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(h), m, n, k, v | 0x4000, _hip.stream())),
+            2.0 * m * n * k)
+    res = {kk: [] for kk in fs}
+    for _ in range(5):
+        for kk, (f, _fl) in fs.items():
+            res[kk].append(timeit(f, iters=10, warm=2))
+    for kk, (f, fl) in fs.items():
+        ms = statistics.median(res[kk])
+        print(f"hybrid {kk:40s} {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
+
+
 def ablate():
     """Where does the time of each shipped GEMM go?  Ablation modes of the experiments build (SAT_HIP_EXP=1): 2 = no LDS-DMA in the
     loop, 4 = + no barrier, 5 = + no ds_read (MFMA on register fragments), 6 = + no epilogue, 7 = 5 with the epilogue arithmetic but
@@ -397,6 +427,8 @@ if __name__ == "__main__":
         section("8 prompts: tile 22 vs 26", b8_tiles)
     if "f32epi" in which:
         section("fp32 epilogue A/B", f32_epi_ab)
+    if "hybrid" in which:
+        section("FF-in two-launch split", hybrid_probe)
     if "smalltiles" in which:
         section("small tiles", small_tiles)
     if "splitk" in which:
