@@ -24,6 +24,12 @@ class SatDitCfg(Structure):
                 ("max_seq_len", c_int32), ("adaln", c_int32), ("fp8_gemm", c_int32), ("ln_fold", c_int32)]
 
 
+class SatT5Cfg(Structure):
+    _fields_ = [("vocab_size", c_int32), ("d_model", c_int32), ("d_kv", c_int32), ("d_ff", c_int32), ("num_layers", c_int32),
+                ("num_heads", c_int32), ("rel_buckets", c_int32), ("rel_max_distance", c_int32), ("gated_gelu", c_int32),
+                ("proj_dim", c_int32), ("eps", c_float)]
+
+
 class SatOobleckCfg(Structure):
     _fields_ = [("is_decoder", c_int32), ("io_channels", c_int32), ("channels", c_int32), ("latent_dim", c_int32),
                 ("n_blocks", c_int32), ("c_mults", c_int32 * 8), ("strides", c_int32 * 8)]
@@ -82,6 +88,13 @@ _SIGNATURES = {
                                          c_void_p]),
     "sat_gemm_swiglu_ln_bf16": (c_int32, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "sat_qkv_rope_ln_bf16": (c_int32, [c_void_p] * 12 + [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "sat_t5_plan_create": (c_int32, [c_void_p, c_void_p]),
+    "sat_t5_plan_destroy": (None, [c_void_p]),
+    "sat_t5_plan_set_tensor": (c_int32, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "sat_t5_plan_finalize": (c_int32, [c_void_p, c_void_p]),
+    "sat_t5_workspace_bytes": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "sat_t5_encode": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
+    "sat_t5_relative_buckets": (c_int32, [c_int32, c_int32, c_int32, c_void_p]),
     "sat_snake_beta": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "sat_overlap_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "sat_number_embed": (c_int32, [c_void_p, c_int32, c_float, c_float, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),

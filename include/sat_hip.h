@@ -292,6 +292,45 @@ int sat_qkv_rope_ln_bf16(const void* xb_dev, const float* ln_part_dev, const flo
                          const float* beta_dev, void* wpack_dev, float* c12_dev, const float* inv_freq_dev, void* q_dev, void* k_dev,
                          void* vt_dev, float* rope_scratch_dev, int32_t b, int32_t s, int32_t s_pad, int32_t d, int32_t variant,
                          sat_stream_t stream);
+/* ------------------------------------------------------------------------------------
+ * T5 encoder stack: the text front-end of the conditioner.  Replaces the transformers.T5EncoderModel call in
+ * T5Conditioner.forward (models/conditioners.py:317-339): last_hidden_state for tokenised prompts.  The algorithm is
+ * transformers' modeling_t5.py (T5Stack encoder: RMS T5LayerNorm, un-scaled attention with bucketed relative position bias shared
+ * from block 0, ReLU or gated-GELU feed-forward); fp32 throughout (the reference runs it under fp16 autocast).
+ * Tensors are named as in a Hugging Face T5 checkpoint: "shared.weight" (or "encoder.embed_tokens.weight"),
+ * "encoder.block.N.layer.0.SelfAttention.{q,k,v,o}.weight", "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
+ * "encoder.block.N.layer.0.layer_norm.weight", "encoder.block.N.layer.1.DenseReluDense.{wi | wi_0,wi_1}.weight", "....wo.weight",
+ * "encoder.block.N.layer.1.layer_norm.weight", "encoder.final_layer_norm.weight".
+ * ---------------------------------------------------------------------------------- */
+typedef struct sat_t5_plan sat_t5_plan;
+typedef struct sat_t5_cfg {
+    int32_t vocab_size;        /* T5Config.vocab_size (32128) */
+    int32_t d_model;           /* 768 for t5-base */
+    int32_t d_kv;              /* 64; inner dim = num_heads * d_kv */
+    int32_t d_ff;              /* 3072 */
+    int32_t num_layers;        /* 12 */
+    int32_t num_heads;         /* 12 */
+    int32_t rel_buckets;       /* relative_attention_num_buckets (32) */
+    int32_t rel_max_distance;  /* relative_attention_max_distance (128) */
+    int32_t gated_gelu;        /* feed_forward_proj: 0 = "relu" (t5-*), 1 = "gated-gelu" (flan-t5-*) */
+    int32_t proj_dim;          /* > 0: Conditioner.proj_out = Linear(d_model, proj_dim) (conditioners.py:23) applied to the output,
+                                  tensors "proj_out.weight" [proj_dim, d_model] / "proj_out.bias"; 0: identity */
+    float eps;                 /* layer_norm_epsilon (1e-6) */
+} sat_t5_cfg;
+int sat_t5_plan_create(const sat_t5_cfg* cfg, sat_t5_plan** out_plan);
+void sat_t5_plan_destroy(sat_t5_plan* plan);
+int sat_t5_plan_set_tensor(sat_t5_plan* plan, const char* name, const float* data_dev, int64_t numel);
+int sat_t5_plan_finalize(sat_t5_plan* plan, sat_stream_t stream);
+int sat_t5_workspace_bytes(const sat_t5_plan* plan, int32_t b, int32_t l, size_t* out_bytes);
+/* input_ids_dev / attention_mask_dev [b, l] int32 (tokenizer output, padding = mask 0) -> out_dev [b, l, proj_dim or d_model] fp32
+ * = proj_out(model(input_ids, attention_mask)["last_hidden_state"]), and with mask_output != 0 multiplied by the mask
+ * (conditioners.py:333-341); l <= 512 */
+int sat_t5_encode(sat_t5_plan* plan, const int32_t* input_ids_dev, const int32_t* attention_mask_dev, float* out_dev, int32_t b,
+                  int32_t l, int32_t mask_output, void* workspace_dev, size_t workspace_bytes, sat_stream_t stream);
+/* HOST helper (no GPU): T5Attention._relative_position_bucket(key - query, bidirectional=True) for key - query in
+ * [-(l-1), l-1] -> out_host[2l - 1] */
+int sat_t5_relative_buckets(int32_t l, int32_t num_buckets, int32_t max_distance, int32_t* out_host);
+
 /* SnakeBeta (models/blocks.py:318-319): y = x + sin^2(x*exp(alpha_c)) / (exp(beta_c)+1e-9); x,y [b,c,t] fp32 */
 int sat_snake_beta(const float* x_dev, const float* alpha_dev, const float* beta_dev, float* y_dev,
                    int32_t b, int32_t c, int32_t t, sat_stream_t stream);
