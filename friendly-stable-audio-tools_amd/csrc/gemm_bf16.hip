@@ -214,20 +214,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 //   * SwiGLU / MXFP8 block maximum: value and gate, resp. the 32 channels of a block, sit in one lane pair.
 // V^T (token-contiguous destination) keeps the un-swapped orientation and the epilogue above.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void half_swap(unsigned& lo_run, unsigned& hi_run) {
-    // lo_run / hi_run: the same dword of channel runs g and g+1.  Afterwards lanes 0-31 hold (run g of half 0, run g of half 1)
-    // = 8 consecutive channels starting at 8g, lanes 32-63 hold (run g+1 of half 0, run g+1 of half 1) starting at 8(g+1).
-    u32x2 r = __builtin_amdgcn_permlane32_swap(lo_run, hi_run, false, false);
-    lo_run = r[0];
-    hi_run = r[1];
-}
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    bf16x2 v;
-    v[0] = f32_to_bf16(a);
-    v[1] = f32_to_bf16(b);
-    return __builtin_bit_cast(unsigned, v);
-}
-
 template <int EPI, int MI, int NI, bool NOSTORE = false, bool LNC = false>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
                                                 const int l31, const float2* ln = nullptr, const float* lc1 = nullptr,

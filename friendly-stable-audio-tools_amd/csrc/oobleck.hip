@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "sat_common.h"
 
 namespace {
@@ -51,183 +53,87 @@ __device__ __forceinline__ float snake_f(float v, float a, float ib) {
     return v + ib * (s * s);
 }
 
+// Epilogue on TRANSPOSED accumulators (the main loop issues its MFMAs with the weight fragment as the A operand, see
+// gather_channel_runs in sat_common.h): lane l31 owns output row m = mw + i*32 + l31 and, after one exchange between the wave
+// halves, two groups of 8 consecutive channels.  Residual reads and bf16 stores are 16 bytes per lane (round 1 moved 2 bytes per
+// access: the unit's 1 x 1 convolution then spent its whole time issuing them), bias and Snake parameters come as float4 pairs.
+// flat = m*N + out_shift + n addresses plain convolutions (shift 0) and the polyphase transposed ones (N = stride * Cout columns per
+// input row, shifted by the padding); shift and limit are multiples of Cout, groups are 8-aligned: a group is in or out as a whole.
 template <int MI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& g, f32x16 (&acc)[MI][2], const int mw, const int nw, const int b,
                                               const int half, const int l31) {
-    constexpr int NI = 2;
-    // ---- epilogue.  acc[i][j][r]: row = i*32 + (r&3) + 8*(r>>2) + 4*half ; col = j*32 + l31
-    float bia[NI], sa_[NI], sib[NI];
-    int nn[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        nn[j] = nw + j * 32 + l31;
-        int co = nn[j] % g.Cout;
-        bia[j] = g.bias ? g.bias[co] : 0.f;
-        sa_[j] = g.out_snk ? g.sn_a[co] : 0.f;
-        sib[j] = g.out_snk ? g.sn_ib[co] : 0.f;
-    }
-    if (g.out_cf) {
+    if (g.out_cf) {      // fp32 channel-first result of the last convolution: consecutive lanes = consecutive time steps
         float* __restrict__ o = g.out_cf + (size_t)b * g.cf_channels * g.M;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i) {
+            const int m = mw + i * 32 + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < g.M) {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        if (nn[j] < g.cf_channels) o[(size_t)nn[j] * g.M + m] = acc[i][j][r] + bia[j];
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nw + j * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    if (m < g.M && n < g.cf_channels) o[(size_t)n * g.M + m] = acc[i][j][r] + (g.bias ? g.bias[n % g.Cout] : 0.f);
                 }
-            }
+        }
         return;
     }
     const bf16_t* res = g.res ? g.res + (size_t)b * g.out_bstride : nullptr;
     bf16_t* oraw = g.out_raw ? g.out_raw + (size_t)b * g.out_bstride : nullptr;
     bf16_t* __restrict__ osnk = g.out_snk ? g.out_snk + (size_t)b * g.out_bstride : nullptr;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        const int m = mw + i * 32 + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < g.M) {
+        for (int j = 0; j < 2; ++j) {
+            float v[16];
+            gather_channel_runs(acc[i][j], v);
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    long long flat = (long long)m * g.N + g.out_shift + nn[j];
-                    if (flat >= 0 && flat < g.out_limit) {
-                        float v = acc[i][j][r] + bia[j];
-                        if (res) v += bf16_to_f32(res[flat]);
-                        if (oraw) oraw[flat] = f32_to_bf16(v);
-                        if (osnk) osnk[flat] = f32_to_bf16(snake_f(v, sa_[j], sib[j]));
+            for (int grp = 0; grp < 2; ++grp) {
+                const int n = nw + j * 32 + grp * 16 + 8 * half;
+                const long long flat = (long long)m * g.N + g.out_shift + n;
+                const bool ok = m < g.M && flat >= 0 && flat + 8 <= g.out_limit;
+                const int co = n % g.Cout;
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = v[grp * 8 + e];
+                if (g.bias) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(g.bias + co), b1 = *reinterpret_cast<const f32x4*>(g.bias + co + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] += b0[e];
+                        x[4 + e] += b1[e];
                     }
+                }
+                if (res && ok) {
+                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + flat);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += bf16_to_f32(rv[e]);
+                }
+                if (oraw && ok)
+                    *reinterpret_cast<u32x4*>(oraw + flat) = u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
+                if (osnk) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(g.sn_a + co), a1 = *reinterpret_cast<const f32x4*>(g.sn_a + co + 4);
+                    const f32x4 i0 = *reinterpret_cast<const f32x4*>(g.sn_ib + co), i1 = *reinterpret_cast<const f32x4*>(g.sn_ib + co + 4);
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[e] = snake_f(x[e], a0[e], i0[e]);
+                        y[4 + e] = snake_f(x[4 + e], a1[e], i1[e]);
+                    }
+                    if (ok)
+                        *reinterpret_cast<u32x4*>(osnk + flat) = u32x4{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
                 }
             }
         }
+    }
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void conv_kernel(ConvArgs g) {
-    constexpr int NT = WM * WN * 64;
-    constexpr int TM = BM / WM;
-    constexpr int TN = BN / WN;
-    static_assert(TN == 64, "wave tile is TM x 64");
-    constexpr int MI = TM / 32;
-    constexpr int NI = 2;
-    constexpr int A_CH = BM * 8 / NT;
-    constexpr int B_CH = BN * 8 / NT;
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int tiles_n = g.N / BN;
-    const int tiles_m = (g.M + BM - 1) / BM;
-    // n fastest: the (few) column tiles of one time window run back-to-back and share the
-    // input window in L2; weights are small and stay cached.
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / tiles_n;
-    const int tn = bid - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    (void)tiles_m;
-
-    const int Cin = g.Cin, Tin = g.Tin;
-    const int cpt = Cin >> 6;                 // 64-channel chunks per tap
-    const int nk = g.taps * cpt;
-    const bf16_t* __restrict__ inb = g.in + (size_t)b * Tin * Cin;
-
-    int a_row[A_CH], a_chk[A_CH], a_m[A_CH];
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        int id = i * NT + tid;
-        a_row[i] = id >> 3;
-        a_chk[i] = id & 7;
-        a_m[i] = (m0 + a_row[i]) * g.stride;
-    }
-    int b_row[B_CH], b_chk[B_CH];
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) {
-        int id = i * NT + tid;
-        b_row[i] = id >> 3;
-        b_chk[i] = id & 7;
-    }
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    u32x4 ra[A_CH], rb[B_CH];
-    auto gload = [&](int kt) {
-        const int tap = kt / cpt;
-        const int ci0 = (kt - tap * cpt) << 6;
-        const int off = g.off0 + tap * g.doff;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            int r = a_m[i] + off;
-            const bool ok = r >= 0 && r < Tin;
-            r = ok ? r : 0;
-            u32x4 v = *reinterpret_cast<const u32x4*>(inb + (size_t)r * Cin + ci0 + a_chk[i] * 8);
-            ra[i] = ok ? v : u32x4{0u, 0u, 0u, 0u};
-        }
-        const bf16_t* wt = g.W + ((size_t)tap * g.N + n0) * Cin + ci0;
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) rb[i] = *reinterpret_cast<const u32x4*>(wt + (size_t)b_row[i] * Cin + b_chk[i] * 8);
-    };
-    auto lstore = [&](int stage) {
-        char* sa = smem + stage * STAGE_BYTES;
-        char* sb = sa + BM * 128;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(sa + lds_tile_off(a_row[i], a_chk[i])) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(sb + lds_tile_off(b_row[i], b_chk[i])) = rb[i];
-    };
-
-    auto compute = [&](int cur) {
-        const char* sa = smem + cur * STAGE_BYTES;
-        const char* sb = sa + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[MI], bfr[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        gload(kt + 1);
-        compute(kt & 1);
-        lstore((kt + 1) & 1);
-        __syncthreads();
-    }
-    compute((nk - 1) & 1);
-
-    conv_epilogue<MI>(g, acc, m0 + wm * TM, n0 + wn * TN, b, half, l31);
-}
-
-// Direct-to-LDS, deep-prefetch variant of conv_kernel (same structure as gemm_pipe_kernel in gemm_bf16.hip): LDS-DMA
-// (global_load_lds_dwordx4) into an NS-stage ring, counted vmcnt, one raw barrier per K-tile, 8 waves, MFMA/ds_read
-// interleave pinned.  Rows that fall into the conv zero padding are fetched from a zero page (an LDS-DMA cannot
-// write an immediate); the XOR swizzle is folded into the per-lane source address.
+// Main loop of the implicit-GEMM convolution: acc[i][j] (+)= the BM x BN output tile (rows m0.., columns n0..) of batch item b.
+// NS-stage LDS ring filled by LDS-DMA, prefetch distance NS-1, one raw barrier per K-tile (= one tap x 64 input channels), counted
+// vmcnt.  Returns with every load landed; the caller owns the barrier that frees the ring.
 template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void conv_pipe_kernel(ConvArgs g) {
+__device__ __forceinline__ void conv_main_loop(const ConvArgs& g, char* smem, const int m0, const int n0, const int b,
+                                               f32x16 (&acc)[BM / WM / 32][2]) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
     constexpr int TN = BN / WN;
@@ -240,19 +146,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pipe_kernel(ConvArgs g) {
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int D = NS - 1;
     static_assert(A_CH >= 1 && B_CH >= 1 && (D > 0) && (D - 1) * LPT < 64, "bad pipeline geometry");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int tiles_n = g.N / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / tiles_n;
-    const int tn = bid - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
 
     const int Cin = g.Cin, Tin = g.Tin;
     const int cpt = Cin >> 6;
@@ -274,14 +173,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pipe_kernel(ConvArgs g) {
         int row = q >> 3, pos = q & 7;
         b_off[i] = row * Cin + (pos ^ ((row >> 1) & 7)) * 8;
     }
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto stage_in = [&](int kt, int stage) {
         const int tap = kt / cpt;
@@ -323,7 +214,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pipe_kernel(ConvArgs g) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);      // C^T: lane = output row
             if (ks + 1 < 4) {
                 constexpr int NR = MI + NI, NM = MI * NI;
 #pragma unroll
@@ -356,7 +247,151 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_pipe_kernel(ConvArgs g) {
         compute(rd);
         rd = (rd + 1 == NS) ? 0 : rd + 1;
     }
-    conv_epilogue<MI>(g, acc, m0 + wm * TM, n0 + wn * TN, b, half, l31);
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void conv_pipe_kernel(ConvArgs g) {
+    constexpr int TM = BM / WM;
+    constexpr int TN = BN / WN;
+    constexpr int MI = TM / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int b = blockIdx.y;
+    const int tiles_n = g.N / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = bid / tiles_n;
+    const int tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    conv_main_loop<BM, BN, WM, WN, NS>(g, smem, m0, n0, b, acc);
+    conv_epilogue<MI>(g, acc, m0 + wm * TM, n0 + wn * TN, b, lane >> 5, lane & 31);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One ResidualUnit (autoencoders.py:45-68: x + conv1(snake(conv7_dilated(snake(x))))) in ONE launch for the layers whose channel
+// count fits one workgroup tile (C = BN).  The k = 7 convolution runs as above; its epilogue applies bias and the second Snake and
+// leaves the 128 x C block in LDS (bf16, the swizzled 64-channel K-tiles the fragment reads expect) instead of HBM; the 1 x 1
+// convolution is a second MFMA pass over that block with its C x C weights streamed through the freed ring; the final epilogue is the
+// ordinary one (bias, raw residual, raw and / or Snake'd output).  Against two launches this removes one write and one read of the
+// activation (537 MB each at the top decoder level), the <= 4-K-tile kernel whose time was all prologue and epilogue, and a launch.
+// ---------------------------------------------------------------------------------------------
+struct RuArgs {
+    ConvArgs c7;     // in = snake1(x); bias / sn_a / sn_ib: those of the k = 7 convolution and of the Snake behind it
+    ConvArgs c1;     // W / bias of the 1 x 1 convolution, res = raw x, out_raw / out_snk (+ the next layer's Snake)
+};
+
+template <int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void ru_fused_kernel(RuArgs ga) {
+    constexpr int BM = 128;
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM;
+    constexpr int TN = BN / WN;
+    constexpr int MI = TM / 32;
+    constexpr int KT1 = BN / 64;                       // K-tiles of the 1 x 1 convolution (64 channels each)
+    constexpr int Y_BYTES = KT1 * BM * 128;            // the intermediate block: KT1 tiles of 128 rows x 128 B
+    constexpr int W_TILE = BN * 128;                   // one K-tile of the 1 x 1 weights: BN rows x 64 channels
+    constexpr int W_CH = BN * 8 / NT;                  // 16-byte pieces per thread per weight tile
+    static_assert(Y_BYTES + 2 * W_TILE <= NS * (BM + BN) * 128, "the 1 x 1 stage must fit into the ring of the k = 7 stage");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM;
+    const ConvArgs& g7 = ga.c7;
+    const ConvArgs& g1 = ga.c1;
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    conv_main_loop<BM, BN, WM, WN, NS>(g7, smem, m0, 0, b, acc);
+    __builtin_amdgcn_s_barrier();                      // every wave is done with the ring
+
+    // ---- the 1 x 1 weights, K-tiles 0 and 1, behind the intermediate block (same swizzle as every other tile)
+    char* sw = smem + Y_BYTES;
+    int w_off[W_CH];
+#pragma unroll
+    for (int i = 0; i < W_CH; ++i) {
+        const int q = i * NT + tid;
+        const int row = q >> 3, pos = q & 7;
+        w_off[i] = row * BN + (pos ^ ((row >> 1) & 7)) * 8;
+    }
+    auto w_in = [&](int kt, int stage) {
+#pragma unroll
+        for (int i = 0; i < W_CH; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1.W + kt * 64 + w_off[i]),
+                                             (__attribute__((address_space(3))) void*)(sw + stage * W_TILE + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    w_in(0, 0);
+    w_in(1, 1);
+
+    // ---- first epilogue: y = snake(acc + bias) -> bf16 -> LDS, 8 channels (one 16-byte chunk of a K-tile row) per store
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm * TM + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[16];
+            gather_channel_runs(acc[i][j], v);
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                const int n = wn * TN + j * 32 + grp * 16 + 8 * half;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(g7.bias + n), b1 = *reinterpret_cast<const f32x4*>(g7.bias + n + 4);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(g7.sn_a + n), a1 = *reinterpret_cast<const f32x4*>(g7.sn_a + n + 4);
+                const f32x4 i0 = *reinterpret_cast<const f32x4*>(g7.sn_ib + n), i1 = *reinterpret_cast<const f32x4*>(g7.sn_ib + n + 4);
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = snake_f(v[grp * 8 + e] + b0[e], a0[e], i0[e]);
+                    y[4 + e] = snake_f(v[grp * 8 + 4 + e] + b1[e], a1[e], i1[e]);
+                }
+                *reinterpret_cast<u32x4*>(smem + (n >> 6) * (BM * 128) + lds_tile_off(row, (n & 63) >> 3)) =
+                    u32x4{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
+
+    // ---- 1 x 1 convolution: acc = y . W1^T, K-tiles of 64 channels, weights in a 2-stage ring
+#pragma unroll 1
+    for (int kt = 0; kt < KT1; ++kt) {
+        wait_vmcnt<0>();
+        __syncthreads();                               // y written by everybody (first pass; waits for the ds_writes too), weight tile kt landed
+        const char* sa_ = smem + kt * (BM * 128);
+        const char* sb_ = sw + (kt & 1) * W_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MI], bfr[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa_ + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb_ + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 2 < KT1) {
+            __builtin_amdgcn_s_barrier();              // stage kt & 1 is free again
+            w_in(kt + 2, kt & 1);
+        }
+    }
+    conv_epilogue<MI>(g1, acc, m0 + wm * TM, wn * TN, b, half, l31);
 }
 
 // z [B][C][T] fp32 (channel-first) -> [B][T][C] bf16
@@ -486,6 +521,16 @@ int launch_conv(const ConvArgs& a, int B, hipStream_t s) {
 struct Snake {
     float *a = nullptr, *ib = nullptr;
 };
+// experiments build only: SAT_OOBLECK_UNFUSED=1 in the environment runs every ResidualUnit as two launches (conv7, conv1) for A/B
+// measurements (tools/codec_only.py)
+#ifdef SAT_GEMM_EXPERIMENTS
+const bool g_ru_unfused = [] {
+    const char* e = getenv("SAT_OOBLECK_UNFUSED");
+    return e && e[0] == '1';
+}();
+#else
+constexpr bool g_ru_unfused = false;
+#endif
 struct ConvW {
     bf16_t* W = nullptr;
     float* bias = nullptr;
@@ -692,6 +737,16 @@ ConvArgs base_args(const ConvW& w, const bf16_t* in, int Tin, int M) {
     return a;
 }
 
+template <int BN, int WM, int WN, int NS>
+int launch_ru_fused(const RuArgs& a, int B, hipStream_t s) {
+    constexpr int LDS = NS * (128 + BN) * 128;
+    auto kern = ru_fused_kernel<BN, WM, WN, NS>;
+    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.c7.M, 128), B), dim3(WM * WN * 64), LDS, s, a);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+
 // one ResidualUnit (autoencoders.py:45-68): in S (snaked x) + R (raw x) -> R (raw x') and/or Sout (snake_next(x'))
 int run_ru(const sat_oobleck_plan::Block& blk, int r, int C, int L, int B, bf16_t* R, const bf16_t* S, bf16_t* Y, bf16_t* Sout,
            const Snake& next, bool need_raw, hipStream_t s) {
@@ -699,11 +754,19 @@ int run_ru(const sat_oobleck_plan::Block& blk, int r, int C, int L, int B, bf16_
     ConvArgs a = base_args(blk.ru_c7[r], S, L, L);
     a.off0 = -3 * dil[r]; a.doff = dil[r];
     a.out_snk = Y; a.sn_a = blk.ru_sn2[r].a; a.sn_ib = blk.ru_sn2[r].ib;
-    SAT_TRY(launch_conv(a, B, s));
     ConvArgs c = base_args(blk.ru_c1[r], Y, L, L);
     c.res = R;
     c.out_raw = need_raw ? R : nullptr;   // in place: each thread reads then writes its own elements
     c.out_snk = Sout; c.sn_a = next.a; c.sn_ib = next.ib;
+    if (!g_ru_unfused && (C == 128 || C == 256)) {      // the whole unit in one launch, the intermediate never leaves LDS
+        RuArgs f{a, c};
+        f.c7.out_snk = nullptr;
+        f.c1.in = nullptr;
+        // C = 128: a 2-stage ring (64 KiB) puts two workgroups on a CU, so one's epilogues overlap the other's main loop
+        if (C == 128) return launch_ru_fused<128, 4, 2, 2>(f, B, s);
+        return launch_ru_fused<256, 2, 4, 3>(f, B, s);
+    }
+    SAT_TRY(launch_conv(a, B, s));
     SAT_TRY(launch_conv(c, B, s));
     return 0;
 }

@@ -127,6 +127,35 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Accumulators of a 32x32 MFMA block issued with the operands swapped (weight fragment first) hold C^T: lane l31 owns one output ROW,
+// its 16 registers are channels 8*(r>>2) + 4*half + (r&3) -- four runs of four.  half_swap exchanges one dword of runs g and g+1
+// between the wave halves (v_permlane32_swap): afterwards lanes 0-31 hold (run g of half 0, run g of half 1) = 8 consecutive
+// channels from 8g, lanes 32-63 (run g+1 of half 0, run g+1 of half 1) = 8 consecutive channels from 8(g+1).
+__device__ __forceinline__ void half_swap(unsigned& lo_run, unsigned& hi_run) {
+    u32x2 r = __builtin_amdgcn_permlane32_swap(lo_run, hi_run, false, false);
+    lo_run = r[0];
+    hi_run = r[1];
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    bf16x2 v;
+    v[0] = f32_to_bf16(a);
+    v[1] = f32_to_bf16(b);
+    return __builtin_bit_cast(unsigned, v);
+}
+// the same exchange on the fp32 values of a whole block: afterwards v[0..7] are channels c0 .. c0+7 and v[8..15] channels
+// c0+16 .. c0+23 of the lane's row, c0 = 8 * half (16-byte residual reads, 16-byte bf16 stores after packing)
+__device__ __forceinline__ void gather_channel_runs(const f32x16& a, float (&v)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; g += 2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned lo = __float_as_uint(a[4 * g + e]), hi = __float_as_uint(a[4 * (g + 1) + e]);
+            half_swap(lo, hi);
+            v[4 * g + e] = __uint_as_float(lo);
+            v[4 * (g + 1) + e] = __uint_as_float(hi);
+        }
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids
 // land on the same XCD (hardware places block b on XCD b % 8), so neighbouring tiles share
 // one L2.  Speed only -- never correctness.
