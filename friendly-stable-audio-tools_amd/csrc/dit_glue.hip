@@ -99,57 +99,62 @@ __global__ __launch_bounds__(256) void adaln_finish_kernel(float* __restrict__ s
 
 // (S - T = number of prepended rows: 1 for global_cond_type 'prepend', 0 for 'adaLN')
 // X[b, (S-T)+t, n] = xscale * sum_c Weff[n][c] * x[b % xB][c][t]       (C <= 64)
-// Lane = output channel n; the folded weight is read TRANSPOSED (WeffT[c][n], built once per plan): consecutive lanes read
-// consecutive floats.  16 tokens per workgroup share one pass over the weights; stores are row-contiguous.
-constexpr int IP_TT = 8;
+// One workgroup = 32 time steps x 256 output channels, thread = output channel n with 32 accumulators (one per time step).  The
+// folded weight is read TRANSPOSED (WeffT[c][n]: consecutive lanes read consecutive floats, once per workgroup, 8 loads in flight);
+// the inputs of the 32 time steps sit in LDS and are read as broadcast float4, so the inner loop is 4 FMAs per LDS read and 32 FMAs
+// per global load (round 1: 8 time steps per workgroup, every workgroup streaming the whole weight: 100 MB of L2 traffic per call);
+// stores are row-contiguous (1 KiB per wave).
+constexpr int IP_TT = 32;
 __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ WeffT,
                                                          float* __restrict__ X, int xB, int C, int T, int S, int D, float xscale) {
-    __shared__ float xs[64][IP_TT];
-    const int b = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) float xs[64][IP_TT];
+    const int b = blockIdx.z;
     const int t0 = blockIdx.x * IP_TT;
+    const int n = blockIdx.y * 256 + threadIdx.x;
     const float* xb = x + (size_t)(b % xB) * C * T;
-    for (int i = threadIdx.x; i < C * IP_TT; i += 256) {
-        int c = i / IP_TT, tt = i - c * IP_TT;
-        int t = t0 + tt;
-        xs[c][tt] = (t < T) ? xb[(size_t)c * T + t] * xscale : 0.f;
+    for (int i = threadIdx.x; i < 64 * IP_TT; i += 256) {
+        const int c = i / IP_TT, tt = i - c * IP_TT;
+        const int t = t0 + tt;
+        xs[c][tt] = (c < C && t < T) ? xb[(size_t)c * T + t] * xscale : 0.f;
     }
     __syncthreads();
-    for (int n = threadIdx.x; n < D; n += 256) {
-        float acc[IP_TT];
+    if (n >= D) return;
+    float acc[IP_TT];
 #pragma unroll
-        for (int tt = 0; tt < IP_TT; ++tt) acc[tt] = 0.f;
-        for (int c0 = 0; c0 < C; c0 += 16) {
-            float w[16];                                   // 16 independent coalesced loads in flight
+    for (int tt = 0; tt < IP_TT; ++tt) acc[tt] = 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float w[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = (c0 + u < C) ? WeffT[(size_t)(c0 + u) * D + n] : 0.f;
+        for (int u = 0; u < 8; ++u) w[u] = (c0 + u < C) ? WeffT[(size_t)(c0 + u) * D + n] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
-                for (int q = 0; q < IP_TT / 4; ++q) {
-                    const float4 xv = *reinterpret_cast<const float4*>(&xs[(c0 + u) & 63][q * 4]);      // LDS broadcast
-                    acc[q * 4] += w[u] * xv.x;
-                    acc[q * 4 + 1] += w[u] * xv.y;
-                    acc[q * 4 + 2] += w[u] * xv.z;
-                    acc[q * 4 + 3] += w[u] * xv.w;
-                }
-        }
-#pragma unroll
-        for (int tt = 0; tt < IP_TT; ++tt) {
-            int t = t0 + tt;
-            if (t < T) X[((size_t)b * S + (S - T) + t) * D + n] = acc[tt];
-        }
+            for (int q = 0; q < IP_TT / 4; ++q) {
+                const float4 xv = *reinterpret_cast<const float4*>(&xs[(c0 + u) & 63][q * 4]);      // LDS broadcast
+                acc[q * 4] += w[u] * xv.x;
+                acc[q * 4 + 1] += w[u] * xv.y;
+                acc[q * 4 + 2] += w[u] * xv.z;
+                acc[q * 4 + 3] += w[u] * xv.w;
+            }
     }
+#pragma unroll
+    for (int tt = 0; tt < IP_TT; ++tt)
+        if (t0 + tt < T) X[((size_t)b * S + (S - T) + t0 + tt) * D + n] = acc[tt];
 }
 
-// out[b][c][t] = sum_n WeffT[n][c] * X[b, (S-T)+t, n].  16 tokens per workgroup: their rows of X are staged in LDS once, the four
-// waves split the D input channels (each streams a quarter of the weights, lane = output channel: coalesced 256-byte rows, 4 rows in
-// flight), partial sums meet in LDS and are written with 16 consecutive time steps per channel (64-byte runs of out[b][c][:]).
+// out[b][c][t] = sum_n WeffT[n][c] * X[b, (S-T)+t, n].  16 tokens per workgroup: their rows of X are staged in LDS once, the eight
+// waves split the D input channels.  Inside a wave, lane = (4 output channels, 4 consecutive input channels): one step covers 16
+// input channels with four 16-byte weight loads per lane (each instruction reads four full 256-byte weight rows) and sixteen
+// broadcast float4 reads of the staged rows for 256 FMAs -- the round-1 kernel had one 4-byte weight load per 16 FMAs and sat on
+// load latency.  The partial sums of the 4 x 8 input-channel slices meet through two lane exchanges and LDS; results are written with
+// 16 consecutive time steps per channel (64-byte runs of out[b][c][:]).
 constexpr int OP_TOK = 16;
 __global__ __launch_bounds__(512) void output_proj_kernel(const float* __restrict__ X, const float* __restrict__ WeffT,
                                                           float* __restrict__ out, int Bf, int C, int T, int S, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem_op[];
     float* xs = reinterpret_cast<float*>(smem_op);          // [OP_TOK][D]
-    float* red = xs + (size_t)OP_TOK * D;                   // [8 waves][OP_TOK][64]
+    float* red = xs + (size_t)OP_TOK * D;                   // [8 waves][64 channels][OP_TOK]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tok0 = blockIdx.x * OP_TOK;                   // token index b * T + t
     const int total = Bf * T;
@@ -161,25 +166,47 @@ __global__ __launch_bounds__(512) void output_proj_kernel(const float* __restric
         reinterpret_cast<float4*>(xs + (size_t)tk * D)[q] = reinterpret_cast<const float4*>(X + ((size_t)b * S + (S - T) + t) * D)[q];
     }
     __syncthreads();
-    const int c = lane < C ? lane : C - 1;
-    float acc[OP_TOK];
+    const int cg = lane & 15, ns = lane >> 4;               // channels 4cg .. 4cg+3, input channels n0 + 4ns .. +3 of a step
+    const int c0 = 4 * cg < C ? 4 * cg : 0;                 // (C % 4 == 0 is checked by the launcher; lanes beyond C recompute group 0)
+    float acc[4][OP_TOK];
 #pragma unroll
-    for (int tk = 0; tk < OP_TOK; ++tk) acc[tk] = 0.f;
-    const int nq = D / 8;                                   // input channels per wave (D % 128 == 0)
-    for (int n0 = wave * nq; n0 < (wave + 1) * nq; n0 += 16) {
-        float w[16];                                        // 16 weight rows (coalesced 256-byte reads) in flight
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = WeffT[(size_t)(n0 + u) * C + c];
+        for (int tk = 0; tk < OP_TOK; ++tk) acc[e][tk] = 0.f;
+    const int nq = D / 8;                                   // input channels per wave (D % 128 == 0: a multiple of 16)
+    const float* wp = WeffT + (size_t)(wave * nq + 4 * ns) * C + c0;
+    float4 w[4], wn[4];
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4)
+    for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (size_t)u * C);
+    for (int n0 = 0; n0 < nq; n0 += 16) {
+        if (n0 + 16 < nq) {
 #pragma unroll
-            for (int tk = 0; tk < OP_TOK; ++tk) {
-                const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)tk * D + n0 + u4 * 4);
-                acc[tk] += (w[u4 * 4] * xv.x + w[u4 * 4 + 1] * xv.y) + (w[u4 * 4 + 2] * xv.z + w[u4 * 4 + 3] * xv.w);
-            }
+            for (int u = 0; u < 4; ++u) wn[u] = *reinterpret_cast<const float4*>(wp + (size_t)(n0 + 16 + u) * C);
+        }
+        const float* xrow = xs + wave * nq + n0 + 4 * ns;
+#pragma unroll
+        for (int tk = 0; tk < OP_TOK; ++tk) {
+            const float4 xv = *reinterpret_cast<const float4*>(xrow + (size_t)tk * D);
+            acc[0][tk] += (w[0].x * xv.x + w[1].x * xv.y) + (w[2].x * xv.z + w[3].x * xv.w);
+            acc[1][tk] += (w[0].y * xv.x + w[1].y * xv.y) + (w[2].y * xv.z + w[3].y * xv.w);
+            acc[2][tk] += (w[0].z * xv.x + w[1].z * xv.y) + (w[2].z * xv.z + w[3].z * xv.w);
+            acc[3][tk] += (w[0].w * xv.x + w[1].w * xv.y) + (w[2].w * xv.z + w[3].w * xv.w);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = wn[u];
     }
+    // fold the four input-channel slices of the wave (lanes l, l+16, l+32, l+48), then the eight waves through LDS
 #pragma unroll
-    for (int tk = 0; tk < OP_TOK; ++tk) red[(wave * OP_TOK + tk) * 64 + lane] = acc[tk];
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int tk = 0; tk < OP_TOK; ++tk) {
+            float v = acc[e][tk];
+            v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));      // lane ^ 16
+            unsigned a = __float_as_uint(v), bq = a;
+            half_swap(a, bq);                                                                  // lane ^ 32
+            v = __uint_as_float(a) + __uint_as_float(bq);
+            if (lane < 16) red[((size_t)wave * 64 + 4 * cg + e) * OP_TOK + tk] = v;
+        }
     __syncthreads();
     for (int i = threadIdx.x; i < OP_TOK * 64; i += 512) {
         const int ch = i / OP_TOK, tk = i - ch * OP_TOK;    // 16 consecutive threads = 16 consecutive time steps of one channel
@@ -187,7 +214,7 @@ __global__ __launch_bounds__(512) void output_proj_kernel(const float* __restric
         if (ch < C && row < total) {
             float v = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < 8; ++wv) v += red[(wv * OP_TOK + tk) * 64 + ch];
+            for (int wv = 0; wv < 8; ++wv) v += red[((size_t)wv * 64 + ch) * OP_TOK + tk];
             const int b = row / T, t = row - b * T;
             out[((size_t)b * C + ch) * T + t] = v;
         }
@@ -358,13 +385,13 @@ int glue_fold_out(const float* Wout, const float* Wpost, float* Weff, int D, int
 int glue_input_proj(const float* x, const float* Weff, float* X, int Bf, int xB, int C, int T, int S, int D, float xscale,
                     hipStream_t s) {
     SAT_CHECK_ARG(C <= 64, SAT_E_UNSUPPORTED, "input_proj: io_channels %d > 64", C);
-    hipLaunchKernelGGL(input_proj_kernel, dim3(cdiv(T, IP_TT), Bf), dim3(256), 0, s, x, Weff, X, xB, C, T, S, D, xscale);
+    hipLaunchKernelGGL(input_proj_kernel, dim3(cdiv(T, IP_TT), cdiv(D, 256), Bf), dim3(256), 0, s, x, Weff, X, xB, C, T, S, D, xscale);
     SAT_LAUNCH_CHECK();
     return 0;
 }
 
 int glue_output_proj(const float* X, const float* WeffT, float* out, int Bf, int C, int T, int S, int D, hipStream_t s) {
-    SAT_CHECK_ARG(C <= 64 && D % 16 == 0, SAT_E_UNSUPPORTED, "output_proj: C=%d D=%d unsupported", C, D);
+    SAT_CHECK_ARG(C <= 64 && C % 4 == 0 && D % 16 == 0, SAT_E_UNSUPPORTED, "output_proj: C=%d (multiple of 4, <= 64) D=%d unsupported", C, D);
     const int lds = (OP_TOK * D + 8 * OP_TOK * 64) * 4;
     SAT_CHECK_ARG(lds <= 160 * 1024 && D % 128 == 0, SAT_E_UNSUPPORTED, "output_proj: embed_dim %d unsupported (multiple of 128, <= 2048)", D);
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(output_proj_kernel), 160 * 1024));
