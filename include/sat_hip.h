@@ -262,7 +262,10 @@ int sat_gemm_swiglu_bf16(const void* a_bf16_dev, const float* w_f32_dev, const f
  * vt [b,kvh,64,sk_pad] bf16 -> out [b*sq, h*64] bf16; softmax(q k^T / 8) v, GQA h/kvh.
  * Key-side layout: the sk keys of sequence i occupy rows (of k) / columns (of vt) [o_i, o_i + sk) with
  * o_i = (i*sk) & 3; everything outside must be finite (zero).  sq_pad % 128 == 0, sk_pad % 64 == 0,
- * sk_pad >= sk + 3.  (The shift lets the QKV GEMM epilogue store V^T with aligned 8-byte stores.) */
+ * sk_pad >= sk + 3.  (The shift lets the QKV GEMM epilogue store V^T with aligned 8-byte stores.)
+ * Key order inside vt: every aligned group of 16 key columns is stored as [0-3, 8-11, 4-7, 12-15], i.e. key s sits at column
+ * (s & ~12) | ((s & 4) << 1) | ((s & 8) >> 1) -- the order in which the second attention MFMA consumes the probabilities a lane
+ * holds, so that a V^T tile is copied to LDS verbatim.  k keeps the natural order.  sat_qkv_rope_bf16 writes this layout. */
 int sat_attention_bf16(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
                        int32_t b, int32_t h, int32_t kvh, int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad,
                        sat_stream_t stream);
