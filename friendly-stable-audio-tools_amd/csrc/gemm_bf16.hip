@@ -11,6 +11,8 @@
 //              32 gate so both land in one wave tile; models/transformer.py:232-235)
 //   EPI_HEADS  split into heads, partial RoPE (models/transformer.py:158-183,438-452) on
 //              q/k, store q/k as [B,H,Spad,64] and v transposed as [B,H,64,Spad]
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "sat_common.h"
@@ -1258,13 +1260,27 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 // -DSAT_GEMM_EXPERIMENTS, see profiles/r01_gemm_variants*.txt for what they measured):
 //    1  128x128, 4 waves, register-staged double buffer   (reference tile; tiny per-generation GEMMs: cross-attention to_kv)
 //    5  128x128, 4 waves, LDS-DMA double buffer            (K < 192: too short for a 3-stage ring)
-//   15  128x128x64, 8 waves, 3-stage LDS-DMA ring          (to_out / FF-out at 1 prompt)
+//   15  128x128x64, 8 waves, 3-stage LDS-DMA ring          (to_out at 1 prompt)
+//   44  the same with a 4-stage ring, fp32 output only     (FF-out at 1 prompt: K = 6144)
 //   16  128x64x64,  4 waves, 3-stage ring                  (cross-attention projections, M = 1025)
 //   22  256x256x64, 16 waves, 2-stage ring                 (FF-in at 1 prompt; every GEMM from 4 prompts on.  The 4-stage BK = 32
 //       variant with cross-tile fragment prefetch and grouped raster of round 1 measured within 2 % of it at 8 prompts after the
 //       epilogue rewrite -- profiles/r02_b8_tiles.txt -- and was removed)
 //   30  256x192x64, 12 waves, 2-stage ring                 (to_qkv at 1 prompt)
 // fp8 (e4m3) operands: 15 / 16 / 22 / 30 in three flavours (plain fp8 MFMA, 2x-rate block-scaled MFMA, MXFP8 A operand).
+// experiments build: SAT_GEMM_NO_DEEP=1 keeps the 3-stage ring for FF-out (A/B measurements)
+inline bool deep_ring_off() {
+#ifdef SAT_GEMM_EXPERIMENTS
+    static const bool off = [] {
+        const char* e = getenv("SAT_GEMM_NO_DEEP");
+        return e && e[0] == '1';
+    }();
+    return off;
+#else
+    return false;
+#endif
+}
+
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
 #ifdef SAT_GEMM_EXPERIMENTS
@@ -1346,6 +1362,8 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             else if (best == s256) v = 22;
             else if (best == s192) v = 30;
             else v = 15;
+            // long reductions (FF-out: 96 K-tiles) gain 4 % from a fourth ring stage (prefetch distance 3); K = 1536 does not care
+            if (v == 15 && EPI == EPI_F32 && a.K >= 4096 && !deep_ring_off()) v = 44;
         } else {
             v = 5;
         }
@@ -1354,6 +1372,9 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
         case 5: return launch_cfg<128, 128, 2, 2, EPI, true>(a, stream);
         case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI>(a, stream);
+        case 44:
+            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 2, 4, EPI>(a, stream);
+            break;
         case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);
         case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI>(a, stream);
         case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
@@ -1366,6 +1387,11 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 13: return launch_pipe<256, 256, 32, 2, 4, 3, EPI>(a, stream);
         case 39: return launch_pipe<128, 128, 128, 4, 2, 2, EPI>(a, stream);       // 256-B rows: half the barriers per k
         case 41: return launch_pipe<256, 128, 32, 4, 2, 3, EPI>(a, stream);        // 72 KiB, <= 128 VGPRs: two workgroups per CU
+        case 45:                                                                    //                               distance 4 (160 KiB)
+            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 2, 5, EPI>(a, stream);
+            break;
+        case 46: return launch_pipe<128, 64, 64, 4, 1, 5, EPI>(a, stream);         // tile 16 with prefetch distance 4
+        case 47: return launch_pipe<128, 64, 64, 4, 1, 6, EPI>(a, stream);         //                               distance 5 (144 KiB)
         case 42: return launch_pipe<128, 128, 64, 2, 2, 4, EPI>(a, stream);        // 4 waves of 64x64 (half the LDS reads per MFMA of tile 15), 4 stages
         case 43: return launch_pipe<128, 128, 64, 2, 2, 2, EPI>(a, stream);        // same, 2 stages = 64 KiB: two workgroups per CU
 #endif

@@ -48,7 +48,7 @@ def test_cast_bf16(dev):
 
 # the shipped tile configurations (gemm_bf16.hip: launch_epi); 0 = the launcher's own choice
 GEMM_VARIANTS = [1, 5, 15, 16, 22, 30]
-GEMM_F32_VARIANTS = GEMM_VARIANTS
+GEMM_F32_VARIANTS = GEMM_VARIANTS + [44]        # 44: tile 15 with a 4-stage ring (fp32 output, long K)
 
 
 def _skip_tile(variant, n, k):
@@ -204,7 +204,7 @@ def _ln_fold_reference(xb, w, gamma, beta, bias):
 
 
 @pytest.mark.parametrize("m", [300, 770])
-@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (0, 0)])
+@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (0, 0)])
 def test_ln_fold_swiglu(dev, prod, cons, m):
     """LayerNorm folded into FF-in (sat_dit_cfg.ln_fold): producer epilogue -> bf16 rows + partial sums -> SwiGLU GEMM that finishes
     the normalisation.  Gates: 4e-3 against the same arithmetic in fp64 (one bf16 rounding of the output), 1e-2 against the plain fp32

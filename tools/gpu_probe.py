@@ -234,7 +234,7 @@ def small_tiles():
         c = torch.zeros(m, n, device=dev)
         bias = torch.randn(n, device=dev)
         fs = {v: (lambda v=v: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(c), m, n, k, 1, v, _hip.stream())))
-              for v in (15, 16, 10, 42, 43, 39, 12)}
+              for v in ([15, 16, 10, 42, 43, 39, 12] if not os.environ.get("PROBE_DEPTH") else [15, 44, 45, 16, 46, 47])}
         res = {v: [] for v in fs}
         for _ in range(5):
             for v, f in fs.items():
