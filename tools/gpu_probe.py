@@ -272,6 +272,50 @@ def hybrid_probe():
         print(f"hybrid {kk:40s} {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
 
 
+def two_streams():
+    """Would running the two CFG halves (conditional / unconditional sequences) as independent kernel streams fill the CUs that every
+    kernel's last round leaves idle?  (a) the shipped CFG-batched step (2 sequences per launch) vs (b) two single-sequence forwards of two
+    model instances on two HIP streams at once -- the conditional one with its context, the unconditional one with the null-context skip."""
+    import copy
+    import stable_audio_tools as S
+    from stable_audio_tools import model_configs as MC, synthetic
+    from stable_audio_tools.models import _init
+    mods = []
+    for _ in range(2):
+        with _init.skip_init():
+            model = S.create_model_from_config(MC.stable_audio_open_1_0())
+        model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), 0))
+        mods.append(model.to(dev).eval().model.model)
+    m0, m1 = mods
+    b = int(os.environ.get("PROBE_B", "1"))
+    c = torch.randn(b, 130, 768, device=dev)
+    g = torch.randn(b, 1536, device=dev)
+    x = torch.randn(b, 64, 1024, device=dev)
+    out = torch.empty_like(x)
+    m0.prepare_generation(c, g, 7.0)
+    ms_a = min(timeit(lambda: m0.denoise(x, 3.0, cfg_scale=7.0, out=out), iters=10, warm=2) for _ in range(3))
+    m0.prepare_generation(c, g, 1.0)
+    m1.prepare_context(torch.zeros_like(c), g, 0)
+    o0, o1 = torch.empty_like(x), torch.empty_like(x)
+    ms_c = min(timeit(lambda: m0.denoise(x, 3.0, out=o0), iters=10, warm=2) for _ in range(3))
+    ms_u = min(timeit(lambda: m1.denoise(x, 3.0, out=o1), iters=10, warm=2) for _ in range(3))
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def both():
+        cur = torch.cuda.current_stream()
+        s0.wait_stream(cur)
+        s1.wait_stream(cur)
+        with torch.cuda.stream(s0):
+            m0.denoise(x, 3.0, out=o0)
+        with torch.cuda.stream(s1):
+            m1.denoise(x, 3.0, out=o1)
+        cur.wait_stream(s0)
+        cur.wait_stream(s1)
+    ms_b = min(timeit(both, iters=10, warm=2) for _ in range(3))
+    print(f"two streams B={b}: batched CFG step {ms_a:.3f} ms | conditional alone {ms_c:.3f} + unconditional alone {ms_u:.3f} = {ms_c + ms_u:.3f} ms | "
+          f"both on two streams {ms_b:.3f} ms", flush=True)
+
+
 def ablate():
     """Where does the time of each shipped GEMM go?  Ablation modes of the experiments build (SAT_HIP_EXP=1): 2 = no LDS-DMA in the
     loop, 4 = + no barrier, 5 = + no ds_read (MFMA on register fragments), 6 = + no epilogue, 7 = 5 with the epilogue arithmetic but
@@ -427,6 +471,8 @@ if __name__ == "__main__":
         section("8 prompts: tile 22 vs 26", b8_tiles)
     if "f32epi" in which:
         section("fp32 epilogue A/B", f32_epi_ab)
+    if "twostreams" in which:
+        section("two CFG halves on two streams", two_streams)
     if "hybrid" in which:
         section("FF-in two-launch split", hybrid_probe)
     if "smalltiles" in which:
