@@ -133,6 +133,8 @@ def main():
     if args.gemm_dtype != "bf16":
         model.model.model.set_gemm_dtype(args.gemm_dtype)
     cond_dim = model_config["model"]["conditioning"]["cond_dim"]
+    if model.conditioner is not None:
+        model.conditioner.set_device(str(device))      # what generate_diffusion_cond does first (generation.py:125); needed by encoders here
     # ids the diffusion model consumes but the conditioner cannot produce here (text / audio encoders): fail before any work is done
     needs_text = any(k not in model.conditioner.conditioners for k in model.cross_attn_cond_ids)
     embed_of = text_embed_source(args, cond_dim) if needs_text else None
