@@ -132,3 +132,52 @@ def test_t5_conditioner_forward_with_projection_and_multiconditioner(dev):
     emb2, _ = cond(texts)
     assert_close("after a weight update", emb2, torch.nn.functional.linear(hidden, cond.proj_out.weight.cpu(), cond.proj_out.bias.cpu())
                  * enc["attention_mask"].unsqueeze(-1).float(), 2e-5)
+
+
+@pytest.mark.gpu
+def test_text_to_audio_through_generate_diffusion_cond(dev):
+    """Prompts as TEXT through the public entry (generation.py:95-261 with ``conditioning=``): MultiConditioner -> T5 encoder on the
+    device -> cross-attention context + mask -> sampler -> decoder, against the same call fed with pre-computed tensors."""
+    import stable_audio_tools as S
+    from stable_audio_tools import model_configs as MC, synthetic
+    from stable_audio_tools.inference.generation import generate_diffusion_cond
+    from stable_audio_tools.models import _init
+    from stable_audio_tools.models.conditioners import T5Conditioner
+    cfg = MC.reduced(MC.stable_audio_open_1_0(with_text_encoder=True))       # conditioning config with the reference's "t5" entry
+    with _init.skip_init():
+        model = S.create_model_from_config(cfg)
+    model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), 5))
+    # t5-base is not in this machine's Hugging Face cache: the factory lists the id as external instead of instantiating the encoder
+    assert "prompt" in model.conditioner.external_ids or "prompt" in model.conditioner.conditioners
+    hf = _hf_encoder("flan", 13)
+    hcfg = hf.config
+
+    class WordTokenizer:
+        def __call__(self, texts, truncation, max_length, padding, return_tensors):
+            ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+            mask = torch.zeros_like(ids)
+            for n, text in enumerate(texts):
+                toks = [2 + sum(map(ord, w)) % (hcfg.vocab_size - 2) for w in text.split()][: max_length - 1] + [1]
+                ids[n, : len(toks)] = torch.tensor(toks)
+                mask[n, : len(toks)] = 1
+            return {"input_ids": ids, "attention_mask": mask}
+
+    torch.manual_seed(2)
+    cond_dim = cfg["model"]["conditioning"]["cond_dim"]
+    t5 = T5Conditioner(cond_dim, "t5-small", max_length=16, project_out=True).load_encoder(hf.state_dict(), hcfg, WordTokenizer())
+    model.conditioner.conditioners["prompt"] = t5              # what create_multi_conditioner does when the weights are cached locally
+    model = model.to(dev).eval()
+    meta = [{"prompt": "dry kick drum one shot", "seconds_start": 0, "seconds_total": 0.03},
+            {"prompt": "a long evolving pad with shimmer", "seconds_start": 0, "seconds_total": 0.04}]
+    kw = dict(steps=4, cfg_scale=6.0, sample_size=cfg["sample_size"], sigma_min=0.3, sigma_max=500, sampler_type="dpmpp-3m-sde",
+              device=str(dev), seed=11)
+    from_text = generate_diffusion_cond(model, conditioning=meta, **kw)
+    tensors = model.conditioner(meta)
+    emb, mask = tensors["prompt"]
+    assert emb.shape == (2, 16, cond_dim) and mask.dtype == torch.bool and mask.sum().item() == (5 + 1) + (6 + 1)      # words + EOS
+    from_tensors = generate_diffusion_cond(model, conditioning_tensors=tensors, **kw)
+    assert torch.isfinite(from_text).all() and from_text.shape == (2, 2, cfg["sample_size"])
+    assert torch.equal(from_text, from_tensors)
+    # and the text matters: another prompt, same seed -> different audio
+    meta[0]["prompt"] = "bright bell"
+    assert not torch.equal(generate_diffusion_cond(model, conditioning=meta, **kw)[0], from_text[0])
