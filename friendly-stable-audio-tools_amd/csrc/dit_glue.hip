@@ -100,47 +100,40 @@ __global__ __launch_bounds__(256) void adaln_finish_kernel(float* __restrict__ s
 // (S - T = number of prepended rows: 1 for global_cond_type 'prepend', 0 for 'adaLN')
 // X[b, (S-T)+t, n] = xscale * sum_c Weff[n][c] * x[b % xB][c][t]       (C <= 64)
 // One workgroup = 32 time steps x 256 output channels, thread = output channel n with 32 accumulators (one per time step).  The
-// folded weight is read TRANSPOSED (WeffT[c][n]: consecutive lanes read consecutive floats, once per workgroup, 8 loads in flight);
-// the inputs of the 32 time steps sit in LDS and are read as broadcast float4, so the inner loop is 4 FMAs per LDS read and 32 FMAs
-// per global load (round 1: 8 time steps per workgroup, every workgroup streaming the whole weight: 100 MB of L2 traffic per call);
-// stores are row-contiguous (1 KiB per wave).
+// folded weight is read TRANSPOSED (WeffT[c][n]: consecutive lanes read consecutive floats, once per workgroup).  The inputs of the
+// 32 time steps are the SAME for every lane, so they are read through wave-uniform addresses -- scalar loads into SGPRs, consumed as
+// the scalar operand of v_fmac: no LDS traffic at all (a first version broadcast them from LDS and was bound by the LDS pipe: one
+// 16-byte broadcast read per 4 FMAs is twice what four SIMDs can be fed).  Stores are row-contiguous (1 KiB per wave).
 constexpr int IP_TT = 32;
 __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ WeffT,
                                                          float* __restrict__ X, int xB, int C, int T, int S, int D, float xscale) {
-    __shared__ __attribute__((aligned(16))) float xs[64][IP_TT];
     const int b = blockIdx.z;
     const int t0 = blockIdx.x * IP_TT;
     const int n = blockIdx.y * 256 + threadIdx.x;
-    const float* xb = x + (size_t)(b % xB) * C * T;
-    for (int i = threadIdx.x; i < 64 * IP_TT; i += 256) {
-        const int c = i / IP_TT, tt = i - c * IP_TT;
-        const int t = t0 + tt;
-        xs[c][tt] = (c < C && t < T) ? xb[(size_t)c * T + t] * xscale : 0.f;
-    }
-    __syncthreads();
+    const float* __restrict__ xb = x + (size_t)(b % xB) * C * T + t0;      // wave-uniform
     if (n >= D) return;
     float acc[IP_TT];
 #pragma unroll
     for (int tt = 0; tt < IP_TT; ++tt) acc[tt] = 0.f;
-#pragma unroll 1
-    for (int c0 = 0; c0 < C; c0 += 8) {
-        float w[8];
+    if (t0 + IP_TT <= T) {
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const float w = WeffT[(size_t)c * D + n];
+            const float* __restrict__ xr = xb + (size_t)c * T;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = (c0 + u < C) ? WeffT[(size_t)(c0 + u) * D + n] : 0.f;
+            for (int tt = 0; tt < IP_TT; ++tt) acc[tt] += w * xr[tt];
+        }
+    } else {          // last chunk of a sequence whose length is not a multiple of 32
+        for (int c = 0; c < C; ++c) {
+            const float w = WeffT[(size_t)c * D + n];
+            const float* __restrict__ xr = xb + (size_t)c * T;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int q = 0; q < IP_TT / 4; ++q) {
-                const float4 xv = *reinterpret_cast<const float4*>(&xs[(c0 + u) & 63][q * 4]);      // LDS broadcast
-                acc[q * 4] += w[u] * xv.x;
-                acc[q * 4 + 1] += w[u] * xv.y;
-                acc[q * 4 + 2] += w[u] * xv.z;
-                acc[q * 4 + 3] += w[u] * xv.w;
-            }
+            for (int tt = 0; tt < IP_TT; ++tt) acc[tt] += w * (t0 + tt < T ? xr[tt] : 0.f);
+        }
     }
 #pragma unroll
     for (int tt = 0; tt < IP_TT; ++tt)
-        if (t0 + tt < T) X[((size_t)b * S + (S - T) + t0 + tt) * D + n] = acc[tt];
+        if (t0 + tt < T) X[((size_t)b * S + (S - T) + t0 + tt) * D + n] = acc[tt] * xscale;
 }
 
 // out[b][c][t] = sum_n WeffT[n][c] * X[b, (S-T)+t, n].  16 tokens per workgroup: their rows of X are staged in LDS once, the eight
