@@ -136,13 +136,13 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
         if (t0 + tt < T) X[((size_t)b * S + (S - T) + t0 + tt) * D + n] = acc[tt] * xscale;
 }
 
-// out[b][c][t] = sum_n WeffT[n][c] * X[b, (S-T)+t, n].  16 tokens per workgroup: their rows of X are staged in LDS once, the eight
+// out[b][c][t] = sum_n WeffT[n][c] * X[b, (S-T)+t, n].  OP_TOK tokens per workgroup: their rows of X are staged in LDS once, the eight
 // waves split the D input channels.  Inside a wave, lane = (4 output channels, 4 consecutive input channels): one step covers 16
-// input channels with four 16-byte weight loads per lane (each instruction reads four full 256-byte weight rows) and sixteen
-// broadcast float4 reads of the staged rows for 256 FMAs -- the round-1 kernel had one 4-byte weight load per 16 FMAs and sat on
+// input channels with four 16-byte weight loads per lane (each instruction reads four full 256-byte weight rows) and OP_TOK
+// broadcast float4 reads of the staged rows for 16 x OP_TOK FMAs -- the round-1 kernel had one 4-byte weight load per 16 FMAs and sat on
 // load latency.  The partial sums of the 4 x 8 input-channel slices meet through two lane exchanges and LDS; results are written with
-// 16 consecutive time steps per channel (64-byte runs of out[b][c][:]).
-constexpr int OP_TOK = 16;
+// OP_TOK consecutive time steps per channel.
+constexpr int OP_TOK = 8;      // 8 tokens: 256 workgroups at T = 1024 x 2 sequences (16 left half the CUs idle: 26.7 -> 15.9 us; 4: 16.4 us)
 __global__ __launch_bounds__(512) void output_proj_kernel(const float* __restrict__ X, const float* __restrict__ WeffT,
                                                           float* __restrict__ out, int Bf, int C, int T, int S, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem_op[];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void output_proj_kernel(const float* __restric
         }
     __syncthreads();
     for (int i = threadIdx.x; i < OP_TOK * 64; i += 512) {
-        const int ch = i / OP_TOK, tk = i - ch * OP_TOK;    // 16 consecutive threads = 16 consecutive time steps of one channel
+        const int ch = i / OP_TOK, tk = i - ch * OP_TOK;    // OP_TOK consecutive threads = consecutive time steps of one channel
         const int row = tok0 + tk;
         if (ch < C && row < total) {
             float v = 0.f;
