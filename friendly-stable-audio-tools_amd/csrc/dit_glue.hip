@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void adaln_finish_kernel(float* __restrict__ s
 
 // (S - T = number of prepended rows: 1 for global_cond_type 'prepend', 0 for 'adaLN')
 // X[b, (S-T)+t, n] = xscale * sum_c Weff[n][c] * x[b % xB][c][t]       (C <= 64)
-// One workgroup = 32 time steps x 256 output channels, thread = output channel n with 32 accumulators (one per time step).  The
+// One workgroup = IP_TT time steps x 256 output channels, thread = output channel n with one accumulator per time step.  The
 // folded weight is read TRANSPOSED (WeffT[c][n]: consecutive lanes read consecutive floats, once per workgroup).  The inputs of the
-// 32 time steps are the SAME for every lane, so they are read through wave-uniform addresses -- scalar loads into SGPRs, consumed as
+// time steps are the SAME for every lane, so they are read through wave-uniform addresses -- scalar loads into SGPRs, consumed as
 // the scalar operand of v_fmac: no LDS traffic at all (a first version broadcast them from LDS and was bound by the LDS pipe: one
 // 16-byte broadcast read per 4 FMAs is twice what four SIMDs can be fed).  Stores are row-contiguous (1 KiB per wave).
-constexpr int IP_TT = 32;
+constexpr int IP_TT = 8;       // measured at T = 1024: 32 -> 19.6 us, 16 -> 15.3, 8 -> 12.5, 4 -> 18.0
 __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ x, const float* __restrict__ WeffT,
                                                          float* __restrict__ X, int xB, int C, int T, int S, int D, float xscale) {
     const int b = blockIdx.z;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
 #pragma unroll
             for (int tt = 0; tt < IP_TT; ++tt) acc[tt] += w * xr[tt];
         }
-    } else {          // last chunk of a sequence whose length is not a multiple of 32
+    } else {          // last chunk of a sequence whose length is not a multiple of IP_TT
         for (int c = 0; c < C; ++c) {
             const float w = WeffT[(size_t)c * D + n];
             const float* __restrict__ xr = xb + (size_t)c * T;
