@@ -217,6 +217,39 @@ def test_full_dit_golden_exists_and_oracle_matches():
     assert rel_l2(out, g["out"]) < 5e-5
 
 
+def test_layernorm_fold_hook_of_the_oracle(small_dit_sd):
+    """``LnFoldRounding`` restates LayerNorm + Linear the way the fused kernels evaluate it (sat_dit_cfg.ln_fold).  With its rounding
+    switched off the rewrite must BE the reference: the reference's own transformer-block and full-forward outputs come back (fp32
+    round-off of the one-pass variance aside); with bf16 rounding it stays as close to them as the plain bf16 hook does."""
+    class Exact(odit.LnFoldRounding):
+        round = staticmethod(lambda x: x)
+
+    class ExactNoFold:                      # same no-op rounding through the un-folded code path
+        def __call__(self, x):
+            return x
+
+    sd = small_dit_sd
+    ops = cases.load("ops")
+    pf = "transformer.layers.1."
+    x = synthetic.synth_input("h", (2, 77, 256), 100)
+    ctx = synthetic.synth_input("ctx", (2, 130, 128), 101)
+    freqs = odit.rotary_freqs(sd["transformer.rotary_pos_emb.inv_freq"], 77)
+    assert rel_l2(odit.transformer_block(sd, pf, x, ctx, freqs, 4, 64, rnd=Exact()), ops["block"]) < 5e-6
+    g = cases.load("dit_small")
+    x, t, c, gl = cases.dit_inputs(2, 64, 128, 96, 1)
+    for cfg, key in ((1.0, "cfg1_T64"), (7.0, "cfg7_T64")):
+        assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, cfg_scale=cfg, rnd=Exact()), g[key]) < 2e-5
+    assert rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, rnd=ExactNoFold()), g["cfg1_T64"]) < TOL
+    # rows with a large common offset: the fold subtracts mean * rowsum(W) from a large accumulator -- still the reference in fp32
+    xo = x * 0.05 + 3.0
+    ref = odit.dit_forward(sd, xo, t, c, gl, 3, 4)
+    assert rel_l2(odit.dit_forward(sd, xo, t, c, gl, 3, 4, rnd=Exact()), ref) < 2e-5
+    # with bf16 rounding: as close to the reference as the plain bf16 rounding points
+    e_fold = rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, rnd=odit.LnFoldRounding()), g["cfg1_T64"])
+    e_plain = rel_l2(odit.dit_forward(sd, x, t, c, gl, 3, 4, rnd=odit.bf16_round), g["cfg1_T64"])
+    assert e_fold < 1.5 * e_plain + 1e-4 and e_fold < 3e-3
+
+
 def test_fp8_rounding_hooks_of_the_oracle():
     """The matched-rounding hooks of the fp8 GEMM mode (BASELINE config 5) are test infrastructure too: pin their arithmetic.
     e4m3 per-row scaling: amax maps to exactly 448, relative error <= 2^-4 per element of the same binade; MXFP8: power-of-two
