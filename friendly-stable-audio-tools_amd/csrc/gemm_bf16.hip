@@ -1281,6 +1281,8 @@ inline bool deep_ring_off() {
 #endif
 }
 
+int g_wide_tile = 80;
+
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
 #ifdef SAT_GEMM_EXPERIMENTS
@@ -1368,6 +1370,9 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             v = 5;
         }
     }
+    // the 256x256 tile is the 8-wave / 8-phase kernel of gemm_ph8.hip wherever it applies (bf16 operands, K % 128 == 0);
+    // sat_gemm_set_wide_tile(22) brings the 16-wave 2-stage tile back for A/B measurements
+    if (v == 22 && !(a.variant & 0xff) && g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
     switch (v) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
         case 5: return launch_cfg<128, 128, 2, 2, EPI, true>(a, stream);
@@ -1402,6 +1407,12 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int sat_gemm_set_wide_tile(int32_t tile) {
+    SAT_CHECK_ARG(tile == 22 || tile == 80, SAT_E_INVALID, "sat_gemm_set_wide_tile: 22 (16 waves, 2-stage ring) or 80 (8 waves, 8-phase)");
+    g_wide_tile = tile;
+    return 0;
+}
 
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG(a.A && a.W, SAT_E_INVALID, "gemm: null operand");

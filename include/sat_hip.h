@@ -252,6 +252,10 @@ int sat_cast_bf16(const float* x_dev, void* y_bf16_dev, int64_t n, sat_stream_t 
  * n % 128 == 0, k % 64 == 0.  variant selects a tile configuration (0 = default). */
 int sat_gemm_bf16_f32(const void* a_bf16_dev, const void* w_bf16_dev, const float* bias_dev, float* c_dev,
                       int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream);
+/* Which kernel serves the 256 x 256 tile of the bf16 GEMMs: 80 (default) = 8 waves, 128 x 64 per wave, 8-phase schedule with a
+ * counted-vmcnt LDS-DMA ring of half-tiles (csrc/gemm_ph8.hip); 22 = the 16-wave 2-stage tile of rounds 1-2 (A/B measurements;
+ * fp8 operands always use it).  Process-wide; not a per-call argument because the tile is chosen inside the plan. */
+int sat_gemm_set_wide_tile(int32_t tile);
 /* SwiGLU GEMM (models/transformer.py:211-235): h[m,n/2] (bf16) = (A W_v^T + b_v) * silu(A W_g^T + b_g)
  * with W [n,k] in the REFERENCE row order (value rows then gate rows); re-packed internally
  * into wpack_dev [n,k] bf16 and bpack_dev [n] fp32 scratch. */

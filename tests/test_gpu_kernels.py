@@ -47,14 +47,17 @@ def test_cast_bf16(dev):
 
 
 # the shipped tile configurations (gemm_bf16.hip: launch_epi); 0 = the launcher's own choice
-GEMM_VARIANTS = [1, 5, 15, 16, 22, 30]
+# 80: the 256x256 tile on 8 waves with the 8-phase schedule (gemm_ph8.hip) -- what variant 0 picks whenever it picks that tile
+GEMM_VARIANTS = [1, 5, 15, 16, 22, 30, 80]
 GEMM_F32_VARIANTS = GEMM_VARIANTS + [44]        # 44: tile 15 with a 4-stage ring (fp32 output, long K)
 
 
 def _skip_tile(variant, n, k):
     v = variant & 0xff
-    if v == 22 and n % 256:
+    if v in (22, 80) and n % 256:
         pytest.skip("256-column tile needs n % 256 == 0")
+    if v == 80 and k % 128:
+        pytest.skip("the 8-phase tile walks K in pairs of 64-wide tiles")
     if v == 30 and n % 192:
         pytest.skip("192-column tile needs n % 192 == 0")
     if v >= 9 and k < 256:
@@ -204,7 +207,7 @@ def _ln_fold_reference(xb, w, gamma, beta, bias):
 
 
 @pytest.mark.parametrize("m", [300, 770])
-@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (0, 0)])
+@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (0, 0), (80, 80), (15, 80), (80, 30)])
 def test_ln_fold_swiglu(dev, prod, cons, m):
     """LayerNorm folded into FF-in (sat_dit_cfg.ln_fold): producer epilogue -> bf16 rows + partial sums -> SwiGLU GEMM that finishes
     the normalisation.  Gates: 4e-3 against the same arithmetic in fp64 (one bf16 rounding of the output), 1e-2 against the plain fp32
@@ -229,7 +232,7 @@ def test_ln_fold_swiglu(dev, prod, cons, m):
 
 
 @pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
-@pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (0, 0)])
+@pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (0, 0), (80, 80), (16, 80), (80, 15)])
 def test_ln_fold_qkv_rope(dev, prod, cons, s, s_pad):
     """LayerNorm folded into to_qkv + RoPE + head split (transformer.py:692, 314, 430-452): q / k through the transposed epilogue,
     V^T through the un-swapped one -- both have to apply the per-row statistics."""

@@ -122,6 +122,150 @@ def opts():
         arms_bench("opts " + name, m, n, k, vs, blas=False, rounds=5)
 
 
+def epi():
+    """the real epilogues at the shapes the plan launches: 16-wave tile 22 vs the 8-phase tile 80, interleaved"""
+    def ab(label, mk, flops, rounds=5):
+        fs = {"v22": mk(22), "v80": mk(80)}
+        res = {k: [] for k in fs}
+        for _ in range(rounds):
+            for k, f in fs.items():
+                res[k].append(timeit(f, iters=10, warm=2))
+        a, b = statistics.median(res["v22"]), statistics.median(res["v80"])
+        print(f"epi {label:40s} v22 {a*1e3:7.1f} us {flops/a/1e9:7.1f} TF | v80 {b*1e3:7.1f} us {flops/b/1e9:7.1f} TF | x{a/b:.3f}", flush=True)
+
+    for name, m in [("B1", 2050), ("B8", 16400), ("sa2", 12290)]:
+        # SwiGLU with the LayerNorm fold (FF-in as the plan runs it)
+        n, k = 12288, 1536
+        xb = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        part = torch.stack([xb.float().view(m, k // 64, 64).sum(-1), (xb.float() ** 2).view(m, k // 64, 64).sum(-1)], -1).contiguous()
+        w = torch.randn(n, k, device=dev) * 0.05
+        gamma = 0.8 + 0.2 * torch.rand(k, device=dev)
+        beta = 0.1 * torch.randn(k, device=dev)
+        bias = torch.randn(n, device=dev) * 0.1
+        wp = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
+        c12 = torch.empty((2 * n,), dtype=torch.float32, device=dev)
+        out = torch.empty((m, n // 2), dtype=torch.bfloat16, device=dev)
+        _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(bias), _hip.ptr(wp),
+                                               _hip.ptr(c12), _hip.ptr(out), m, n, k, 22, _hip.stream()))
+        ab(f"ff_in swiglu+ln {name} {m}x{n}x{k}",
+           lambda v: (lambda: _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(bias),
+                                                                       _hip.ptr(wp), _hip.ptr(c12), _hip.ptr(out), m, n, k, v | 0x4000, _hip.stream()))),
+           2.0 * m * n * k)
+        # fp32 residual update + LayerNorm-fold producer (FF-out, to_out)
+        for nm, kk in [("ff_out", 6144), ("to_out", 1536)]:
+            nn = 1536
+            a = torch.randn(m, kk, device=dev).to(torch.bfloat16)
+            w2 = (torch.randn(nn, kk, device=dev) * 0.05).to(torch.bfloat16)
+            b2 = torch.randn(nn, device=dev)
+            c = torch.zeros(m, nn, device=dev)
+            xo = torch.empty((m, nn), dtype=torch.bfloat16, device=dev)
+            po = torch.empty((m, nn // 64, 2), dtype=torch.float32, device=dev)
+            ab(f"{nm} resid+ln {name} {m}x{nn}x{kk}",
+               lambda v: (lambda: _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, nn, kk, v,
+                                                                          _hip.stream()))), 2.0 * m * nn * kk)
+    for name, b in [("B1", 2), ("B8", 16)]:
+        s_len, s_pad, d = 1025, 1152, 1536
+        a = torch.randn(b * s_len, d, device=dev).to(torch.bfloat16)
+        w = (torch.randn(3 * d, d, device=dev) * 0.05).to(torch.bfloat16)
+        inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+        q = torch.empty((b, 24, s_pad, 64), dtype=torch.bfloat16, device=dev)
+        kk = torch.empty_like(q)
+        vt = torch.empty((b, 24, 64, s_pad), dtype=torch.bfloat16, device=dev)
+        scratch = torch.empty((2 * s_len * 16,), dtype=torch.float32, device=dev)
+        ab(f"qkv heads+rope {name} {b*s_len}x{3*d}x{d} (+memsets)",
+           lambda v: (lambda: _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(inv_freq), _hip.ptr(q), _hip.ptr(kk), _hip.ptr(vt), _hip.ptr(scratch),
+                                                               b, s_len, s_pad, d, v, _hip.stream()))), 2.0 * b * s_len * 3 * d * d)
+
+
+def ksweep():
+    """one full round (256 tiles) at growing K: time = fixed per-tile overhead (prologue + epilogue) + slope * K"""
+    m, n = 2048, 8192
+    for epi in ("f32", "f32+resid+ln", "swiglu", "swiglu+ln"):
+        pts = []
+        for k in (256, 512, 1024, 1536, 3072, 6144):
+            a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+            if epi.startswith("f32"):
+                w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+                c = torch.zeros(m, n, device=dev)
+                if epi == "f32":
+                    f = gemm_fn(a, w, c, m, n, k, 80)
+                else:
+                    xo = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                    po = torch.empty((m, n // 64, 2), dtype=torch.float32, device=dev)
+                    b2 = torch.randn(n, device=dev)
+                    f = (lambda a=a, w=w, c=c, xo=xo, po=po, b2=b2, k=k: _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo),
+                                                                                                                    _hip.ptr(po), m, n, k, 80, _hip.stream())))
+            else:
+                w = torch.randn(n, k, device=dev) * 0.05
+                bias = torch.randn(n, device=dev) * 0.1
+                wp = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
+                out = torch.empty((m, n // 2), dtype=torch.bfloat16, device=dev)
+                if epi == "swiglu":
+                    bp = torch.empty((n,), dtype=torch.float32, device=dev)
+                    _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m, n, k, 80, _hip.stream()))
+                    f = (lambda a=a, w=w, bias=bias, wp=wp, bp=bp, out=out, k=k: _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp),
+                                                                                                                      _hip.ptr(out), m, n, k, 80 | 0x4000, _hip.stream())))
+                else:
+                    part = torch.stack([a.float().view(m, k // 64, 64).sum(-1), (a.float() ** 2).view(m, k // 64, 64).sum(-1)], -1).contiguous()
+                    gamma = 0.8 + 0.2 * torch.rand(k, device=dev)
+                    beta = 0.1 * torch.randn(k, device=dev)
+                    c12 = torch.empty((2 * n,), dtype=torch.float32, device=dev)
+                    _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(a), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(bias), _hip.ptr(wp),
+                                                           _hip.ptr(c12), _hip.ptr(out), m, n, k, 80, _hip.stream()))
+                    f = (lambda a=a, part=part, w=w, gamma=gamma, beta=beta, bias=bias, wp=wp, c12=c12, out=out, k=k: _hip.check(lib.sat_gemm_swiglu_ln_bf16(
+                        _hip.ptr(a), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(c12), _hip.ptr(out), m, n, k,
+                        80 | 0x4000, _hip.stream())))
+            t = min(timeit(f, iters=20, warm=3) for _ in range(3)) * 1e3
+            pts.append((k, t))
+        (k1, t1), (k2, t2) = pts[2], pts[-1]
+        slope = (t2 - t1) / (k2 - k1)
+        print(f"ksweep {epi:14s} " + "  ".join(f"K={k}: {t:6.1f} us" for k, t in pts) + f"   slope {slope*64:.3f} us per K-tile, intercept {t1 - slope*k1:.1f} us", flush=True)
+
+
+def timeline():
+    """DBG 9: per-workgroup timestamps (100 MHz) of FF-in: where a CU's time goes between tiles"""
+    import ctypes
+    import numpy as np
+    lib.sat_gemm_ph8_timestamps.restype = ctypes.c_int32
+    lib.sat_gemm_ph8_timestamps.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    for name, m in [("B1", 2050), ("B8", 16400), ("1 round", 2048)]:
+        n, k = (12288, 1536) if name != "1 round" else (8192, 1536)
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w = torch.randn(n, k, device=dev) * 0.05
+        bias = torch.randn(n, device=dev) * 0.1
+        wp = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
+        bp = torch.empty((n,), dtype=torch.float32, device=dev)
+        out = torch.empty((m, n // 2), dtype=torch.bfloat16, device=dev)
+        _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m, n, k, 80, _hip.stream()))
+        f = lambda: _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m, n, k, 980 | 0x4000, _hip.stream()))
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        nwg = ((m + 255) // 256) * (n // 256)
+        buf = np.zeros((nwg, 6), dtype=np.uint64)
+        _hip.check(lib.sat_gemm_ph8_timestamps(buf.ctypes.data, nwg))
+        t = buf[:, :4].astype(np.int64)
+        t0 = t[:, 0].min()
+        t = (t - t0) / 100.0          # us
+        cu = (buf[:, 5].astype(np.int64) << 32) | (buf[:, 4].astype(np.int64) & 0xfffff00)   # xcc | se/cu bits (wave slot bits masked)
+        tail = np.array([(i % ((m + 255) // 256)) == ((m + 255) // 256 - 1) and (m % 256) != 0 for i in range(nwg)])
+        full = ~tail
+        print(f"timeline {name}: {nwg} workgroups, kernel span {t[:, 3].max():.1f} us, distinct CU ids {len(set(cu.tolist()))}")
+        print(f"  full tiles: prologue {np.median((t[:,1]-t[:,0])[full]):.2f} us  main loop {np.median((t[:,2]-t[:,1])[full]):.2f} us  epilogue {np.median((t[:,3]-t[:,2])[full]):.2f} us"
+              f"  (p90 {np.percentile((t[:,1]-t[:,0])[full],90):.2f} / {np.percentile((t[:,2]-t[:,1])[full],90):.2f} / {np.percentile((t[:,3]-t[:,2])[full],90):.2f})")
+        # per CU: gaps between the end of one workgroup and the start of the next
+        gaps = []
+        for c in set(cu.tolist()):
+            idx = np.where(cu == c)[0]
+            o = idx[np.argsort(t[idx, 0])]
+            for a_, b_ in zip(o[:-1], o[1:]):
+                gaps.append(t[b_, 0] - t[a_, 3])
+        if gaps:
+            gaps = np.array(gaps)
+            print(f"  gap between consecutive workgroups on one CU: median {np.median(gaps):.2f} us, p90 {np.percentile(gaps,90):.2f}, min {gaps.min():.2f} ({len(gaps)} gaps)")
+        print(f"  first start {t[:,0].min():.2f}, last start of the first 256: {np.sort(t[:,0])[min(255,nwg-1)]:.2f} us", flush=True)
+
+
 def ablate():
     for name, m, n, k in [("4096^3", 4096, 4096, 4096), ("ff_in B8", 16400, 12288, 1536)]:
         arms_bench("ablate " + name, m, n, k, [80, 180, 280, 380], blas=False, rounds=3)
