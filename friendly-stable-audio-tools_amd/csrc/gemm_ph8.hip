@@ -1,9 +1,9 @@
 // 256 x 256 x 64 bf16 MFMA GEMM in the 8-wave / 256-register / 8-phase regime (round 3):
 //     C[M,N] = A[M,K] . W[N,K]^T      A, W bf16 (K contiguous), fp32 accumulate
-// for the wide DiT projections (FF-in SwiGLU, to_qkv; every block GEMM from 4 prompts per GPU on) -- the nn.Linear calls at
-// models/transformer.py:222,270,314,311-312,319 of the reference.  gfx950 only.
+// for the DiT projections (FF-in SwiGLU, to_qkv, FF-out at one prompt; every block GEMM from 4 prompts per GPU on) -- the nn.Linear
+// calls at models/transformer.py:222,270,314,311-312,319 of the reference.  gfx950 only.
 //
-// Structure (one workgroup = 8 waves = 2 (M) x 4 (N), wave tile 128 x 64, v_mfma_f32_16x16x32_bf16, 128 accumulator registers):
+// Main loop (one workgroup = 8 waves = 2 (M) x 4 (N), wave tile 128 x 64, v_mfma_f32_16x16x32_bf16, 128 accumulator registers):
 //   * a K-tile (64 k) is FOUR 16-KiB half-tiles in LDS, in the order a wave consumes them:
 //         kind 0  W-lo : the first 32 channels of every wave's 64       kind 1  A-lo : the first 64 rows of every wave's 128
 //         kind 2  W-hi : the last 32 channels                           kind 3  A-hi : the last 64 rows
@@ -21,10 +21,30 @@
 //     K-tile it retires is first read one phase later.  Restaging is WAR-safe by construction: slot j of the current buffer is
 //     rewritten in phase j + 1 -- W-lo after an lgkmcnt that retired its reads before phase 0's first barrier, the others two
 //     phases after their last read.
+//   Measured in the loop: 1.36 us per K-tile on 256 CUs = 1575 TFLOP/s (profiles/r03_ph8_ksweep_fixed_overhead.txt).
+//
+// Schedule (PERSISTENT workgroups, one per CU; Ph8Sched, built on the host).  With one 136-KiB workgroup per CU nothing overlaps a
+// tile's prologue and epilogue, and a launch of T tiles costs ceil(T / 256) rounds: measured 8-10 us of a 42-52 us tile
+// (profiles/r03_ph8_workgroup_timeline.txt) and, at one prompt, 2 rounds for 1.5 rounds of work.  So:
+//   * workgroup i walks `dp_rounds` whole tiles (logical tile s G + i in round s: the same neighbourhood per round as hardware
+//     dispatch order, XCD-aware), then its share of the REMAINDER round, which is split along K ("stream-K" for the last round only):
+//     the remaining tiles' K-pair units (128 k) are dealt to the G workgroups in contiguous, cost-balanced ranges (row tiles with
+//     <= 64 valid rows -- the 2 leftover rows of M = 2 x 1025 -- count 0.4);
+//   * a K-range that is not a whole tile ends in a fix-up: every contributor writes its raw accumulators to its own slab
+//     (lane-for-lane the register image, 1-KiB coalesced pieces), agent-scope release + ticket; the LAST arriver acquires, adds the
+//     slabs in ascending workgroup order (bit-deterministic whoever is last; two contributors: own registers + the other slab,
+//     fp32 addition commutes) and runs the normal epilogue.  Nobody waits for anybody;
+//   * the LDS-DMA prologue of the next K-range (7 half-tiles) is issued BEFORE the epilogue of the current one -- the ring is
+//     free after the last barrier of the main loop and the DMA needs no registers -- so its latency hides behind the epilogue.
+//
 // Epilogues run on TRANSPOSED accumulators (W fragment = MFMA A operand): lane l owns token row (l & 15) of a 16 x 16 block and
 // four consecutive output channels; which channels a wave's W rows are is a free permutation applied where the DMA picks its
 // source rows (chan_of), chosen per epilogue so that stores are 16 bytes and SwiGLU / RoPE partners are lane-local.
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
+#include <vector>
 
 #include "sat_common.h"
 
@@ -38,9 +58,12 @@ __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (10 instructions per element in the epilogue)
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
 // Channel (0..63 inside the wave's 64) held by W half-tile `ni` (0 lo / 1 hi), fragment nf (0/1), fragment row i (0..15).
 // After the MFMA lane (i' = l & 15, q = l >> 4) holds rows 4q..4q+3 of the fragment, i.e. fragment rows i = 4q + r.
-//   PERM 0 (fp32 output):  natural order ni*32 + nf*16 + i      -> 4 lanes q write 64 contiguous bytes of a row per store
+//   PERM 0 (fp32 output, V^T):  natural order ni*32 + nf*16 + i  -> 4 lanes q write 64 contiguous bytes of a row per store
 //   PERM 1 (bf16 output):  ni*32 + q*8 + nf*4 + r                -> a lane holds 8 consecutive channels per ni: one 16-byte store;
 //                          value (ni = 0) and gate (ni = 1) of a SwiGLU pair sit in the same lane
 //   PERM 2 (heads):        ni = 0 natural (RoPE partner d + 16 = fragment nf + 1 of the same lane), ni = 1 as PERM 1
@@ -52,63 +75,117 @@ __device__ __forceinline__ int chan_of(int ni, int nf, int i) {
     else return ni == 0 ? nf * 16 + i : 32 + q * 8 + nf * 4 + r;
 }
 
-// DBG (tools/gpu_probe.py ablations, wrong results): 1 no LDS-DMA in the loop, 2 no ds_read (fragments stay), 3 no MFMA
+struct Ph8Sched {
+    int G;                  // workgroups (== gridDim.x)
+    int tiles_n;
+    int tiles_m_full;       // row tiles of the "full" logical tile space
+    int light;              // 1: one more row of tiles with <= 64 valid rows ("light": about half the time of a full tile: the W panel still streams)
+    int light_first;        // work order: light tiles before the full ones (K-split schedules with whole rounds) instead of behind them
+    int dp_rounds;          // whole tiles per workgroup
+    int nkp;                // K-pair units (128 k) per tile
+    int sk_tiles;           // tiles of the remainder space (the full tiles left over by the whole rounds, and the light tiles)
+    const int* sk_tile;     // [sk_tiles] position in the work order
+    const int* sk_begin;    // [G + 1] first unit of workgroup i in that space
+    const int* sk_first;    // [sk_tiles] first contributing workgroup
+    const int* sk_parts;    // [sk_tiles] number of contributing workgroups
+    unsigned* sk_count;     // [sk_tiles] arrival tickets, zero between launches
+    float* sk_slab;         // [G][2][65536] raw accumulator images
+};
+
+struct Seg {                // one K-range of one tile
+    int m0, n0;
+    int kt0, nk;            // first K-tile, K-tiles (even)
+    int skj;                // stream-K tile index (ticket / contributor tables)
+    int slot;               // slab of this workgroup that takes the partial: 0 = its first stream-K range, 1 = a later one
+    bool whole;             // the K-range covers the tile: plain epilogue
+    bool tr;                // accumulator orientation (transposed unless a V^T destination)
+};
+
+// DBG (tools/ph8_probe.py ablations, wrong results): 1 no LDS-DMA in the loop, 2 no ds_read (fragments stay), 3 no MFMA
 // Measured and dropped (profiles/r03_ph8_schedule_options.txt): without the explicit lgkmcnt(0) behind the barrier, without s_setprio,
 // with a static priority for waves 4-7 -- all within 1 %; LDS-DMA issued at the head of the MFMA section instead of the load
 // section -- 5 % slower.
-#ifdef SAT_GEMM_EXPERIMENTS
-unsigned long long* g_ts_buf = nullptr;       // DBG 9: per workgroup (start, prologue done, main loop done, end) in 100 MHz ticks + HW id
-#endif
-
+// DBG 9 (experiments build): per workgroup and K-range the 100 MHz timestamps (range start, main loop done, fix-up done, epilogue
+// done) + (whole, K-tiles, last arriver) -> tools/ph8_probe.py timeline
 template <int EPI, int DBG = 0>
-__global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, unsigned long long* ts = nullptr) {
-    [[maybe_unused]] unsigned long long t_start = 0, t_pro = 0, t_main = 0;
-    if constexpr (DBG == 9) t_start = __builtin_amdgcn_s_memrealtime();
+__global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
+    [[maybe_unused]] int ts_n = 0;
     constexpr int BUF_BYTES = 65536, HALF_BYTES = 16384, RING_BYTES = 131072;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid_ = threadIdx.x;
+    const int lane = tid_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int l15 = lane & 15, q4 = lane >> 4;
-
+    const int l15_ = lane & 15, q4_ = lane >> 4;
     const int M = g.M, N = g.N, K = g.K;
-    const int tiles_m = (M + 255) >> 8;
-    const int tiles_n = N >> 8;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    if (tiles_m <= 12) {               // short M: m fastest, the W panel of a column tile stays in one XCD's L2
-        tn = bid / tiles_m;
-        tm = bid - tn * tiles_m;
-    } else {                           // long M: bands of 8 row tiles, n-major inside a band (8 A panels + the W panels in flight)
-        const int band_sz = 8 * tiles_n;
-        const int band = bid / band_sz;
-        const int rem = bid - band * band_sz;
-        const int gm = min(8, tiles_m - band * 8);
-        tn = rem / gm;
-        tm = band * 8 + (rem - tn * gm);
-    }
-    const int m0 = tm << 8, n0 = tn << 8;
-    // Accumulator orientation, uniform over the workgroup (a 256-column tile never straddles a q / k / v part): transposed
-    // (lane = token) everywhere except for a V^T destination, whose token-contiguous stores want lane = channel.
-    bool tr = true;
-    if constexpr (EPI == EPI_HEADS) tr = !(g.heads.kind[n0 / (g.heads.heads * 64)] & 1);
-    // waves whose 128 rows lie entirely beyond M (the M-tail tile) keep staging and joining barriers, nothing else
-    const bool rows_valid = (m0 + wr * 128) < M;
+    const int wgi = xcd_remap(blockIdx.x, sc.G);          // consecutive logical workgroups share an XCD (and so the tiles they split)
+
+    // ---- the walk over this workgroup's K-ranges
+    auto full_tile = [&](int L, int& tm, int& tn) {        // logical id -> tile of the full space
+        const int tiles_m = sc.tiles_m_full, tiles_n = sc.tiles_n;
+        if (tiles_m <= 12) {               // short M: m fastest, the W panel of a column tile stays in one XCD's L2
+            tn = L / tiles_m;
+            tm = L - tn * tiles_m;
+        } else {                           // long M: bands of 8 row tiles, n-major inside a band (8 A panels + the W panels in flight)
+            const int band_sz = 8 * tiles_n;
+            const int band = L / band_sz;
+            const int rem = L - band * band_sz;
+            const int gm = min(8, tiles_m - band * 8);
+            tn = rem / gm;
+            tm = band * 8 + (rem - tn * gm);
+        }
+    };
+    // work order: the full tiles with the light row behind them, or (light_first) in front of them
+    auto tile_of = [&](int id, int& tm, int& tn) {
+        const int nl = sc.light ? sc.tiles_n : 0;
+        const int lid = sc.light_first ? id : id - sc.tiles_m_full * sc.tiles_n;
+        if (lid >= 0 && lid < nl) { tm = sc.tiles_m_full; tn = lid; }
+        else full_tile(sc.light_first ? id - nl : id, tm, tn);
+    };
+    int dp_s = 0;
+    const int sk_b = sc.sk_tiles ? sc.sk_begin[wgi] : 0;
+    const int sk_e = sc.sk_tiles ? sc.sk_begin[wgi + 1] : 0;
+    int sk_u = sk_b;
+    auto next_seg = [&](Seg& s) -> bool {
+        int tm, tn;
+        if (dp_s < sc.dp_rounds) {
+            tile_of(dp_s * sc.G + wgi, tm, tn);
+            ++dp_s;
+            s.kt0 = 0; s.nk = 2 * sc.nkp; s.whole = true; s.skj = 0; s.slot = 0;
+        } else {
+            if (sk_u >= sk_e) return false;
+            const int j = sk_u / sc.nkp;
+            const int ub = sk_u - j * sc.nkp;
+            const int ue = min(sc.nkp, ub + (sk_e - sk_u));
+            tile_of(sc.sk_tile[j], tm, tn);
+            s.kt0 = 2 * ub; s.nk = 2 * (ue - ub); s.whole = (ub == 0 && ue == sc.nkp); s.skj = j;
+            s.slot = (sk_u == sk_b) ? 0 : 1;
+            sk_u += ue - ub;
+        }
+        s.m0 = tm << 8; s.n0 = tn << 8;
+        // Accumulator orientation, uniform over the workgroup (a 256-column tile never straddles a q / k / v part): transposed
+        // (lane = token) everywhere except for a V^T destination, whose token-contiguous stores want lane = channel.
+        s.tr = true;
+        if constexpr (EPI == EPI_HEADS) s.tr = !(g.heads.kind[s.n0 / (g.heads.heads * 64)] & 1);
+        return true;
+    };
 
     // ---- LDS-DMA sources.  One instruction of one wave fills 8 LDS rows (1 KiB); round i of wave w covers rows 64 i + 8 w + (lane >> 3).
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((unsigned)M * (unsigned)K * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)n0 * K), 0, 256 * K * 2, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = rsA;
     int voffA[2], voffW[2][2];          // [round] (A: lo; hi = + 64 rows), [ni][round]
-    {
-        const int sub = lane >> 3, pos = lane & 7;
+    auto setup_dma = [&](const Seg& s) {
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)s.n0 * K), 0, 256 * K * 2, 0x00020000);
+        const int sub = lane_l >> 3, pos = lane_l & 7;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = i * 64 + wave * 8 + sub;                   // LDS row of the half-tile
             const int c = pos ^ ((r >> 1) & 7);
-            // A: LDS rows [0,64) belong to wave row 0, [64,128) to wave row 1
-            voffA[i] = (m0 + (r >> 6) * 128 + (r & 63)) * (K * 2) + c * 16;
+            // A: LDS rows [0,64) belong to wave row 0, [64,128) to wave row 1; rows beyond M are out of range of rsA: zeros
+            voffA[i] = (s.m0 + (r >> 6) * 128 + (r & 63)) * (K * 2) + c * 16;
             // W: LDS rows [32 w', 32 w' + 32) belong to wave column w'; row = 16 nf + fragment row
             const int wcol = r >> 5, nf = (r >> 4) & 1, fi = r & 15;
 #pragma unroll
@@ -116,16 +193,15 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, unsigned long
                 int ch;
                 if constexpr (EPI == EPI_F32) ch = chan_of<0>(ni, nf, fi);
                 else if constexpr (EPI == EPI_SWIGLU) ch = chan_of<1>(ni, nf, fi);
-                else ch = tr ? chan_of<2>(ni, nf, fi) : chan_of<0>(ni, nf, fi);
+                else ch = s.tr ? chan_of<2>(ni, nf, fi) : chan_of<0>(ni, nf, fi);
                 voffW[ni][i] = (wcol * 64 + ch) * (K * 2) + c * 16;
             }
         }
-    }
+    };
     const int hiA = 64 * K * 2;
     auto issue = [&](int kind, int buf, int kt) {          // kind: 0 W-lo, 1 A-lo, 2 W-hi, 3 A-hi (compile-time after inlining)
-        if constexpr (DBG == 1) return;
         char* dst = smem + buf * BUF_BYTES + kind * HALF_BYTES + wave * 1024;
-        const int soff = kt * 128;
+        const int soff = __builtin_amdgcn_readfirstlane(kt * 128);      // (stays scalar even if the K-tile counter was spilled to a VGPR lane)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (kind & 1)
@@ -136,21 +212,16 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, unsigned long
     };
 
     // ---- fragment addresses: row = (wave's first row of the half-tile) + 16 f + l15, chunk (4 ks + q4) ^ (l15 >> 1)
-    const int swz = l15 >> 1;
+    const int swz = l15_ >> 1;
     int offA[2], offW[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const int ch = ((ks * 4 + q4) ^ swz) << 4;
-        offA[ks] = (wr * 64 + l15) * 128 + ch;
-        offW[ks] = (wc * 32 + l15) * 128 + ch;
+        const int ch = ((ks * 4 + q4_) ^ swz) << 4;
+        offA[ks] = (wr * 64 + l15_) * 128 + ch;
+        offW[ks] = (wc * 32 + l15_) * 128 + ch;
     }
 
     f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
     bf16x8 fa[4][2], fwl[2][2], fwh[2][2];
     auto read_a = [&](int buf, int hi) {
         const char* base = smem + buf * BUF_BYTES + (hi ? 3 : 1) * HALF_BYTES;
@@ -167,14 +238,14 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, unsigned long
             for (int ks = 0; ks < 2; ++ks) fw[f][ks] = *reinterpret_cast<const bf16x8*>(base + offW[ks] + f * 2048);
     };
 
-    const int nk = K >> 6;             // launcher: even
-
-    // SWAP: W fragment as the MFMA A operand -> a 16 x 16 block holds C^T (lane = token l15, registers = channels 4 q4 + r)
-    auto main_loop = [&](auto swap_c) {
+    // SWAP: W fragment as the MFMA A operand -> a 16 x 16 block holds C^T (lane = token l15, registers = channels 4 q4 + r).
+    // K-tiles kt0 .. kt0 + nk - 1 (nk even); on entry half-tiles 0..6 of the range are in flight or landed and tile kt0 is visible.
+    // Quadrant mi of a wave is skipped when its 64 rows lie beyond M (M-tail tiles: the wave keeps staging and joining barriers).
+    auto main_loop = [&](auto swap_c, const int kt0, const int nk, const bool q_valid0, const bool q_valid1) {
         constexpr bool SWAP = decltype(swap_c)::value;
         auto mfma_quadrant = [&](int mi, int ni, bf16x8 (&fw)[2][2]) {
             if constexpr (DBG == 3) return;
-            if (!rows_valid) return;
+            if (!(mi ? q_valid1 : q_valid0)) return;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -187,10 +258,10 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, unsigned long
             __builtin_amdgcn_s_setprio(0);
         };
         // One K-tile = four phases.  BUF is the LDS buffer of tile t; tile t + 2 restages the same buffer.
-        // ISSUE: 4 = issue all four half-tiles (steady state), 1 = only phase 0's (tile nk - 2), 0 = none (tile nk - 1)
+        // ISSUE: 4 = issue all four half-tiles (steady state), 1 = only phase 0's (the range's tile nk - 2), 0 = none (tile nk - 1)
         auto k_tile = [&](auto buf_c, auto issue_c, auto wait_c, int t) {
             constexpr int BUF = decltype(buf_c)::value;
-            constexpr int ISSUE = decltype(issue_c)::value;
+            constexpr int ISSUE = (DBG == 1) ? 0 : decltype(issue_c)::value;
             constexpr int WAIT = decltype(wait_c)::value;          // vmcnt at phase 3: 6 steady, 0 for tile nk - 2, -1 none
             // ---- phase 0
             if constexpr (DBG != 2) {
@@ -243,285 +314,513 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, unsigned long
         using I4 = std::integral_constant<int, 4>;
         using I6 = std::integral_constant<int, 6>;
         using IM = std::integral_constant<int, -1>;
-        for (int t = 0; t < nk - 2; t += 2) {
+        if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger: wave row 1 runs one barrier behind wave row 0
+        const int kt_last = kt0 + nk - 2;
+        for (int t = kt0; t < kt_last; t += 2) {
             k_tile(I0{}, I4{}, I6{}, t);
             k_tile(I1{}, I4{}, I6{}, t + 1);
         }
-        k_tile(I0{}, I1{}, I0{}, nk - 2);
-        k_tile(I1{}, I0{}, IM{}, nk - 1);
+        k_tile(I0{}, I1{}, I0{}, kt_last);
+        k_tile(I1{}, I0{}, IM{}, kt_last + 1);
+        if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two wave rows: every wave is done with the ring
     };
 
-    // ---- prologue: half-tiles 0..6 in flight
+    // ---- LayerNorm fold, consumer side (GemmArgs): (mean, 1/std) of the tile's 256 rows from the producer's per-64-column partial
+    // sums and the tile's 256 (c1, c2) channel constants go to LDS behind the ring (two buffers: the next K-range's are written
+    // while the current epilogue still reads its own).  Without the fold the same epilogues run on (0, 1), 0, bias.
+    // The loads are ISSUED in front of the range's LDS-DMA prologue and consumed behind it: the vector-memory counter retires in
+    // order, so a load issued after the 14 DMA pieces could only be used once all of them have landed.
+    constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS);
+    constexpr int LN_BYTES = 4096;
+    const bool ln_fold = LN_CONS && g.ln_part != nullptr;
+    const int np = K >> 6;
+    const bool ln_fast = ln_fold && np == 24;             // 12 partial pairs per thread, held in registers across the DMA issue
+    // everything a K-range needs before its main loop: LayerNorm loads, DMA addresses, half-tiles 0..6 in flight, LayerNorm constants
+    auto prepare = [&](const Seg& s, int lb) {
+        int tid = tid_;
+        asm volatile("" : "+v"(tid));            // (keeps this block's address arithmetic inside the persistent loop, see the epilogue)
+        [[maybe_unused]] float2 lnp[12];         // local: nothing of this is live across the main loop
+        [[maybe_unused]] f32x4_t lncst = {0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] const int ct = 511 - tid;           // the last 128 threads bring in the channel constants, 16 bytes each
+        if constexpr (LN_CONS) {
+            if (ln_fast) {
+                int m = s.m0 + (tid >> 1);
+                m = m < M ? m : M - 1;
+                const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np + (tid & 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) issue(j, 0, 0);
+                for (int i = 0; i < 12; ++i) lnp[i] = pp[2 * i];
+            } else {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) issue(j, 1, 1);
-
-    // LayerNorm fold, consumer side (GemmArgs): (mean, 1/std) of the tile's 256 rows from the producer's per-64-column partial sums
-    // and the tile's 256 (c1, c2) channel constants, into LDS behind the ring while the first tiles are in flight; the K loop's
-    // barriers order these writes before the epilogue's reads.  Without the fold the same epilogue runs on (0, 1), 0, bias.
-    constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && (DBG == 0 || DBG == 9);
-    [[maybe_unused]] float2* lnst = reinterpret_cast<float2*>(smem + RING_BYTES);               // [256] (mean, rstd)
-    [[maybe_unused]] float* lnc = reinterpret_cast<float*>(smem + RING_BYTES + 2048);           // c1[256] then c2[256]
-    if constexpr (LN_CONS) {
-        const bool ln_fold = g.ln_part != nullptr;
-        const int np = K >> 6;
-        const int r = tid >> 1, sub = tid & 1;           // two threads per row
-        float sum = 0.f, sq = 0.f;
-        if (ln_fold) {
-            int m = m0 + r;
-            m = m < M ? m : M - 1;
-            const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np;
-#pragma unroll 6
-            for (int i = sub; i < np; i += 2) {
-                const float2 v = pp[i];
-                sum += v.x;
-                sq += v.y;
+                for (int i = 0; i < 12; ++i) lnp[i] = make_float2(0.f, 0.f);
+            }
+            if (ct < 128) {
+                const bool first = ct < 64;
+                const float* src = ln_fold ? (first ? g.ln_c1 + s.n0 + ct * 4 : g.ln_c2 + s.n0 + (ct - 64) * 4)
+                                           : ((first || !g.bias) ? nullptr : g.bias + s.n0 + (ct - 64) * 4);
+                if (src) lncst = *reinterpret_cast<const f32x4_t*>(src);
             }
         }
-        sum += dpp_move<0xB1>(sum);
-        sq += dpp_move<0xB1>(sq);
-        if (sub == 0) {
-            const float inv_k = 1.0f / (float)K;
-            const float mean = sum * inv_k;
-            const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
-            lnst[r] = ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, 1.f);
+        setup_dma(s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue(j, 0, s.kt0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) issue(j, 1, s.kt0 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LN_CONS) {
+            float2* lnst = reinterpret_cast<float2*>(smem + RING_BYTES + lb * LN_BYTES);
+            float* lnc = reinterpret_cast<float*>(smem + RING_BYTES + lb * LN_BYTES + 2048);
+            const int r = tid >> 1, sub = tid & 1;           // two threads per row
+            float sum = 0.f, sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                sum += lnp[i].x;
+                sq += lnp[i].y;
+            }
+            if (ln_fold && !ln_fast) {                       // any other K: plain loop (behind the DMA pieces in the memory queue)
+                int m = s.m0 + r;
+                m = m < M ? m : M - 1;
+                const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np;
+                for (int i = sub; i < np; i += 2) {
+                    const float2 v = pp[i];
+                    sum += v.x;
+                    sq += v.y;
+                }
+            }
+            sum += dpp_move<0xB1>(sum);
+            sq += dpp_move<0xB1>(sq);
+            if (sub == 0) {
+                const float inv_k = 1.0f / (float)K;
+                const float mean = sum * inv_k;
+                const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
+                lnst[r] = ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, 1.f);
+            }
+            if (ct < 128) *reinterpret_cast<f32x4_t*>(lnc + ct * 4) = lncst;
         }
-        const int ct = 511 - tid;           // the last 128 threads bring in the channel constants, 16 bytes each
-        if (ct < 128) {
-            const bool first = ct < 64;
-            const float* src = ln_fold ? (first ? g.ln_c1 + n0 + ct * 4 : g.ln_c2 + n0 + (ct - 64) * 4)
-                                       : ((first || !g.bias) ? nullptr : g.bias + n0 + (ct - 64) * 4);
-            *reinterpret_cast<f32x4_t*>(lnc + ct * 4) = src ? *reinterpret_cast<const f32x4_t*>(src) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-
-    if constexpr (DBG == 2) {       // ablation: fragments are read once
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        read_w(0, 0, fwl);
-        read_w(0, 1, fwh);
-        read_a(0, 0);
-    }
-    // tile 0 has landed.  (With the fold the plain loads above were consumed already, so they are not part of the count.)
-    wait_vmcnt<6>();
-    __builtin_amdgcn_s_barrier();
-    if constexpr (DBG == 9) t_pro = __builtin_amdgcn_s_memrealtime();
-    if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger: wave row 1 runs one barrier behind wave row 0
-    if constexpr (EPI == EPI_HEADS) {
-        if (tr) main_loop(std::true_type{});
-        else main_loop(std::false_type{});
-    } else {
-        main_loop(std::true_type{});
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two wave rows
-    if constexpr (DBG == 9) t_main = __builtin_amdgcn_s_memrealtime();
-    if (!rows_valid) return;
+    };
 
     // ---- epilogues.  Transposed: lane (l15, q4) holds, for block (mb = 0..7, nb = 2 ni + nf): token row m0 + wr*128 + mb*16 + l15,
     //      channels n0 + wc*64 + chan_of(ni, nf, 4 q4 + r), r = 0..3
-    const int mrow0 = m0 + wr * 128 + l15;
-    const int ncol0 = n0 + wc * 64;
-    [[maybe_unused]] const float2* ln = lnst + wr * 128;
-    [[maybe_unused]] const float* lc1 = lnc + wc * 64;
-    [[maybe_unused]] const float* lc2 = lnc + 256 + wc * 64;
-    if constexpr (EPI == EPI_F32) {
-        // fp32 output / residual update (transformer.py:692-700), adaLN gate (:674, 688); LayerNorm fold, producer side: bf16 image of
-        // the updated rows + (sum, sum of squares) of the ROUNDED values over this wave's 64-column block
-        const bool accum = g.accumulate != 0;
-        const bool prod = g.xb != nullptr;
-        f32x4_t bia[4];
+    auto epilogue = [&](const Seg& s, int lb) {
+        // (laundered copies: keeps the segment-invariant address arithmetic of the epilogue from being hoisted out of the persistent
+        // loop, where it would stay live across the main loop and push its 128 + 64 registers into scratch)
+        int l15 = l15_, q4 = q4_;
+        asm volatile("" : "+v"(l15), "+v"(q4));
+        const int mrow0 = s.m0 + wr * 128 + l15;
+        const int ncol0 = s.n0 + wc * 64;
+        [[maybe_unused]] const float2* ln = reinterpret_cast<const float2*>(smem + RING_BYTES + lb * LN_BYTES) + wr * 128;
+        [[maybe_unused]] const float* lc1 = reinterpret_cast<const float*>(smem + RING_BYTES + lb * LN_BYTES + 2048) + wc * 64;
+        [[maybe_unused]] const float* lc2 = lc1 + 256;
+        if constexpr (EPI == EPI_F32) {
+            // fp32 output / residual update (transformer.py:692-700), adaLN gate (:674, 688); LayerNorm fold, producer side: bf16 image
+            // of the updated rows + (sum, sum of squares) of the ROUNDED values over this wave's 64-column block
+            const bool accum = g.accumulate != 0;
+            const bool prod = g.xb != nullptr;
+            f32x4_t bia[4];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-            bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-            const int m = mrow0 + mb * 16;
-            const int mc = m < M ? m : M - 1;
-            float* __restrict__ crow = g.C + (size_t)mc * g.ldc + ncol0 + 4 * q4;
-            const float* grow = g.gate ? g.gate + (size_t)(mc / g.gate_rows) * g.gate_ld + ncol0 + 4 * q4 : nullptr;
-            f32x4_t old[4];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) old[nb] = accum ? *reinterpret_cast<const f32x4_t*>(crow + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            float sum = 0.f, sq = 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                f32x4_t v = acc[mb][nb] + bia[nb];
-                if (grow) v *= *reinterpret_cast<const f32x4_t*>(grow + nb * 16);
-                v += old[nb];
-                if (m < M) *reinterpret_cast<f32x4_t*>(crow + nb * 16) = v;
-                if (prod) {
-                    bf16x4 xr;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        xr[e] = f32_to_bf16(v[e]);
-                        const float f = bf16_to_f32(xr[e]);
-                        sum += f;
-                        sq += f * f;
-                    }
-                    if (m < M) *reinterpret_cast<bf16x4*>(g.xb + (size_t)m * N + ncol0 + 4 * q4 + nb * 16) = xr;
-                }
-            }
-            if (prod) {       // add the four lanes (q4 = 0..3) that share the token row
-                sum += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sum), 0x401F));       // lane ^ 16
-                sq += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sq), 0x401F));
-                u32x2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-                u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
-                sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-                sq = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-                if (q4 == 0 && m < M)
-                    *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (N >> 6) + (ncol0 >> 6)) * 2) = make_float2(sum, sq);
-            }
-        }
-    } else if constexpr (EPI == EPI_SWIGLU) {
-        // H = (v + b_v) * silu(gate + b_g) (transformer.py:232-235): value rows are channels [0, 32) of the wave's 64, gate rows
-        // [32, 64) (pack_rows interleave); PERM 1 puts value and gate of hidden columns hc0 + 8 q4 + 4 nf + r into this lane
-        const int ldh = N >> 1;
-        f32x4_t c1v[2], c1g[2], c2v[2], c2g[2];
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-            c1v[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + q4 * 8 + nf * 4);
-            c1g[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + 32 + q4 * 8 + nf * 4);
-            c2v[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + q4 * 8 + nf * 4);
-            c2g[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + 32 + q4 * 8 + nf * 4);
-        }
-        bf16_t* __restrict__ hbase = g.H + (ncol0 >> 1) + q4 * 8;
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-            const int m = mrow0 + mb * 16;
-            const float2 st = ln[mb * 16 + l15];
-            unsigned pk[4];
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                float hv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = st.y * (acc[mb][nf][e] - st.x * c1v[nf][e]) + c2v[nf][e];
-                    const float gt = st.y * (acc[mb][2 + nf][e] - st.x * c1g[nf][e]) + c2g[nf][e];
-                    hv[e] = v * silu_f(gt);
-                }
-                pk[2 * nf] = pack_bf16x2(hv[0], hv[1]);
-                pk[2 * nf + 1] = pack_bf16x2(hv[2], hv[3]);
-            }
-            if (m < M) *reinterpret_cast<u32x4*>(hbase + (size_t)m * ldh) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-        }
-    } else {   // EPI_HEADS: split into heads, LayerNorm fold, partial RoPE on d < 32 (transformer.py:158-183, 438-452)
-        const HeadsEpi& he = g.heads;
-        const int hp = he.heads * 64;
-        const int part = ncol0 / hp;
-        const int head = (ncol0 - part * hp) >> 6;
-        const int kind = he.kind[part];
-        bf16_t* __restrict__ dst = he.out[part];
-        const int S = he.S, Spad = he.Spad;
-        if (tr) {
-            // q / k, row-major [B, H, Spad, 64].  PERM 2: block ni = 0 holds d = 16 nf + 4 q4 + r (the rotation partner d + 16 is block
-            // nf + 1 of the same lane), block ni = 1 holds d = 32 + 8 q4 + 4 nf + r (8 consecutive channels)
-            f32x4_t c1[4], c2[4];
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                c1[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + nf * 16 + 4 * q4);
-                c2[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + nf * 16 + 4 * q4);
-                c1[2 + nf] = *reinterpret_cast<const f32x4_t*>(lc1 + 32 + q4 * 8 + nf * 4);
-                c2[2 + nf] = *reinterpret_cast<const f32x4_t*>(lc2 + 32 + q4 * 8 + nf * 4);
-            }
+            for (int nb = 0; nb < 4; ++nb)
+                bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
                 const int m = mrow0 + mb * 16;
                 const int mc = m < M ? m : M - 1;
-                const int b = mc / S;
-                const int sq_ = mc - b * S;
-                const int ob = (kind & 4) ? ((b * S) & 3) : 0;
-                const float2 st = ln[mb * 16 + l15];
-                f32x4_t x[4];
+                float* __restrict__ crow = g.C + (size_t)mc * g.ldc + ncol0 + 4 * q4;
+                const float* grow = g.gate ? g.gate + (size_t)(mc / g.gate_rows) * g.gate_ld + ncol0 + 4 * q4 : nullptr;
+                f32x4_t old[4];
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) x[nb][e] = st.y * (acc[mb][nb][e] - st.x * c1[nb][e]) + c2[nb][e];
-                if (kind & 2) {
-                    const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(he.rope_cos + (size_t)sq_ * 16 + 4 * q4);
-                    const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(he.rope_sin + (size_t)sq_ * 16 + 4 * q4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x1 = x[0][e], x2 = x[1][e];
-                        x[0][e] = x1 * cs[e] - x2 * sn[e];
-                        x[1][e] = x2 * cs[e] + x1 * sn[e];
-                    }
-                }
-                if (m < M) {
-                    bf16_t* row = dst + ((size_t)(b * he.heads + head) * Spad + sq_ + ob) * 64;
-                    *reinterpret_cast<u32x2*>(row + 4 * q4) = u32x2{pack_bf16x2(x[0][0], x[0][1]), pack_bf16x2(x[0][2], x[0][3])};
-                    *reinterpret_cast<u32x2*>(row + 16 + 4 * q4) = u32x2{pack_bf16x2(x[1][0], x[1][1]), pack_bf16x2(x[1][2], x[1][3])};
-                    *reinterpret_cast<u32x4*>(row + 32 + 8 * q4) = u32x4{pack_bf16x2(x[2][0], x[2][1]), pack_bf16x2(x[2][2], x[2][3]),
-                                                                         pack_bf16x2(x[3][0], x[3][1]), pack_bf16x2(x[3][2], x[3][3])};
-                }
-            }
-        } else {
-            // V^T [B, H, 64, Spad] (no rotation): un-swapped accumulators, lane = channel d = 16 nb + l15, registers = the four consecutive
-            // token rows mb*16 + 4 q4 + e.  Columns of sequence b are shifted by (b S) & 3 (kind bit 2) so that those four tokens are
-            // an 8-byte aligned group of vt_pos order (see gemm_bf16.hip / sat_common.h vt_pos)
-            const bool shift = (kind & 4) != 0;
-            float c1[4], c2[4];
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                c1[nb] = lc1[nb * 16 + l15];
-                c2[nb] = lc2[nb * 16 + l15];
-            }
-#pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
-                const int mbase = m0 + wr * 128 + mb * 16 + 4 * q4;          // multiple of 4
-                const f32x4_t* sp = reinterpret_cast<const f32x4_t*>(ln + mb * 16 + 4 * q4);
-                const f32x4_t st01 = sp[0], st23 = sp[1];                    // (mean, rstd) of rows e = 0, 1 / 2, 3
-                int bb[4], ss[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int mm = mbase + e;
-                    mm = mm < M ? mm : M - 1;
-                    bb[e] = mm / S;
-                    ss[e] = mm - bb[e] * S;
-                }
-                const bool whole = mbase + 3 < M && bb[0] == bb[3];
-                const int ob0 = shift ? ((bb[0] * S) & 3) : 0;
-                const size_t hb0 = ((size_t)(bb[0] * he.heads + head) * 64) * Spad;
+                for (int nb = 0; nb < 4; ++nb) old[nb] = accum ? *reinterpret_cast<const f32x4_t*>(crow + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                float sum = 0.f, sq = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    float v[4];
+                    f32x4_t v = acc[mb][nb] + bia[nb];
+                    if (grow) v *= *reinterpret_cast<const f32x4_t*>(grow + nb * 16);
+                    v += old[nb];
+                    if (m < M) *reinterpret_cast<f32x4_t*>(crow + nb * 16) = v;
+                    if (prod) {
+                        bf16x4 xr;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            xr[e] = f32_to_bf16(v[e]);
+                            const float f = bf16_to_f32(xr[e]);
+                            sum += f;
+                            sq += f * f;
+                        }
+                        if (m < M) *reinterpret_cast<bf16x4*>(g.xb + (size_t)m * N + ncol0 + 4 * q4 + nb * 16) = xr;
+                    }
+                }
+                if (prod) {       // add the four lanes (q4 = 0..3) that share the token row
+                    sum += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sum), 0x401F));       // lane ^ 16
+                    sq += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sq), 0x401F));
+                    u32x2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+                    u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+                    sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+                    sq = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+                    if (q4 == 0 && m < M)
+                        *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (N >> 6) + (ncol0 >> 6)) * 2) = make_float2(sum, sq);
+                }
+            }
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            // H = (v + b_v) * silu(gate + b_g) (transformer.py:232-235): value rows are channels [0, 32) of the wave's 64, gate rows
+            // [32, 64) (pack_rows interleave); PERM 1 puts value and gate of hidden columns hc0 + 8 q4 + 4 nf + r into this lane
+            const int ldh = N >> 1;
+            f32x4_t c1v[2], c1g[2], c2v[2], c2g[2];
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                c1v[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + q4 * 8 + nf * 4);
+                c1g[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + 32 + q4 * 8 + nf * 4);
+                c2v[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + q4 * 8 + nf * 4);
+                c2g[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + 32 + q4 * 8 + nf * 4);
+            }
+            bf16_t* __restrict__ hbase = g.H + (ncol0 >> 1) + q4 * 8;
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                const int m = mrow0 + mb * 16;
+                const float2 st = ln[mb * 16 + l15];
+                unsigned pk[4];
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) {
+                    float hv[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float mean = e < 2 ? st01[2 * e] : st23[2 * e - 4];
-                        const float rstd = e < 2 ? st01[2 * e + 1] : st23[2 * e - 3];
-                        v[e] = rstd * (acc[mb][nb][e] - mean * c1[nb]) + c2[nb];
+                        const float v = st.y * (acc[mb][nf][e] - st.x * c1v[nf][e]) + c2v[nf][e];
+                        const float gt = st.y * (acc[mb][2 + nf][e] - st.x * c1g[nf][e]) + c2g[nf][e];
+                        hv[e] = v * silu_fast(gt);
                     }
-                    const size_t drow = (size_t)(nb * 16 + l15) * Spad;
-                    if (whole && shift) {         // aligned: (ss[0] + ob) % 4 == mbase % 4 == 0
-                        *reinterpret_cast<u32x2*>(dst + hb0 + vt_pos(ss[0] + ob0) + drow) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    } else {
+                    pk[2 * nf] = pack_bf16x2(hv[0], hv[1]);
+                    pk[2 * nf + 1] = pack_bf16x2(hv[2], hv[3]);
+                }
+                if (m < M) *reinterpret_cast<u32x4*>(hbase + (size_t)m * ldh) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            }
+        } else {   // EPI_HEADS: split into heads, LayerNorm fold, partial RoPE on d < 32 (transformer.py:158-183, 438-452)
+            const HeadsEpi& he = g.heads;
+            const int hp = he.heads * 64;
+            const int part = ncol0 / hp;
+            const int head = (ncol0 - part * hp) >> 6;
+            const int kind = he.kind[part];
+            bf16_t* __restrict__ dst = he.out[part];
+            const int S = he.S, Spad = he.Spad;
+            if (s.tr) {
+                // q / k, row-major [B, H, Spad, 64].  PERM 2: block ni = 0 holds d = 16 nf + 4 q4 + r (the rotation partner d + 16 is
+                // block nf + 1 of the same lane), block ni = 1 holds d = 32 + 8 q4 + 4 nf + r (8 consecutive channels)
+                f32x4_t c1[4], c2[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (mbase + e < M) {
-                                const int ob = shift ? ((bb[e] * S) & 3) : 0;
-                                dst[((size_t)(bb[e] * he.heads + head) * 64) * Spad + vt_pos(ss[e] + ob) + drow] = f32_to_bf16(v[e]);
-                            }
+                for (int nf = 0; nf < 2; ++nf) {
+                    c1[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + nf * 16 + 4 * q4);
+                    c2[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + nf * 16 + 4 * q4);
+                    c1[2 + nf] = *reinterpret_cast<const f32x4_t*>(lc1 + 32 + q4 * 8 + nf * 4);
+                    c2[2 + nf] = *reinterpret_cast<const f32x4_t*>(lc2 + 32 + q4 * 8 + nf * 4);
+                }
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    const int m = mrow0 + mb * 16;
+                    const int mc = m < M ? m : M - 1;
+                    const int b = mc / S;
+                    const int sq_ = mc - b * S;
+                    const int ob = (kind & 4) ? ((b * S) & 3) : 0;
+                    const float2 st = ln[mb * 16 + l15];
+                    f32x4_t x[4];
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[nb][e] = st.y * (acc[mb][nb][e] - st.x * c1[nb][e]) + c2[nb][e];
+                    if (kind & 2) {
+                        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(he.rope_cos + (size_t)sq_ * 16 + 4 * q4);
+                        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(he.rope_sin + (size_t)sq_ * 16 + 4 * q4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x1 = x[0][e], x2 = x[1][e];
+                            x[0][e] = x1 * cs[e] - x2 * sn[e];
+                            x[1][e] = x2 * cs[e] + x1 * sn[e];
+                        }
+                    }
+                    if (m < M) {
+                        bf16_t* row = dst + ((size_t)(b * he.heads + head) * Spad + sq_ + ob) * 64;
+                        *reinterpret_cast<u32x2*>(row + 4 * q4) = u32x2{pack_bf16x2(x[0][0], x[0][1]), pack_bf16x2(x[0][2], x[0][3])};
+                        *reinterpret_cast<u32x2*>(row + 16 + 4 * q4) = u32x2{pack_bf16x2(x[1][0], x[1][1]), pack_bf16x2(x[1][2], x[1][3])};
+                        *reinterpret_cast<u32x4*>(row + 32 + 8 * q4) = u32x4{pack_bf16x2(x[2][0], x[2][1]), pack_bf16x2(x[2][2], x[2][3]),
+                                                                             pack_bf16x2(x[3][0], x[3][1]), pack_bf16x2(x[3][2], x[3][3])};
+                    }
+                }
+            } else {
+                // V^T [B, H, 64, Spad] (no rotation): un-swapped accumulators, lane = channel d = 16 nb + l15, registers = the four
+                // consecutive token rows mb*16 + 4 q4 + e.  Columns of sequence b are shifted by (b S) & 3 (kind bit 2) so that those
+                // four tokens are an 8-byte aligned group of vt_pos order (sat_common.h)
+                const bool shift = (kind & 4) != 0;
+                float c1[4], c2[4];
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    c1[nb] = lc1[nb * 16 + l15];
+                    c2[nb] = lc2[nb * 16 + l15];
+                }
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb) {
+                    const int mbase = s.m0 + wr * 128 + mb * 16 + 4 * q4;          // multiple of 4
+                    const f32x4_t* sp = reinterpret_cast<const f32x4_t*>(ln + mb * 16 + 4 * q4);
+                    const f32x4_t st01 = sp[0], st23 = sp[1];                    // (mean, rstd) of rows e = 0, 1 / 2, 3
+                    int bb[4], ss[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int mm = mbase + e;
+                        mm = mm < M ? mm : M - 1;
+                        bb[e] = mm / S;
+                        ss[e] = mm - bb[e] * S;
+                    }
+                    const bool whole4 = mbase + 3 < M && bb[0] == bb[3];
+                    const int ob0 = shift ? ((bb[0] * S) & 3) : 0;
+                    const size_t hb0 = ((size_t)(bb[0] * he.heads + head) * 64) * Spad;
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float mean = e < 2 ? st01[2 * e] : st23[2 * e - 4];
+                            const float rstd = e < 2 ? st01[2 * e + 1] : st23[2 * e - 3];
+                            v[e] = rstd * (acc[mb][nb][e] - mean * c1[nb]) + c2[nb];
+                        }
+                        const size_t drow = (size_t)(nb * 16 + l15) * Spad;
+                        if (whole4 && shift) {         // aligned: (ss[0] + ob) % 4 == mbase % 4 == 0
+                            *reinterpret_cast<u32x2*>(dst + hb0 + vt_pos(ss[0] + ob0) + drow) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (mbase + e < M) {
+                                    const int ob = shift ? ((bb[e] * S) & 3) : 0;
+                                    dst[((size_t)(bb[e] * he.heads + head) * 64) * Spad + vt_pos(ss[e] + ob) + drow] = f32_to_bf16(v[e]);
+                                }
+                        }
                     }
                 }
             }
         }
-    }
-    if constexpr (DBG == 9) {
+    };
+
+    // ---- stream-K fix-up of a partial K-range.  Returns true when this workgroup is the last arriver: `acc` then holds the whole sum.
+    // Inter-workgroup visibility without cache-wide fences (an agent-scope release / acquire writes back and invalidates a whole
+    // XCD's L2 under every other workgroup's feet: measured 2x slower kernels): slabs are written with sc1 (write-through) stores
+    // and read with sc1 loads, the ticket is a relaxed agent-scope atomic issued after every wave's stores have been acknowledged.
+    unsigned* misc = reinterpret_cast<unsigned*>(smem + RING_BYTES + 2 * LN_BYTES);
+    auto fixup = [&](const Seg& s) -> bool {
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)sc.sk_slab, 0, sc.G * 2 * 262144, 0x00020000);
+        auto slab_off = [&](int w, int slot) { return (w * 2 + slot) * 262144 + wave * 32768 + lane_l * 16; };       // bytes
+        const int parts = sc.sk_parts[s.skj];
+        const int first = sc.sk_first[s.skj];
+        const int mine = slab_off(wgi, s.slot);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[mb][nb]), rsS, mine + (mb * 4 + nb) * 1024, 0, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) {
-            unsigned hw;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* o = ts + (size_t)blockIdx.x * 6;
-            o[0] = t_start; o[1] = t_pro; o[2] = t_main; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = hw; o[5] = xcc;
+        __syncthreads();
+        if (tid_ == 0) misc[0] = __hip_atomic_fetch_add(sc.sk_count + s.skj, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = misc[0];
+        if ((int)ticket != parts - 1) return false;
+        if (tid_ == 0) __hip_atomic_store(sc.sk_count + s.skj, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // every ticket of this launch is drawn
+        const int tile_u0 = s.skj * sc.nkp;
+        // (two batches of 16 pieces with a scheduling fence between them: the whole image at once would need 128 registers on top of
+        // the 128 accumulators, and the allocator would answer by spilling accumulators -- inside the main loop as well)
+        auto add_slab = [&](int off) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4_t t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rsS, off + (h * 16 + i) * 1024, 0, 16);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[h * 4 + (i >> 2)][i & 3] += __builtin_bit_cast(f32x4_t, t[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // Two contributors: own registers + the other slab (fp32 addition commutes: the same bits whoever is last).  More: all slabs in
+        // ascending workgroup order, own included, on zeroed registers.  ONE code path for both (the registers are scaled by 1 or 0):
+        // two paths that redefine the 128 accumulators differently cost 100+ spilled registers, inside the main loop as well.
+        const bool two = parts == 2;
+        const float keep = two ? 1.0f : 0.0f;
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] *= keep;
+        int seen = 0;
+        for (int w = first; seen < parts; ++w) {
+            const int wb = sc.sk_begin[w];
+            if (sc.sk_begin[w + 1] <= wb) continue;          // a workgroup whose share of the (cost-weighted) unit space is empty
+            ++seen;
+            if (two && w == wgi) continue;
+            add_slab(slab_off(w, wb >= tile_u0 ? 0 : 1));
         }
+        return true;
+    };
+
+    // ---- the persistent loop
+    Seg cur, nxt;
+    if (!next_seg(cur)) return;
+    int lb = 0;
+    prepare(cur, lb);
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // the range's first tiles have landed (and the previous epilogue's stores are out); LayerNorm constants are visible
+        wait_vmcnt<0>();
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (DBG == 2) {       // ablation: fragments are read once
+            read_w(0, 0, fwl);
+            read_w(0, 1, fwh);
+            read_a(0, 0);
+        }
+        [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if constexpr (DBG == 9) t0 = __builtin_amdgcn_s_memrealtime();
+        const int mq = cur.m0 + wr * 128;
+        const bool rows_valid = mq < M;
+        if (cur.tr) main_loop(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+        else main_loop(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+        if constexpr (DBG == 9) t1 = __builtin_amdgcn_s_memrealtime();
+        const bool more = next_seg(nxt);
+        if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
+        bool fin = true;
+        if (!cur.whole) fin = fixup(cur);
+        if constexpr (DBG == 9) t2 = __builtin_amdgcn_s_memrealtime();
+        if (fin && rows_valid) epilogue(cur, lb);
+        if constexpr (DBG == 9) {
+            if (tid_ == 0 && ts_n < 4) {
+                unsigned long long* o = ts + ((size_t)blockIdx.x * 4 + ts_n) * 8;
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = __builtin_amdgcn_s_memrealtime();
+                o[4] = cur.whole; o[5] = cur.nk; o[6] = fin; o[7] = 1;
+            }
+            ++ts_n;
+        }
+        if (!more) break;
+        cur = nxt;
+        lb ^= 1;
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host side: the persistent schedule of a shape (cached per device and shape)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct DevState {
+    int cus = 0;
+    float* slab = nullptr;
+    size_t slab_wgs = 0;
+    std::map<std::tuple<int, int, int, int>, Ph8Sched> shapes;
+};
+std::mutex g_sched_mu;
+std::map<int, DevState> g_dev;
+
+// split: 0 = the remainder round's tiles stay whole (one per workgroup, light tiles last), 1 = the remainder round is split along K,
+// -1 = the measured policy (profiles/r03_ph8_streamk.txt): split only long reductions behind at least one whole round -- FF-out from
+// 4 prompts on (-5 %), SA-2.0 (-15 %); at K = 1536 the fix-up (two 256-KiB slab transfers at HBM speed, every workgroup at the same
+// time) costs more than the half round it saves, and below one whole round the 128x128 tiles of gemm_bf16.hip are faster
+int ph8_schedule(const GemmArgs& a, int split, Ph8Sched& out) {
+    int dev = 0;
+    SAT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_sched_mu);
+    DevState& d = g_dev[dev];
+    if (!d.cus) SAT_HIP(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (split < 0) split = (a.K >= 4096 && (long)cdiv(a.M, 256) * (a.N / 256) > d.cus) ? 1 : 0;
+    auto key = std::make_tuple(a.M, a.N, a.K, split);
+    auto it = d.shapes.find(key);
+    if (it != d.shapes.end()) {
+        out = it->second;
+        out.sk_slab = d.slab;
+        return 0;
+    }
+    Ph8Sched s{};
+    const int tiles_m = cdiv(a.M, 256), tail = a.M % 256;
+    s.tiles_n = a.N / 256;
+    s.light = (tail != 0 && tail <= 64 && tiles_m > 1) ? 1 : 0;
+    s.tiles_m_full = tiles_m - s.light;
+    s.nkp = a.K / 128;
+    const long t_full = (long)s.tiles_m_full * s.tiles_n, t_light = s.light ? s.tiles_n : 0;
+    const long units_all = (t_full + t_light) * s.nkp;
+    s.G = (int)std::min<long>(d.cus, split ? units_all : t_full + t_light);
+    const long t_all = t_full + t_light;
+    s.dp_rounds = (int)((split ? t_all : t_full) / s.G);
+    // K-split with at least one whole round: the light tiles go FIRST (they idle their workgroup for half of round 0 -- a handful of
+    // them) so that the remainder round holds full tiles only and splits evenly
+    s.light_first = (split && s.dp_rounds >= 1 && t_light) ? 1 : 0;
+    const int rem0 = (int)((long)s.dp_rounds * s.G);          // first work-order position of the remainder
+    s.sk_tiles = (int)(t_all - rem0);
+    if (s.sk_tiles) {
+        // The remainder space, tile by tile, and who works on it.
+        //   split == 0: whole tiles, contiguous shares (the first sk_tiles % G workgroups take one more); light tiles are last.
+        //   split == 1: every tile is cut along K into equal parts, one workgroup per part (so a workgroup has ONE K-range and at
+        //     most one fix-up); parts in proportion to cost (a light tile counts half).
+        std::vector<int> tile, begin(s.G + 1, 0), first, parts;
+        std::vector<int> share;          // units of each workgroup, in order
+        auto is_light = [&](int pos) { return s.light_first ? pos < t_light : pos >= t_full; };
+        for (int j = 0; j < s.sk_tiles; ++j) tile.push_back(rem0 + j);
+        if (!split) {
+            const long q = s.sk_tiles / s.G, r = s.sk_tiles % s.G;
+            for (int i = 0; i < s.G; ++i) share.push_back((int)((q + (i < r ? 1 : 0)) * s.nkp));
+        } else {
+            long cost2 = 0;              // in halves of a full tile
+            for (int j = 0; j < s.sk_tiles; ++j) cost2 += is_light(tile[j]) ? 1 : 2;
+            std::vector<int> pj(s.sk_tiles);
+            long used = 0;
+            for (int j = 0; j < s.sk_tiles; ++j) {
+                const long c2 = is_light(tile[j]) ? 1 : 2;
+                pj[j] = (int)std::max<long>(1, std::min<long>(s.nkp, (long)s.G * c2 / cost2));
+                used += pj[j];
+            }
+            for (int j = 0; j < s.sk_tiles && used < s.G; ++j)          // leftover workgroups: one more part for the first full tiles
+                if (!is_light(tile[j]) && pj[j] < s.nkp) { ++pj[j]; ++used; }
+            for (int j = 0; j < s.sk_tiles; ++j)
+                for (int k = 0; k < pj[j]; ++k) share.push_back((int)((long)s.nkp * (k + 1) / pj[j] - (long)s.nkp * k / pj[j]));
+        }
+        SAT_CHECK_ARG((int)share.size() <= s.G, SAT_E_INVALID, "gemm(8-phase): schedule needs %d workgroups, has %d", (int)share.size(), s.G);
+        for (int i = 0; i < s.G; ++i) begin[i + 1] = begin[i] + (i < (int)share.size() ? share[i] : 0);
+        SAT_CHECK_ARG(begin[s.G] == s.sk_tiles * s.nkp, SAT_E_INVALID, "gemm(8-phase): schedule covers %d of %d units", begin[s.G], s.sk_tiles * s.nkp);
+        first.assign(s.sk_tiles, 0);
+        parts.assign(s.sk_tiles, 0);
+        for (int i = 0; i < s.G; ++i) {
+            if (begin[i + 1] <= begin[i]) continue;
+            for (int j = begin[i] / s.nkp; j <= (begin[i + 1] - 1) / s.nkp; ++j) {
+                if (!parts[j]) first[j] = i;
+                parts[j]++;
+            }
+        }
+        bool any_split = false;
+        for (int j = 0; j < s.sk_tiles; ++j) any_split = any_split || parts[j] > 1;
+        int *dt, *db, *df, *dp;
+        unsigned* dc;
+        SAT_HIP(hipMalloc(&dt, s.sk_tiles * sizeof(int)));
+        SAT_HIP(hipMalloc(&db, (s.G + 1) * sizeof(int)));
+        SAT_HIP(hipMalloc(&df, s.sk_tiles * sizeof(int)));
+        SAT_HIP(hipMalloc(&dp, s.sk_tiles * sizeof(int)));
+        SAT_HIP(hipMalloc(&dc, s.sk_tiles * sizeof(unsigned)));
+        SAT_HIP(hipMemcpy(dt, tile.data(), s.sk_tiles * sizeof(int), hipMemcpyHostToDevice));
+        SAT_HIP(hipMemcpy(db, begin.data(), (s.G + 1) * sizeof(int), hipMemcpyHostToDevice));
+        SAT_HIP(hipMemcpy(df, first.data(), s.sk_tiles * sizeof(int), hipMemcpyHostToDevice));
+        SAT_HIP(hipMemcpy(dp, parts.data(), s.sk_tiles * sizeof(int), hipMemcpyHostToDevice));
+        SAT_HIP(hipMemset(dc, 0, s.sk_tiles * sizeof(unsigned)));
+        s.sk_tile = dt; s.sk_begin = db; s.sk_first = df; s.sk_parts = dp; s.sk_count = dc;
+        if (any_split && d.slab_wgs < (size_t)s.G) {
+            // one slab pair per workgroup, shared by every shape on this device: launches on ONE stream only (the plans' use)
+            SAT_HIP(hipDeviceSynchronize());
+            if (d.slab) SAT_HIP(hipFree(d.slab));
+            SAT_HIP(hipMalloc(&d.slab, (size_t)s.G * 2 * 65536 * sizeof(float)));
+            d.slab_wgs = s.G;
+        }
+    }
+    d.shapes[key] = s;
+    out = s;
+    out.sk_slab = d.slab;
+    return 0;
+}
+
+#ifdef SAT_GEMM_EXPERIMENTS
+unsigned long long* g_ts_buf = nullptr;
+#endif
+
 template <int EPI, int DBG = 0>
 int launch_ph8(const GemmArgs& a, hipStream_t stream) {
-    constexpr int LDS = 131072 + 4096;          // ring + (mean, rstd) per row + (c1, c2) per column
+    constexpr int LDS = 131072 + 2 * 4096 + 64;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column) + ticket
     SAT_CHECK_ARG(a.N % 256 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of 256", a.N);
     SAT_CHECK_ARG(a.K % 128 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): K=%d must be a multiple of 128", a.K);
     SAT_CHECK_ARG((uint64_t)a.M * (uint64_t)a.K * 2u < (1ull << 31), SAT_E_UNSUPPORTED, "gemm(8-phase): A larger than 2 GiB");
@@ -536,18 +835,20 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
         for (int p = 0; p < a.heads.parts; ++p)
             SAT_CHECK_ARG((a.heads.kind[p] & 3) != 3, SAT_E_UNSUPPORTED, "gemm(8-phase): no rotation on a transposed destination");
     }
+    Ph8Sched sc;
+    // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements)
+    SAT_TRY(ph8_schedule(a, (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1, sc));
     auto kern = gemm_ph8_kernel<EPI, DBG>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
-    const int tiles = cdiv(a.M, 256) * (a.N / 256);
     unsigned long long* ts = nullptr;
 #ifdef SAT_GEMM_EXPERIMENTS
     if constexpr (DBG == 9) {
-        if (!g_ts_buf) SAT_HIP(hipMalloc(&g_ts_buf, 8192 * 6 * sizeof(unsigned long long)));
-        SAT_CHECK_ARG(tiles <= 8192, SAT_E_UNSUPPORTED, "timestamp buffer holds 8192 workgroups");
+        if (!g_ts_buf) SAT_HIP(hipMalloc(&g_ts_buf, 256 * 4 * 8 * sizeof(unsigned long long)));
+        SAT_HIP(hipMemsetAsync(g_ts_buf, 0, 256 * 4 * 8 * sizeof(unsigned long long), stream));
         ts = g_ts_buf;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS, stream, a, ts);
+    hipLaunchKernelGGL(kern, dim3(sc.G), dim3(512), LDS, stream, a, sc, ts);
     SAT_LAUNCH_CHECK();
     return 0;
 }
@@ -561,10 +862,10 @@ bool sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
 }
 
 #ifdef SAT_GEMM_EXPERIMENTS
-extern "C" int sat_gemm_ph8_timestamps(unsigned long long* out_host, int n_wg) {
-    SAT_CHECK_ARG(g_ts_buf && n_wg <= 8192, SAT_E_INVALID, "no timestamps recorded");
+extern "C" int sat_gemm_ph8_timestamps(unsigned long long* out_host) {
+    SAT_CHECK_ARG(g_ts_buf, SAT_E_INVALID, "no timestamps recorded");
     SAT_HIP(hipDeviceSynchronize());
-    SAT_HIP(hipMemcpy(out_host, g_ts_buf, (size_t)n_wg * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    SAT_HIP(hipMemcpy(out_host, g_ts_buf, 256 * 4 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 #endif
@@ -580,6 +881,7 @@ int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
                 case 1: return launch_ph8<EPI_F32, 1>(a, stream);
                 case 2: return launch_ph8<EPI_F32, 2>(a, stream);
                 case 3: return launch_ph8<EPI_F32, 3>(a, stream);
+                case 9: return launch_ph8<EPI_F32, 9>(a, stream);
 #endif
             }
             break;
