@@ -83,36 +83,77 @@ def one_generation(model, cond, seed, dev, world):
 
 def cpu_baseline(sd):
     """The oracle (torch fp32 restatement == the reference's CPU path) on the host cores, bounded sample:
-    ONE CFG denoiser evaluation at full SA-Open size + decode of 43 latent frames, extrapolated to
-    100 steps + 1024 frames."""
+    ONE CFG denoiser evaluation at full SA-Open size per thread count of a small sweep + decode of 43 latent frames at the best
+    count, extrapolated to 100 steps + 1024 frames.  The line reports the best count, every count tried, os.cpu_count() and the
+    affinity mask size ("core count printed")."""
     from oracle import dit as odit, oobleck as oob
     from stable_audio_tools import synthetic
-    # host threads: the cores this process may run on, capped at 16 -- torch's CPU GEMMs stop scaling (and on a
-    # cgroup-limited box collapse) far below the 256 logical CPUs os.cpu_count() reports on the GPU host
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))
-    torch.set_num_threads(cores)
+    counts = sorted({c for c in (8, 16, 32, avail) if 1 <= c <= avail} or {avail})
     dsd = {k[len("model.model."):]: v for k, v in sd.items() if k.startswith("model.model.")}
     vsd = {k[len("pretransform.model.decoder."):]: v for k, v in sd.items() if k.startswith("pretransform.model.decoder.")}
     x = synthetic.synth_input("x", (1, 64, 1024), 1)
     c = synthetic.synth_input("c", (1, 130, 768), 2)
     g = synthetic.synth_input("g", (1, 1536), 3)
     t = torch.tensor([0.5])
+    sweep = {}
     with torch.no_grad():
-        t0 = time.perf_counter()
-        odit.dit_forward(dsd, x, t, c, g, 24, 24, cfg_scale=CFG_SCALE)
-        t_step = time.perf_counter() - t0
+        for n in counts:
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            odit.dit_forward(dsd, x, t, c, g, 24, 24, cfg_scale=CFG_SCALE)
+            sweep[n] = time.perf_counter() - t0
+            if sweep[n] > 2.0 * min(sweep.values()):      # more threads only get slower from here (oversubscribed / cgroup-limited host)
+                break
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        t_step = sweep[best]
         z = synthetic.synth_input("z", (1, 64, 43), 4)
         oob.oobleck_decoder(vsd, z)      # warm-up
         t0 = time.perf_counter()
         oob.oobleck_decoder(vsd, z)
         t_dec = time.perf_counter() - t0
     total = DIT_STEPS * t_step + t_dec * (1024 / 43)
-    return {"value": (SAMPLE_SIZE / SAMPLE_RATE) / total, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 CFG DiT evaluation at full size ({t_step:.2f} s) x100 + Oobleck decode of 43 frames ({t_dec:.2f} s) x(1024/43), extrapolated"}
+    return {"value": (SAMPLE_SIZE / SAMPLE_RATE) / total, "unit": "audio-seconds/sec", "cores": best, "kind": "port",
+            "host_logical_cpus": os.cpu_count(), "affinity_cpus": avail,
+            "thread_sweep_s_per_cfg_step": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": f"1 CFG DiT evaluation at full size per thread count (best: {best} threads, {t_step:.2f} s) x100 + Oobleck decode of "
+                      f"43 frames ({t_dec:.2f} s) x(1024/43), extrapolated"}
+
+
+# ---- the multi-rank logic, in functions of its own so that the CPU test (tests/test_bench_ranks.py, gloo, world size 2) runs exactly
+# what an 8-GPU launch runs, with the generation stubbed out
+def shard_prompts(world, rank, batch):
+    """rank-strided prompt ids, as the reference's generate.py:119-120"""
+    return list(range(world * batch))[rank::world]
+
+
+def timed_steps(step_fn, steps, use_dist, sync, device):
+    """K steps bracketed by barrier + device sync on both sides; returns the MAX over ranks of the elapsed seconds"""
+    if use_dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(2000 + i)
+    if use_dist:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def stub_generation(prompt_ids, seed, dev):
+    """SAT_BENCH_STUB=1 (CPU test of the rank plumbing): int16 'audio' that encodes (prompt id, seed), 2 x 64 samples per prompt"""
+    rows = [torch.full((2, 64), (pid * 131 + seed) % 30000, dtype=torch.int16) + torch.arange(64, dtype=torch.int16) for pid in prompt_ids]
+    return torch.stack(rows).to(dev)
 
 
 def main():
@@ -128,7 +169,17 @@ def main():
                     help="LayerNorms of the blocks inside the GEMM epilogues (sat_dit_cfg.ln_fold, default) or as three kernels per block")
     ap.add_argument("--workload", choices=("sa_open", "sa2_a2a"), default="sa_open",
                     help="sa_open: the headline (BASELINE config 2/3); sa2_a2a: config 4, SA-2.0 shape, audio-to-audio, 1 GPU")
+    ap.add_argument("--dry-run", action="store_true", help="check the arguments and print the rank -> prompt plan as JSON; touches no GPU")
     args = ap.parse_args()
+    if args.gpus < 1 or args.batch < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("bench.py: --gpus / --batch / --steps must be >= 1 and --warmup >= 0")
+    if args.dry_run:
+        print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "prompts_per_gpu": args.batch, "global_batch": args.gpus * args.batch,
+                          "prompt_ids_per_rank": [shard_prompts(args.gpus, r, args.batch) for r in range(args.gpus)],
+                          "collectives_per_step": 1 if args.gpus > 1 else 0, "launch": "python -m torch.distributed.run --nnodes=1 "
+                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} --steps {args.steps} "
+                          f"--warmup {args.warmup} --batch {args.batch}"}))
+        return
     global SAMPLE_SIZE
     WORKLOAD["name"] = args.workload
     if args.workload == "sa2_a2a":
@@ -152,11 +203,38 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched with a different --nproc-per-node?)")
+    use_dist = world > 1 or FORCE_DIST
+    if os.environ.get("SAT_BENCH_STUB") == "1":
+        # CPU test of the rank plumbing: same sharding, barriers, max-reduced clock, gather and JSON line; gloo instead of RCCL and a
+        # stub instead of the model.  Never a benchmark: the line says so.
+        from stable_audio_tools.inference.distributed import gather_sharded
+        dev = torch.device("cpu")
+        if use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        prompt_ids = shard_prompts(world, rank, args.batch)
+        last = {}
+
+        def step(seed):
+            out = stub_generation(prompt_ids, seed, dev)
+            last["audio"] = gather_sharded(out, world * args.batch) if use_dist else out
+
+        for i in range(args.warmup):
+            step(1000 + i)
+        elapsed = timed_steps(step, args.steps, use_dist, lambda: None, dev)
+        if rank == 0:
+            audio = last["audio"]
+            print(json.dumps({"stub": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "rccl_ranks": world if use_dist else 0, "gathered_shape": list(audio.shape),
+                              "gathered_first_samples": [int(v) for v in audio[:, 0, 0]], "prompt_ids_rank0": prompt_ids}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if torch.cuda.device_count() <= local:
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or FORCE_DIST
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -182,7 +260,7 @@ def main():
     if rank != 0 or args.no_cpu_baseline:
         sd = None
     # rank-strided prompt sharding, as the reference's generate.py:119-120
-    prompt_ids = list(range(world * args.batch))[rank::world]
+    prompt_ids = shard_prompts(world, rank, args.batch)
     cond = conditioning(model, prompt_ids, dev)
     dit = model.model.model
     dit.set_gemm_dtype(args.dtype)
@@ -194,20 +272,7 @@ def main():
         one_generation(model, cond, 1000 + i, dev, world)
     dit._ensure_plan()                              # --warmup 0: the plan is otherwise built lazily by the first generation
     _hip.check(lib.sat_dit_profile(dit._plan, 1))
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_generation(model, cond, 2000 + i, dev, world)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(lambda seed: one_generation(model, cond, seed, dev, world), args.steps, use_dist, torch.cuda.synchronize, dev)
 
     # dominant kernel: FFN-in SwiGLU GEMM, timed live with HIP events on the launch stream (one layer per forward)
     tot = ctypes.c_double()

@@ -27,14 +27,25 @@ void sat_set_error(const char* fmt, ...) {
 extern "C" const char* sat_last_error(void) { return g_last_error.c_str(); }
 
 int sat_ensure_dynamic_lds(const void* kernel, int bytes) {
-    static std::mutex mu;
-    static std::set<std::pair<const void*, int>> done;
+    // Launch-path cost: one thread-local table probe (no lock, no allocation) once a (kernel, device) pair has been seen by this
+    // thread; the mutex-protected set is only consulted on a thread's first launch of a kernel on a device.
+    struct Seen { const void* k; int dev; };
+    static thread_local Seen seen[64];
+    static thread_local int n_seen = 0;
     int dev = 0;
     SAT_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    if (done.count({kernel, dev})) return 0;
-    SAT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    done.insert({kernel, dev});
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].k == kernel && seen[i].dev == dev) return 0;
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done.count({kernel, dev})) {
+            SAT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            done.insert({kernel, dev});
+        }
+    }
+    if (n_seen < 64) seen[n_seen++] = Seen{kernel, dev};
     return 0;
 }
 extern "C" int sat_version(void) { return 3; }

@@ -216,12 +216,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 //   * SwiGLU / MXFP8 block maximum: value and gate, resp. the 32 channels of a block, sit in one lane pair.
 // V^T (token-contiguous destination) keeps the un-swapped orientation and the epilogue above.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int MI, int NI, bool NOSTORE = false, bool LNC = false>
+template <int EPI, int MI, int NI, bool LNC = false>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
                                                 const int l31, const float2* ln = nullptr, const float* lc1 = nullptr,
                                                 const float* lc2 = nullptr) {
-    // NOSTORE (ablation builds only): all the arithmetic, stores behind a never-true runtime test
-    const int M = NOSTORE ? (g.K < 0 ? g.M : 0) : g.M, N = g.N;
+    const int M = g.M, N = g.N;
     (void)N;
     if constexpr (EPI == EPI_F32) {
         const bool accum = g.accumulate != 0;
@@ -720,13 +719,12 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
     else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
-// DBG (micro-benchmark ablations, wrong results): 0 production; 1 all tiles load tile (0,0); 2 no LDS-DMA in the loop;
-// 3 no ds_read/MFMA; 4 = 2 + no barrier; 5 = 4 + no ds_read (MFMA on register-resident fragments); 6 = 5 + no epilogue
-// (the stores are kept behind a never-true data-dependent test so that the MFMAs stay)
+// (The ablation modes of rounds 1-2 -- no LDS-DMA / no ds_read / no barrier / no epilogue builds of this kernel -- are in the git
+// history at 9661dcc; what they measured is in profiles/r01_gemm_ablation.txt, r02_gemm_ablation.txt.)
 // FP8: A and W are e4m3 bytes.  The launcher hands the kernel K/2 "bf16 columns", so staging, LDS layout and swizzle are
 // byte-for-byte those of the bf16 kernel (128-B rows now hold 128 k); a 16-B fragment is two 8-byte MFMA operands:
 // v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16 rate, but every LDS / L2 / HBM byte carries twice the k.
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int FP8 = 0>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
@@ -752,7 +750,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     constexpr int D = NS - 1;                      // prefetch distance
     static_assert(!MXA || D == 1 || UNIFORM, "MXFP8: counted waits are built for uniform tiles or 2-stage rings");
     static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
-    static_assert(!FP8 || (BK == 64 && DBG == 0), "fp8: 128-byte rows only");
+    static_assert(!FP8 || BK == 64, "fp8: 128-byte rows only");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -783,7 +781,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     const bool wave_rows_valid = (m0 + wm * TM) < M;
     // fp32 residual epilogue of the small tiles (one 32-row block per wave, registers to spare): fetch the residual values NOW.
     // They are the oldest entries of the vector-memory queue, so every counted vmcnt wait of the K loop still holds.
-    constexpr bool PRE_RESID = EPI == EPI_F32 && MI == 1 && NI == 2 && DBG == 0 && NT <= 512;
+    constexpr bool PRE_RESID = EPI == EPI_F32 && MI == 1 && NI == 2 && NT <= 512;
     [[maybe_unused]] f32x4 resid[PRE_RESID ? 8 : 1];
     if constexpr (PRE_RESID) {
         // (exactly the condition under which the staged epilogue runs, see the end of the kernel)
@@ -803,17 +801,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 
     // LayerNorm fold, consumer side: mean and 1/std of the BM rows of this tile from the producer's per-block partial sums, into
     // LDS behind the ring (filled right after the prologue's LDS-DMA below, read by the epilogue).
-    constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && FP8 == 0 && DBG == 0;
+    constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && FP8 == 0;
     // LDS behind the ring: (mean, 1/std) of the BM rows, then the BN (c1, c2) pairs of this tile's output channels
     [[maybe_unused]] float2* lnst = reinterpret_cast<float2*>(smem + NS * STAGE_BYTES);
     [[maybe_unused]] float* lnc = reinterpret_cast<float*>(smem + NS * STAGE_BYTES + BM * 8);      // c1[BN] then c2[BN]
-    constexpr bool dbg_same = DBG == 1;
-    constexpr bool dbg_noload = DBG == 2 || (DBG >= 4 && DBG != 8);      // 8: production main loop, stores suppressed
-    constexpr bool dbg_noepi = DBG == 6;
-    constexpr bool dbg_nostore = DBG == 7 || DBG == 8;         // 7 = 5 + the full epilogue arithmetic, stores suppressed
-    constexpr bool dbg_nomfma = DBG == 3;
-    constexpr bool dbg_nobar = DBG >= 4 && DBG != 8;
-    constexpr bool dbg_nolds = DBG >= 5 && DBG != 8;
     const bf16_t* ld_ptr[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
@@ -822,9 +813,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         int q = (is_a ? L : L - WL_A) * 64 + lane;
         int row = q / CPR, pos = q % CPR;
         int c = (BK == 128) ? (pos ^ (row & 15)) : (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
-        int gm = (dbg_same ? 0 : m0) + row;
+        int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        int gn = (dbg_same ? 0 : n0) + row;
+        int gn = n0 + row;
         gn = gn < N ? gn : N - 1;                  // only reachable by the unused slot of a short wave
         ld_ptr[i] = is_a ? g.A + (size_t)gm * K + c * 8 : g.W + (size_t)gn * K + c * 8;
     }
@@ -1086,15 +1077,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     int rd = 0;          // stage of tile k
     int wr = D;          // stage that receives tile k+D (== stage of tile k-1)
     // steady state: tiles k+1..k+D-1 stay in flight across the barrier
-    bf16x8 fa0[MI], fb0[NI];       // ablation only: fragments that stay in registers
-    if constexpr (dbg_nolds) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(smem + lds_off_bk<BK>(wm * TM + i * 32 + l31, half));
-#pragma unroll
-        for (int j = 0; j < NI; ++j) fb0[j] = *reinterpret_cast<const bf16x8*>(smem + BM * ROWB + lds_off_bk<BK>(wn * TN + j * 32 + l31, half));
-    }
     // Orientation (uniform over the workgroup: tiles never straddle a q / k / v part): transposed accumulators everywhere except
     // for a V^T destination (token-contiguous stores want lane = channel), the MXFP8 A operand and the fp32 output.
     // Measured (profiles/r02_epilogue_ab.txt): bf16 outputs gain 3-4 % (SwiGLU) / 13 % (heads) from the transposed orientation, the
@@ -1119,22 +1101,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
     auto main_loop = [&](auto trc) {
         for (int k = 0; k < nk - D; ++k) {
-            if constexpr (!dbg_nobar) {
-                wait_steady();
-                __builtin_amdgcn_s_barrier();
-            }
-            if constexpr (!dbg_noload) stage_in(k + D, wr);
-            if constexpr (dbg_nolds) {
-#pragma unroll
-                for (int ks = 0; ks < BK / 16; ++ks)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
-            } else if constexpr (!dbg_nomfma) {
-                if (wave_rows_valid) compute(rd, trc);
-            }
+            wait_steady();
+            __builtin_amdgcn_s_barrier();
+            stage_in(k + D, wr);
+            if (wave_rows_valid) compute(rd, trc);
             rd = (rd + 1 == NS) ? 0 : rd + 1;
             wr = (wr + 1 == NS) ? 0 : wr + 1;
         }
@@ -1155,9 +1125,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         else main_loop(std::false_type{});
     }
 
-    if constexpr (dbg_noepi) {
-        if (acc[0][0][0] != 12345.678f) return;
-    }
     if constexpr (FP8 != 0) {
         // dequantise: per-token scale of A x per-output-channel scale of W (kept out of the last K-tile's MFMA schedule)
         __builtin_amdgcn_sched_barrier(0);
@@ -1194,7 +1161,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             }
         }
     }
-    if constexpr (EPI == EPI_F32 && NI == 2 && DBG == 0) {
+    if constexpr (EPI == EPI_F32 && NI == 2) {
         if (!tr && !direct_f32) {
             __builtin_amdgcn_s_barrier();       // every wave is done reading the ring: it becomes the staging area
             if (wave_rows_valid) {
@@ -1208,7 +1175,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
     if (wave_rows_valid) {
         if constexpr (NI == 2 || EPI == EPI_F32) {
-            if (tr) gemm_epilogue_t<EPI, MI, NI, dbg_nostore, LN_CONS>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31, lnst + wm * TM, lnc + wn * TN, lnc + BN + wn * TN);
+            if (tr) gemm_epilogue_t<EPI, MI, NI, LN_CONS>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31, lnst + wm * TM, lnc + wn * TN, lnc + BN + wn * TN);
             else gemm_epilogue<EPI, MI, NI, LN_CONS>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31, lnst + wm * TM, lnc + wn * TN, lnc + BN + wn * TN);
         } else {
             gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);
@@ -1216,17 +1183,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int DBG = 0, int FP8 = 0>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
-    constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && FP8 == 0 && DBG == 0;
+    constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && FP8 == 0;
     constexpr int LDS = NS * ((BM + BN) * BK * 2 + (FP8 == 3 ? BM * 4 : 0)) + (LN_CONS ? (BM + BN) * 8 : 0);     // + (mean, rstd) per row, (c1, c2) per column
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
     SAT_CHECK_ARG(LN_CONS || !a.ln_part, SAT_E_UNSUPPORTED, "gemm: LayerNorm fold needs bf16 operands and a SwiGLU / heads epilogue");
     SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (EPI == EPI_F32 && BN / WN == 64 && FP8 == 0 && a.xb && a.ln_part_out), SAT_E_UNSUPPORTED,
                   "gemm: the bf16 image / row statistics come from the bf16 fp32-output tiles with 64-column wave tiles");
     static_assert(EPI != EPI_F32 || BN / WN != 64 || LDS >= WM * WN * 8192, "the staged fp32 epilogue needs 8 KiB of LDS per wave");
-    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, DBG, FP8>;
+    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, FP8>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     GemmArgs b = a;
     if (FP8) {
@@ -1285,32 +1252,6 @@ int g_wide_tile = 80;
 
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
-#ifdef SAT_GEMM_EXPERIMENTS
-    if ((a.variant & 0xfff) >= 100) {   // micro-benchmark ablations (tools/gpu_probe.py): 100 * DBG mode + tile id
-        switch (a.variant & 0xfff) {
-            case 222: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 2>(a, stream);
-            case 422: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 4>(a, stream);
-            case 522: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 5>(a, stream);
-            case 622: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 6>(a, stream);
-            case 722: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 7>(a, stream);
-            case 822: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 8>(a, stream);
-            case 215: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 2>(a, stream);
-            case 415: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 4>(a, stream);
-            case 515: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 5>(a, stream);
-            case 615: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 6>(a, stream);
-            case 216: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 2>(a, stream);
-            case 416: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 4>(a, stream);
-            case 516: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 5>(a, stream);
-            case 616: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 6>(a, stream);
-            case 230: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 2>(a, stream);
-            case 430: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 4>(a, stream);
-            case 530: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 5>(a, stream);
-            case 630: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 6>(a, stream);
-        }
-        sat_set_error("gemm: unknown ablation variant %d", a.variant);
-        return SAT_E_INVALID;
-    }
-#endif
     int v = a.variant & 0xff;
     // fill of the last round of 256 CUs x measured in-kernel rate of the tile, relative to the 256x256 tile
     auto score = [&](int bm, int bn, double rate) {
@@ -1328,25 +1269,25 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         if (a.fp8 == 3) {      // MXFP8 A operand (hardware block scales), fp32 output only: FF-out, to_out
             if constexpr (EPI == EPI_F32) {
                 switch (v) {
-                    case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 3>(a, stream);
-                    case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 0, 3>(a, stream);
-                    case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 0, 3>(a, stream);
-                    case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 3>(a, stream);
+                    case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 3>(a, stream);
+                    case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 3>(a, stream);
+                    case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 3>(a, stream);
+                    case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 3>(a, stream);
                 }
             }
         } else if (a.fp8 == 2) {      // block-scaled MFMA with unit scales: 2x the MFMA rate
             switch (v) {
-                case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 2>(a, stream);
-                case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 0, 2>(a, stream);
-                case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 0, 2>(a, stream);
-                case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 2>(a, stream);
+                case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 2>(a, stream);
+                case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 2>(a, stream);
+                case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 2>(a, stream);
+                case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 2>(a, stream);
             }
         } else {
             switch (v) {
-                case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 1>(a, stream);
-                case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 0, 1>(a, stream);
-                case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 0, 1>(a, stream);
-                case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 1>(a, stream);
+                case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 1>(a, stream);
+                case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 1>(a, stream);
+                case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI, 1>(a, stream);
+                case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 1>(a, stream);
             }
         }
         sat_set_error("gemm(fp8): variant %d has no e4m3 build (15, 16, 22, 30)", v);

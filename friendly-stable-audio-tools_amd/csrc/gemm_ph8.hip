@@ -40,6 +40,7 @@
 // Epilogues run on TRANSPOSED accumulators (W fragment = MFMA A operand): lane l owns token row (l & 15) of a 16 x 16 block and
 // four consecutive output channels; which channels a wave's W rows are is a free permutation applied where the DMA picks its
 // source rows (chan_of), chosen per epilogue so that stores are 16 bytes and SwiGLU / RoPE partners are lane-local.
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -90,6 +91,8 @@ struct Ph8Sched {
     const int* sk_parts;    // [sk_tiles] number of contributing workgroups
     unsigned* sk_count;     // [sk_tiles] arrival tickets, zero between launches
     float* sk_slab;         // [G][2][65536] raw accumulator images
+    int any_split;          // some remainder tile has more than one contributor
+    int dump;               // 1: a partial K-range only stores its accumulators; ph8_reduce_f32_kernel adds them up and finishes the tile
 };
 
 struct Seg {                // one K-range of one tile
@@ -100,6 +103,77 @@ struct Seg {                // one K-range of one tile
     bool whole;             // the K-range covers the tile: plain epilogue
     bool tr;                // accumulator orientation (transposed unless a V^T destination)
 };
+
+
+// position in the work order -> tile.  Work order: the full tiles (short M: m fastest, the W panel of a column tile stays in one
+// XCD's L2; long M: bands of 8 row tiles, n-major inside a band -- 8 A panels + the W panels in flight) with the light row behind
+// them, or (light_first) in front of them.
+__device__ __forceinline__ void ph8_tile_of(const Ph8Sched& sc, int id, int& tm, int& tn) {
+    const int nl = sc.light ? sc.tiles_n : 0;
+    const int lid = sc.light_first ? id : id - sc.tiles_m_full * sc.tiles_n;
+    if (lid >= 0 && lid < nl) {
+        tm = sc.tiles_m_full;
+        tn = lid;
+        return;
+    }
+    const int L = sc.light_first ? id - nl : id;
+    const int tiles_m = sc.tiles_m_full, tiles_n = sc.tiles_n;
+    if (tiles_m <= 12) {
+        tn = L / tiles_m;
+        tm = L - tn * tiles_m;
+    } else {
+        const int band_sz = 8 * tiles_n;
+        const int band = L / band_sz;
+        const int rem = L - band * band_sz;
+        const int gm = min(8, tiles_m - band * 8);
+        tn = rem / gm;
+        tm = band * 8 + (rem - tn * gm);
+    }
+}
+
+// fp32 output / residual update of ONE token row piece (transformer.py:692-700), adaLN gate (:674, 688), and the producer side of the
+// LayerNorm fold: bf16 image of the updated row + (sum, sum of squares) of the ROUNDED values over the wave's 64-column block.
+// v[nb] = the accumulators of channels ncol0 + 16 nb + 4 q4 .. + 3 of token row m (lane (l15, q4) of a transposed 16 x 16 block).
+__device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[4], const f32x4_t (&bia)[4], int m, int ncol0, int q4) {
+    const int M = g.M, N = g.N;
+    const bool accum = g.accumulate != 0;
+    const bool prod = g.xb != nullptr;
+    const int mc = m < M ? m : M - 1;
+    float* __restrict__ crow = g.C + (size_t)mc * g.ldc + ncol0 + 4 * q4;
+    const float* grow = g.gate ? g.gate + (size_t)(mc / g.gate_rows) * g.gate_ld + ncol0 + 4 * q4 : nullptr;
+    f32x4_t old[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) old[nb] = accum ? *reinterpret_cast<const f32x4_t*>(crow + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        f32x4_t x = v[nb] + bia[nb];
+        if (grow) x *= *reinterpret_cast<const f32x4_t*>(grow + nb * 16);
+        x += old[nb];
+        if (m < M) *reinterpret_cast<f32x4_t*>(crow + nb * 16) = x;
+        if (prod) {
+            bf16x4 xr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xr[e] = f32_to_bf16(x[e]);
+                const float f = bf16_to_f32(xr[e]);
+                sum += f;
+                sq += f * f;
+            }
+            if (m < M) *reinterpret_cast<bf16x4*>(g.xb + (size_t)m * N + ncol0 + 4 * q4 + nb * 16) = xr;
+        }
+    }
+    if (prod) {       // add the four lanes (q4 = 0..3) that share the token row
+        sum += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sum), 0x401F));       // lane ^ 16
+        sq += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sq), 0x401F));
+        u32x2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+        u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+        sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+        sq = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+        if (q4 == 0 && m < M)
+            *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (N >> 6) + (ncol0 >> 6)) * 2) = make_float2(sum, sq);
+    }
+}
 
 // DBG (tools/ph8_probe.py ablations, wrong results): 1 no LDS-DMA in the loop, 2 no ds_read (fragments stay), 3 no MFMA
 // Measured and dropped (profiles/r03_ph8_schedule_options.txt): without the explicit lgkmcnt(0) behind the barrier, without s_setprio,
@@ -122,27 +196,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
     const int wgi = xcd_remap(blockIdx.x, sc.G);          // consecutive logical workgroups share an XCD (and so the tiles they split)
 
     // ---- the walk over this workgroup's K-ranges
-    auto full_tile = [&](int L, int& tm, int& tn) {        // logical id -> tile of the full space
-        const int tiles_m = sc.tiles_m_full, tiles_n = sc.tiles_n;
-        if (tiles_m <= 12) {               // short M: m fastest, the W panel of a column tile stays in one XCD's L2
-            tn = L / tiles_m;
-            tm = L - tn * tiles_m;
-        } else {                           // long M: bands of 8 row tiles, n-major inside a band (8 A panels + the W panels in flight)
-            const int band_sz = 8 * tiles_n;
-            const int band = L / band_sz;
-            const int rem = L - band * band_sz;
-            const int gm = min(8, tiles_m - band * 8);
-            tn = rem / gm;
-            tm = band * 8 + (rem - tn * gm);
-        }
-    };
-    // work order: the full tiles with the light row behind them, or (light_first) in front of them
-    auto tile_of = [&](int id, int& tm, int& tn) {
-        const int nl = sc.light ? sc.tiles_n : 0;
-        const int lid = sc.light_first ? id : id - sc.tiles_m_full * sc.tiles_n;
-        if (lid >= 0 && lid < nl) { tm = sc.tiles_m_full; tn = lid; }
-        else full_tile(sc.light_first ? id - nl : id, tm, tn);
-    };
+    auto tile_of = [&](int id, int& tm, int& tn) { ph8_tile_of(sc, id, tm, tn); };
     int dp_s = 0;
     const int sk_b = sc.sk_tiles ? sc.sk_begin[wgi] : 0;
     const int sk_e = sc.sk_tiles ? sc.sk_begin[wgi + 1] : 0;
@@ -412,53 +466,12 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         [[maybe_unused]] const float* lc1 = reinterpret_cast<const float*>(smem + RING_BYTES + lb * LN_BYTES + 2048) + wc * 64;
         [[maybe_unused]] const float* lc2 = lc1 + 256;
         if constexpr (EPI == EPI_F32) {
-            // fp32 output / residual update (transformer.py:692-700), adaLN gate (:674, 688); LayerNorm fold, producer side: bf16 image
-            // of the updated rows + (sum, sum of squares) of the ROUNDED values over this wave's 64-column block
-            const bool accum = g.accumulate != 0;
-            const bool prod = g.xb != nullptr;
             f32x4_t bia[4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
                 bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
-                const int m = mrow0 + mb * 16;
-                const int mc = m < M ? m : M - 1;
-                float* __restrict__ crow = g.C + (size_t)mc * g.ldc + ncol0 + 4 * q4;
-                const float* grow = g.gate ? g.gate + (size_t)(mc / g.gate_rows) * g.gate_ld + ncol0 + 4 * q4 : nullptr;
-                f32x4_t old[4];
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) old[nb] = accum ? *reinterpret_cast<const f32x4_t*>(crow + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                float sum = 0.f, sq = 0.f;
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    f32x4_t v = acc[mb][nb] + bia[nb];
-                    if (grow) v *= *reinterpret_cast<const f32x4_t*>(grow + nb * 16);
-                    v += old[nb];
-                    if (m < M) *reinterpret_cast<f32x4_t*>(crow + nb * 16) = v;
-                    if (prod) {
-                        bf16x4 xr;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            xr[e] = f32_to_bf16(v[e]);
-                            const float f = bf16_to_f32(xr[e]);
-                            sum += f;
-                            sq += f * f;
-                        }
-                        if (m < M) *reinterpret_cast<bf16x4*>(g.xb + (size_t)m * N + ncol0 + 4 * q4 + nb * 16) = xr;
-                    }
-                }
-                if (prod) {       // add the four lanes (q4 = 0..3) that share the token row
-                    sum += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sum), 0x401F));       // lane ^ 16
-                    sq += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(sq), 0x401F));
-                    u32x2 a = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
-                    u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
-                    sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-                    sq = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-                    if (q4 == 0 && m < M)
-                        *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (N >> 6) + (ncol0 >> 6)) * 2) = make_float2(sum, sq);
-                }
-            }
+            for (int mb = 0; mb < 8; ++mb) ph8_epi_f32_row(g, acc[mb], bia, mrow0 + mb * 16, ncol0, q4);
         } else if constexpr (EPI == EPI_SWIGLU) {
             // H = (v + b_v) * silu(gate + b_g) (transformer.py:232-235): value rows are channels [0, 32) of the wave's 64, gate rows
             // [32, 64) (pack_rows interleave); PERM 1 puts value and gate of hidden columns hc0 + 8 q4 + 4 nf + r into this lane
@@ -683,7 +696,18 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         const bool more = next_seg(nxt);
         if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
         bool fin = true;
-        if (!cur.whole) fin = fixup(cur);
+        if (!cur.whole) {
+            if (sc.dump) {          // two-launch split (fp32 output): plain stores, the kernel boundary publishes them
+                float* mine = sc.sk_slab + ((size_t)wgi * 2 + cur.slot) * 65536 + (size_t)(wave * 32) * 256 + lane * 4;
+#pragma unroll
+                for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4_t*>(mine + (mb * 4 + nb) * 256) = acc[mb][nb];
+                fin = false;
+            } else {
+                fin = fixup(cur);
+            }
+        }
         if constexpr (DBG == 9) t2 = __builtin_amdgcn_s_memrealtime();
         if (fin && rows_valid) epilogue(cur, lb);
         if constexpr (DBG == 9) {
@@ -700,9 +724,46 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
     }
 }
 
+// Second launch of a K-split fp32-output GEMM: workgroup (j, mb) adds the slabs of remainder tile j for the row blocks mb of all
+// eight waves -- every contributor's accumulator image in ascending workgroup order, bit-deterministic -- and runs the fp32 /
+// residual / LayerNorm-producer epilogue on the sums.  Same lane <-> element map as the GEMM, so the slab reads are 1-KiB coalesced.
+__global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sched sc) {
+    const int j = blockIdx.x >> 3, mb = blockIdx.x & 7;
+    const int parts = sc.sk_parts[j];
+    if (parts <= 1) return;                          // a whole tile: finished by the GEMM launch itself
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, q4 = lane >> 4;
+    int tm, tn;
+    ph8_tile_of(sc, sc.sk_tile[j], tm, tn);
+    const int m = (tm << 8) + wr * 128 + mb * 16 + l15;
+    const int ncol0 = (tn << 8) + wc * 64;
+    if ((tm << 8) + wr * 128 >= g.M) return;
+    f32x4_t v[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int tile_u0 = j * sc.nkp;
+    int seen = 0;
+    for (int w = sc.sk_first[j]; seen < parts; ++w) {
+        const int wb = sc.sk_begin[w];
+        if (sc.sk_begin[w + 1] <= wb) continue;
+        ++seen;
+        const float* src = sc.sk_slab + ((size_t)w * 2 + (wb >= tile_u0 ? 0 : 1)) * 65536 + (size_t)(wave * 32 + mb * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) v[nb] += *reinterpret_cast<const f32x4_t*>(src + nb * 256);
+    }
+    f32x4_t bia[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+        bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    ph8_epi_f32_row(g, v, bia, m, ncol0, q4);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side: the persistent schedule of a shape (cached per device and shape)
 // ---------------------------------------------------------------------------------------------------------------------------------
+// the slab of a device may be re-allocated when a later shape needs a bigger one (ph8_schedule): the lock-free hit table of
+// launch_ph8 compares the pointer it cached with one relaxed read
+std::atomic<float*> g_slab_now[16];
+float* slab_of_device(int dev) { return dev < 16 ? g_slab_now[dev].load(std::memory_order_relaxed) : nullptr; }
+
 struct DevState {
     int cus = 0;
     float* slab = nullptr;
@@ -713,16 +774,26 @@ std::mutex g_sched_mu;
 std::map<int, DevState> g_dev;
 
 // split: 0 = the remainder round's tiles stay whole (one per workgroup, light tiles last), 1 = the remainder round is split along K,
-// -1 = the measured policy (profiles/r03_ph8_streamk.txt): split only long reductions behind at least one whole round -- FF-out from
-// 4 prompts on (-5 %), SA-2.0 (-15 %); at K = 1536 the fix-up (two 256-KiB slab transfers at HBM speed, every workgroup at the same
-// time) costs more than the half round it saves, and below one whole round the 128x128 tiles of gemm_bf16.hip are faster
-int ph8_schedule(const GemmArgs& a, int split, Ph8Sched& out) {
+// -1 = the measured policy below
+int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, Ph8Sched& out) {
     int dev = 0;
     SAT_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_sched_mu);
     DevState& d = g_dev[dev];
     if (!d.cus) SAT_HIP(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (split < 0) split = (a.K >= 4096 && (long)cdiv(a.M, 256) * (a.N / 256) > d.cus) ? 1 : 0;
+    if (split < 0) {
+        // Measured policy (profiles/r03_ph8_streamk.txt): split only fp32-output GEMMs with a long reduction (K >= 4096: FF-out) behind
+        // at least one whole round, and only when every remainder tile gets >= 2 parts (otherwise the whole tiles set the makespan and
+        // the slab traffic -- 2 x 256 KiB per part at HBM speed, everybody at the same time -- is pure loss): SA-2.0 FF-out -25 %.
+        // 8 prompts (134 remainder tiles on 256 CUs) and every K = 1536 GEMM stay whole; below one whole round the 128 x 128 tiles of
+        // gemm_bf16.hip are faster (FF-out at 1 prompt: 60 us against 67).
+        const int tm = cdiv(a.M, 256), tail_ = a.M % 256;
+        const long lights = (tail_ != 0 && tail_ <= 64 && tm > 1) ? a.N / 256 : 0;
+        const long t_all_ = (long)tm * (a.N / 256);
+        const long rem = t_all_ % d.cus;
+        split = (epi_f32 && a.K >= 4096 && t_all_ > d.cus && rem > 0 && 2 * rem <= d.cus) ? 1 : 0;
+        (void)lights;
+    }
     auto key = std::make_tuple(a.M, a.N, a.K, split);
     auto it = d.shapes.find(key);
     if (it != d.shapes.end()) {
@@ -765,11 +836,11 @@ int ph8_schedule(const GemmArgs& a, int split, Ph8Sched& out) {
             long used = 0;
             for (int j = 0; j < s.sk_tiles; ++j) {
                 const long c2 = is_light(tile[j]) ? 1 : 2;
-                pj[j] = (int)std::max<long>(1, std::min<long>(s.nkp, (long)s.G * c2 / cost2));
+                pj[j] = (int)std::max<long>(1, std::min<long>(std::min(s.nkp, 8), (long)s.G * c2 / cost2));
                 used += pj[j];
             }
             for (int j = 0; j < s.sk_tiles && used < s.G; ++j)          // leftover workgroups: one more part for the first full tiles
-                if (!is_light(tile[j]) && pj[j] < s.nkp) { ++pj[j]; ++used; }
+                if (!is_light(tile[j]) && pj[j] < std::min(s.nkp, 8)) { ++pj[j]; ++used; }
             for (int j = 0; j < s.sk_tiles; ++j)
                 for (int k = 0; k < pj[j]; ++k) share.push_back((int)((long)s.nkp * (k + 1) / pj[j] - (long)s.nkp * k / pj[j]));
         }
@@ -800,12 +871,14 @@ int ph8_schedule(const GemmArgs& a, int split, Ph8Sched& out) {
         SAT_HIP(hipMemcpy(dp, parts.data(), s.sk_tiles * sizeof(int), hipMemcpyHostToDevice));
         SAT_HIP(hipMemset(dc, 0, s.sk_tiles * sizeof(unsigned)));
         s.sk_tile = dt; s.sk_begin = db; s.sk_first = df; s.sk_parts = dp; s.sk_count = dc;
+        s.any_split = any_split ? 1 : 0;
         if (any_split && d.slab_wgs < (size_t)s.G) {
             // one slab pair per workgroup, shared by every shape on this device: launches on ONE stream only (the plans' use)
             SAT_HIP(hipDeviceSynchronize());
             if (d.slab) SAT_HIP(hipFree(d.slab));
             SAT_HIP(hipMalloc(&d.slab, (size_t)s.G * 2 * 65536 * sizeof(float)));
             d.slab_wgs = s.G;
+            if (dev < 16) g_slab_now[dev].store(d.slab, std::memory_order_relaxed);
         }
     }
     d.shapes[key] = s;
@@ -837,7 +910,25 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
     }
     Ph8Sched sc;
     // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements)
-    SAT_TRY(ph8_schedule(a, (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1, sc));
+    const int split = (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;
+    {
+        // launch path: the few shapes of a plan are found in a thread-local table without taking the lock
+        struct Hit { int dev, M, N, K, split; float* slab; Ph8Sched s; };
+        static thread_local Hit hits[16];
+        static thread_local int n_hits = 0;
+        int dev = 0;
+        SAT_HIP(hipGetDevice(&dev));
+        Hit* h = nullptr;
+        for (int i = 0; i < n_hits; ++i)
+            if (hits[i].dev == dev && hits[i].M == a.M && hits[i].N == a.N && hits[i].K == a.K && hits[i].split == split) h = &hits[i];
+        if (h && h->slab == slab_of_device(dev)) {
+            sc = h->s;
+        } else {
+            SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, sc));
+            if (!h && n_hits < 16) h = &hits[n_hits++];
+            if (h) *h = Hit{dev, a.M, a.N, a.K, split, slab_of_device(dev), sc};
+        }
+    }
     auto kern = gemm_ph8_kernel<EPI, DBG>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     unsigned long long* ts = nullptr;
@@ -848,15 +939,22 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
         ts = g_ts_buf;
     }
 #endif
+    sc.dump = (EPI == EPI_F32 && sc.sk_slab != nullptr) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(sc.G), dim3(512), LDS, stream, a, sc, ts);
+    if (sc.dump && sc.any_split) hipLaunchKernelGGL(ph8_reduce_f32_kernel, dim3(sc.sk_tiles * 8), dim3(512), 0, stream, a, sc);
     SAT_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
 
+// whether the launcher's automatic choice of the 256 x 256 tile should land here (a forced variant 80 always does)
 bool sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
     if (a.fp8 || a.H8 || a.N % 256 || a.K % 128 || (uint64_t)a.M * (uint64_t)a.K * 2u >= (1ull << 31)) return false;
+    // fp32-output GEMMs with a short reduction (to_out, cross to_out: K = 1536) spend a third of their time in the residual
+    // read-modify-write at HBM speed; persistent workgroups run those epilogues in lockstep, the 16-wave tile's independent workgroups
+    // drift apart and overlap them with other tiles' main loops: measured 111 us against 122 at 8 prompts (profiles/r03_ph8_streamk.txt)
+    if ((epi == EPI_F32 || epi == EPI_RESID) && a.K < 4096) return false;
     if (epi == EPI_HEADS) return (a.heads.heads * 64) % 256 == 0;
     return true;
 }

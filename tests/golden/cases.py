@@ -56,6 +56,18 @@ GEN = {
 }
 
 
+# full-size multi-step fixture (make_traj_golden.py -> traj_full.npz): 12 steps of DPM-Solver++(3M) SDE, CFG 7, noise injected
+TRAJ = dict(steps=12, sigma_min=0.3, sigma_max=500.0, cfg_scale=7.0, snapshots=(4, 8, 12))
+
+
+def traj_inputs():
+    """(cross_attn_cond, global_cond, unit initial noise, per-step unit noise) of the full-size trajectory fixture"""
+    _, _, c, g = dit_inputs(1, 1024, 768, 1536, 1)
+    noise = synthetic.synth_input("traj_noise", (1, 64, 1024), 500)
+    step_noise = [synthetic.synth_input(f"traj_sn{i}", (1, 64, 1024), 510 + i) for i in range(TRAJ["steps"])]
+    return c, g, noise, step_noise
+
+
 def dit_inputs(b, t_len, cond_dim, global_dim, seed, lc=130):
     x = synthetic.synth_input("x", (b, 64, t_len), seed)
     c = synthetic.synth_input("c", (b, lc, cond_dim), seed + 1)

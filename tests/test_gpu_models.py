@@ -541,8 +541,9 @@ def test_full_size_batch8_config3_config5(dev, full_dit, gemm_dtype):
       * batch invariance: every prompt of the batched evaluation against its own B=1 evaluation.  Not bit-equal by design: the
         key-side shift (b*S)&3 moves the attention tile boundaries per sequence, so P is rounded against a different running
         max; CFG 7 then amplifies the bf16 (e4m3) rounding noise ~7-10x exactly as it does against the oracle.
-    Gates = ~2x the values measured on MI355X (bf16: 3.7e-3 / CFG-7 batch invariance 7.8e-3; fp8: 6.7e-2 / 1.6e-1 -- e4m3 has 3
-    mantissa bits, the stated looser tolerance of config 5)."""
+    Gates = 2x the values measured on MI355X (bf16: 3.7e-3 / CFG-7 batch invariance 7.8e-3; fp8: 6.4e-2 at cfg 1, 1.8e-1 at CFG 7, batch
+    invariance 1.6e-1 -- e4m3 has 3 mantissa bits: config 5's stated tolerance is 1.3e-1 per denoiser call without CFG, 3.6e-1 with CFG 7;
+    what that does to a trajectory is pinned by test_full_size_trajectory)."""
     import cases
     bf = gemm_dtype == "bf16"
     x, t, c, g = _batch8_inputs()
@@ -552,10 +553,10 @@ def test_full_size_batch8_config3_config5(dev, full_dit, gemm_dtype):
     try:
         xd, td, cd, gd = x.to(dev), t.to(dev), c.to(dev), g.to(dev)
         got1 = full_dit(xd, td, cross_attn_cond=cd, global_embed=gd, cfg_scale=1.0)                 # M = 8200
-        e0 = assert_close(f"[{gemm_dtype}] prompt 0 of 8 vs reference (cfg 1)", got1[:1], gold["out"], 8e-3 if bf else 1.4e-1)
+        e0 = assert_close(f"[{gemm_dtype}] prompt 0 of 8 vs reference (cfg 1)", got1[:1], gold["out"], 8e-3 if bf else 1.3e-1)
         got7 = full_dit(xd, td, cross_attn_cond=cd, global_embed=gd, cfg_scale=7.0)                 # Bf = 16, M = 16400
         assert torch.isfinite(got7).all()
-        e7 = assert_close(f"[{gemm_dtype}] prompt 0 of 8 vs reference (CFG 7)", got7[:1], gold["cfg7"], 3e-2 if bf else 4e-1)
+        e7 = assert_close(f"[{gemm_dtype}] prompt 0 of 8 vs reference (CFG 7)", got7[:1], gold["cfg7"], 3e-2 if bf else 3.6e-1)
         w1 = w7 = 0.0
         for i in range(8):
             one1 = full_dit(xd[i:i + 1], td[i:i + 1], cross_attn_cond=cd[i:i + 1], global_embed=gd[i:i + 1], cfg_scale=1.0)
@@ -578,6 +579,65 @@ def test_full_size_batch8_config3_config5(dev, full_dit, gemm_dtype):
         print(f"[config {'3' if bf else '5'}] fused denoise_cfg at B=8 vs forward + scalings: {e_d:.2e}")
     finally:
         full_dit.set_gemm_dtype("bf16")
+
+
+@pytest.mark.parametrize("gemm_dtype", ["bf16", "fp8"])
+def test_full_size_trajectory(dev, full_dit, gemm_dtype):
+    """Multi-step parity at FULL size: 12 steps of DPM-Solver++(3M) SDE, sigma 500 -> 0.3, batched CFG 7, on the
+    SA-Open DiT (D = 1536, T = 1024) through the product's own `sample_k`, initial and per-step noise injected, against the CPU
+    oracle's trajectory with the SAME rounding points (tests/golden/traj_full.npz, generated by tests/golden/make_traj_golden.py:
+    fp32, bf16-matched, e4m3-matched) after 4, 8 and 12 steps.  What it pins that the single-forward tests cannot: the per-step
+    rounding noise is fed back through x and amplified by CFG 7 at every step.  Gates = ~2x the values measured on MI355X (printed)."""
+    import cases
+    import os
+    if os.environ.get("SAT_SKIP_SLOW") == "1":
+        pytest.skip("SAT_SKIP_SLOW=1")
+    path = os.path.join(cases.GOLDEN_DIR, "traj_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("traj_full.npz not generated")
+    from stable_audio_tools.inference.sampling import sample_k
+    from stable_audio_tools.models.diffusion import DiTWrapper
+    gold = cases.load("traj_full")
+    tj = cases.TRAJ
+    c, g, noise, step_noise = cases.traj_inputs()
+    wrap = DiTWrapper.__new__(DiTWrapper)          # sample_k wants the wrapper type; the full-size DiT of the fixture goes inside
+    torch.nn.Module.__init__(wrap)
+    wrap.model = full_dit
+    snaps = {}
+
+    def cb(info):
+        if info["i"] in tj["snapshots"]:           # x at the start of step i = the latents after i steps
+            snaps[info["i"]] = info["x"].clone()
+
+    it = iter(step_noise)
+    full_dit.set_gemm_dtype(gemm_dtype)
+    try:
+        x = sample_k(wrap, noise.to(dev), steps=tj["steps"], sampler_type="dpmpp-3m-sde", sigma_min=tj["sigma_min"], sigma_max=tj["sigma_max"],
+                     device=str(dev), callback=cb, noise_sampler=lambda s, sn: next(it).to(dev), cfg_scale=tj["cfg_scale"],
+                     cross_attn_cond=c.to(dev), global_cond=g.to(dev))
+    finally:
+        full_dit.set_gemm_dtype("bf16")
+    snaps[tj["steps"]] = x
+    # tolerances: (vs the matched-rounding oracle, vs the fp32 oracle) per snapshot
+    # Measured on MI355X (round 3), rel-L2 after 4 / 8 / 12 steps:
+    #   bf16: vs matched oracle 2.9e-4 / 6.5e-3 / 9.4e-3, vs fp32 oracle 3.6e-4 / 5.2e-3 / 8.1e-3 (the matched ORACLE itself is 3.7e-4 / 4.6e-3 /
+    #         7.9e-3 away from the fp32 oracle: the trajectory amplifies rounding noise chaotically, two bf16 evaluations with the same
+    #         rounding points but different summation order drift apart as fast as either drifts from fp32);
+    #   fp8 (BASELINE config 5): vs matched 8.7e-3 / 1.8e-1 / 3.7e-1, vs fp32 6.6e-3 / 1.2e-1 / 2.9e-1 (matched oracle vs fp32: 8.1e-3 / 1.1e-1 /
+    #         2.3e-1) -- the stated fidelity cost of e4m3 operands on this 12-step, CFG-7 schedule; the 4-step gate is the tight one.
+    tol = {"bf16": {4: (6e-4, 8e-4), 8: (1.3e-2, 1.1e-2), 12: (1.9e-2, 1.7e-2)},
+           "fp8": {4: (1.8e-2, 1.4e-2), 8: (3.6e-1, 2.5e-1), 12: (7.4e-1, 5.7e-1)}}[gemm_dtype]
+    msg = []
+    for i in tj["snapshots"]:
+        em = rel_l2(snaps[i], gold[f"{gemm_dtype}_step{i}"])
+        ef = rel_l2(snaps[i], gold[f"fp32_step{i}"])
+        om = rel_l2(gold[f"{gemm_dtype}_step{i}"], gold[f"fp32_step{i}"])
+        msg.append(f"after {i:2d} steps: vs matched oracle {em:.2e}, vs fp32 oracle {ef:.2e} (matched oracle vs fp32 oracle {om:.2e})")
+        assert torch.isfinite(snaps[i]).all()
+    print(f"\n[full-size trajectory, {gemm_dtype}]\n  " + "\n  ".join(msg))
+    for i in tj["snapshots"]:
+        assert_close(f"[{gemm_dtype}] latents after {i} steps vs matched oracle", snaps[i], gold[f"{gemm_dtype}_step{i}"], tol[i][0])
+        assert_close(f"[{gemm_dtype}] latents after {i} steps vs fp32 oracle", snaps[i], gold[f"fp32_step{i}"], tol[i][1])
 
 
 def test_fp32x_mode_vs_reference_golden(dev, full_dit, small_dit):

@@ -1,0 +1,39 @@
+#!/bin/bash
+# One parametrised GPU-box session (run through gpurun from the repo root):   tools/gpu_session.sh <stage> [args...]
+#   pytest [-k expr]        the -m gpu parity suite                          -> gpurun_out/${TAG}_pytest.log
+#   bench [bench.py args]   one bench line                                   -> gpurun_out/${TAG}_bench.json
+#   stats [bench.py args]   rocprofv3 --kernel-trace --stats of bench.py     -> gpurun_out/${TAG}_kernel_stats.csv + _summary.md
+#   pmc                     FETCH_SIZE / WRITE_SIZE / SQ counter passes of tools/gpu_probe.py full (separate passes, no traces)
+#   probe <sections...>     tools/ph8_probe.py sections with the experiments build
+# TAG (default r03) names the outputs.
+cd "$(dirname "$0")/.."
+R=$PWD
+mkdir -p gpurun_out
+export PYTHONPATH=$R/friendly-stable-audio-tools_amd:$PYTHONPATH
+TAG=${TAG:-r03}
+stage=$1; shift
+case $stage in
+  pytest)
+    timeout 2400 python -m pytest tests -m gpu -q -rf --no-header -p no:cacheprovider "$@" > gpurun_out/${TAG}_pytest.log 2>&1
+    echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -5 gpurun_out/${TAG}_pytest.log ;;
+  bench)
+    timeout 900 python bench.py "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-400 gpurun_out/${TAG}_bench.json ;;
+  stats)
+    cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$TAG
+    timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_stats_bench.json 2> $R/gpurun_out/${TAG}_stats.err
+    f=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1); cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv
+    python $R/tools/stats_summary.py $R/gpurun_out/${TAG}_kernel_stats.csv 2 "$TAG: bench.py $*" > $R/gpurun_out/${TAG}_kernel_stats_summary.md; head -16 $R/gpurun_out/${TAG}_kernel_stats_summary.md | cut -c1-180 ;;
+  pmc)
+    cd /tmp; export TMPDIR=/tmp
+    for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
+      tag=$(echo $pass | cut -d' ' -f1)
+      timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_pmc_$tag -- python $R/tools/gpu_probe.py full > $R/gpurun_out/${TAG}_pmc_$tag.log 2>&1
+      f=$(find $R/gpurun_out/${TAG}_pmc_$tag -name "*counter_collection.csv" | head -1)
+      python $R/tools/pmc_summarize.py $f > $R/gpurun_out/${TAG}_pmc_${tag}_per_kernel.csv
+      rm -rf $R/gpurun_out/${TAG}_pmc_$tag
+    done
+    head -4 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE_per_kernel.csv | cut -c1-200 ;;
+  probe)
+    SAT_HIP_EXP=1 timeout 900 python tools/ph8_probe.py "$@" > gpurun_out/${TAG}_probe.log 2>&1; tail -40 gpurun_out/${TAG}_probe.log ;;
+  *) echo "unknown stage $stage"; exit 2 ;;
+esac
