@@ -61,9 +61,11 @@ def main():
     fix_channels = Mono() if model.in_channels == 1 else Stereo()
     for f in files:
         audio, in_sr = load_wav(f)
-        if in_sr != sr:
-            raise NotImplementedError(f"{f}: sample rate {in_sr} != model rate {sr} (resampling needs torchaudio)")
-        audio = fix_channels(audio).unsqueeze(0).to(device)
+        audio = audio.to(device)
+        if in_sr != sr:                             # reconstruct_audios.py:33-35 of the reference (torchaudio Resample): HIP polyphase kernel
+            from stable_audio_tools.inference.resample import resample
+            audio = resample(audio, in_sr, sr)
+        audio = fix_channels(audio).unsqueeze(0)
         rec = model.reconstruct_audio(audio, chunked=True, chunk_size=chunk_size, overlap=overlap, max_batch_size=args.batch_size)
         name = os.path.basename(f)
         save_wav_float(out_dir / name, rec.squeeze(0), sr)

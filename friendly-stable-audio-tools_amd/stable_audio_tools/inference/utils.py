@@ -17,12 +17,14 @@ def set_audio_channels(audio, target_channels):
 
 
 def prepare_audio(audio, in_sr, target_sr, target_length, target_channels, device):
-    """Move to ``device``, pad / crop (from the start) to ``target_length``, lift to [B, C, T], fix the channel count."""
+    """Move to ``device``, resample to ``target_sr``, pad / crop (from the start) to ``target_length``, lift to [B, C, T], fix the channel count."""
     if target_channels not in (1, 2):
         raise AssertionError("target_channels must be 1 or 2")
-    if in_sr != target_sr:
-        raise NotImplementedError("resampling needs torchaudio, which this image does not provide; pass audio at the model sample rate")
-    fitted = PadCrop(target_length, randomize=False)(audio.to(device))
+    audio = audio.to(device)
+    if in_sr != target_sr:                      # torchaudio.transforms.Resample in the reference (utils.py:25-27): the HIP polyphase kernel
+        from .resample import resample
+        audio = resample(audio, in_sr, target_sr)
+    fitted = PadCrop(target_length, randomize=False)(audio)
     while fitted.dim() < 3:                     # [T] -> [1, 1, T]; [C, T] -> [1, C, T]
         fitted = fitted.unsqueeze(0)
     return set_audio_channels(fitted, target_channels)

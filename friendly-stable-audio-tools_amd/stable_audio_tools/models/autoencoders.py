@@ -273,8 +273,9 @@ class AudioAutoencoder(nn.Module):
             elif audio.dim() == 1:
                 audio = audio.unsqueeze(0)
             assert audio.dim() == 2, "Audio should be shape (Channels x Length) with no batch dimension"
-            if in_sr != self.sample_rate:
-                raise NotImplementedError("resampling needs torchaudio, which this image does not provide; pass audio at the model sample rate")
+            if in_sr != self.sample_rate:           # autoencoders.py:394-397 of the reference (torchaudio Resample): HIP polyphase kernel
+                from ..inference.resample import resample
+                audio = resample(audio, in_sr, self.sample_rate)
             new_audio.append(audio)
             max_length = max(max_length, audio.shape[-1])
         padded = max_length + (self.min_length - (max_length % self.min_length)) % self.min_length

@@ -342,6 +342,12 @@ int sat_t5_relative_buckets(int32_t l, int32_t num_buckets, int32_t max_distance
 int sat_snake_beta(const float* x_dev, const float* alpha_dev, const float* beta_dev, float* y_dev,
                    int32_t b, int32_t c, int32_t t, sat_stream_t stream);
 
+/* Sample-rate conversion, polyphase windowed-sinc FIR = torchaudio.transforms.Resample with its defaults (inference/utils.py:25-27,
+ * models/autoencoders.py:394-397, reconstruct_audios.py:34-35 of the reference).  x [rows, in_len] fp32 -> y [rows, out_len] fp32,
+ * out_len <= ceil(in_len * new / orig); orig / new are the two rates divided by their gcd; bank [new, 2 * width + orig] fp32 is the
+ * filter bank (row p = output phase p; built on the host, stable_audio_tools/inference/resample.py: sinc_resample_bank). */
+int sat_resample_sinc(const float* x_dev, const float* bank_dev, float* y_dev, int32_t rows, int32_t in_len, int32_t out_len,
+                      int32_t orig, int32_t new_rate, int32_t width, sat_stream_t stream);
 /* Windowed overlap-add of the chunked codec paths, AudioAutoencoder.encode_audio / decode_audio / reconstruct_audio
  * (models/autoencoders.py:476-497, 548-571, 622-645): pieces_dev [batch, n_chunk, channels, chunk_len], chunk i placed at i * hop,
  * faded in / out over `overlap` samples with window_dev [2 * overlap] (torch.bartlett_window(2 * overlap)) except at the outer
