@@ -495,8 +495,9 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
                   "dit_plan_create: dim_heads must be 64 (embed_dim %d, heads %d)", cfg->embed_dim, cfg->num_heads);
     SAT_CHECK_ARG(cfg->embed_dim % 128 == 0 && cfg->embed_dim <= 2048, SAT_E_UNSUPPORTED,
                   "dit_plan_create: embed_dim %d must be a multiple of 128 and <= 2048", cfg->embed_dim);
-    SAT_CHECK_ARG(cfg->io_channels > 0 && cfg->io_channels <= 64, SAT_E_UNSUPPORTED, "dit_plan_create: io_channels %d not in 1..64",
-                  cfg->io_channels);
+    // (the input / output projection kernels move 4 channels per lane: glue_output_proj checks the same at forward time)
+    SAT_CHECK_ARG(cfg->io_channels > 0 && cfg->io_channels <= 64 && cfg->io_channels % 4 == 0, SAT_E_UNSUPPORTED,
+                  "dit_plan_create: io_channels %d must be a multiple of 4 in 4..64", cfg->io_channels);
     SAT_CHECK_ARG(cfg->depth > 0 && cfg->max_seq_len > 0, SAT_E_INVALID, "dit_plan_create: depth/max_seq_len must be positive");
     if (cfg->cond_token_dim > 0) {
         SAT_CHECK_ARG(cfg->cond_embed_dim % 64 == 0 && cfg->cond_embed_dim > 0 && cfg->cond_token_dim % 4 == 0, SAT_E_UNSUPPORTED,

@@ -136,7 +136,12 @@ def main():
     if model.conditioner is not None:
         model.conditioner.set_device(str(device))      # what generate_diffusion_cond does first (generation.py:125); needed by encoders here
     # ids the diffusion model consumes but the conditioner cannot produce here (text / audio encoders): fail before any work is done
-    needs_text = any(k not in model.conditioner.conditioners for k in model.cross_attn_cond_ids)
+    have = model.conditioner.conditioners if model.conditioner is not None else {}
+    missing = [k for k in model.cross_attn_cond_ids if k not in have]
+    if any(k != "prompt" for k in missing):
+        raise SystemExit(f"generate.py: the model consumes cross-attention conditioning {missing} that no registered conditioner produces; "
+                         f"--text-embeds only supplies the 'prompt' id (other encoders, e.g. CLAP, are outside this build)")
+    needs_text = bool(missing)
     embed_of = text_embed_source(args, cond_dim) if needs_text else None
 
     conds = flatten_conditions(yaml.safe_load(open(args.cond_yaml_path)))

@@ -24,7 +24,13 @@ def fast_scandir(directory, ext, keywords=None):
     exts = {e.lower() if e.startswith(".") else "." + e.lower() for e in ext}
     keywords = [k.lower() for k in keywords] if keywords else None
     folders, files = [], []
-    for root, dirs, names in os.walk(directory):
+    seen = set()                      # real paths already walked: symlinked sub-folders are followed (as os.scandir + is_dir() does), cycles are not
+    for root, dirs, names in os.walk(directory, followlinks=True):
+        real = os.path.realpath(root)
+        if real in seen:
+            dirs[:] = []
+            continue
+        seen.add(real)
         folders += [os.path.join(root, d) for d in dirs]
         files += [os.path.join(root, n) for n in names if _wanted(n, exts, keywords)]
     return folders, files

@@ -115,9 +115,13 @@ class T5Conditioner(Conditioner):
     def cached_locally(cls, t5_model_name: str) -> bool:
         """True when tokenizer and encoder weights of ``t5_model_name`` can be loaded without a download."""
         try:
-            from transformers import AutoConfig
+            from huggingface_hub import try_to_load_from_cache
+            from transformers import AutoConfig, AutoTokenizer
             AutoConfig.from_pretrained(t5_model_name, local_files_only=True)
-            return True
+            AutoTokenizer.from_pretrained(t5_model_name, local_files_only=True)
+            # a cache that holds only config.json would register the conditioner and then fail at the first forward: probe the weights
+            return any(isinstance(try_to_load_from_cache(t5_model_name, f), str)
+                       for f in ("model.safetensors", "pytorch_model.bin", "model.safetensors.index.json", "pytorch_model.bin.index.json"))
         except Exception:
             return False
 
@@ -213,6 +217,8 @@ class T5Conditioner(Conditioner):
         need = ctypes.c_size_t()
         _hip.check(lib.sat_t5_workspace_bytes(plan, b, l, ctypes.byref(need)))
         ws = self.__dict__["_ws"]
+        if dev.index is None:                      # torch.device("cuda") != tensor.device ("cuda:0"): compare resolved devices
+            dev = torch.device(dev.type, torch.cuda.current_device())
         if ws is None or ws.numel() < need.value or ws.device != dev:
             ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
             self.__dict__["_ws"] = ws

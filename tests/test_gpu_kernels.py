@@ -233,6 +233,51 @@ def test_ln_fold_swiglu(dev, prod, cons, m):
     assert_close("ln-fold swiglu vs fp32 LayerNorm + Linear", out, val * F.silu(gate), 1e-2)
 
 
+@pytest.mark.parametrize("row_mean,outlier", [(0.0, 0.0), (8.0, 0.0), (30.0, 0.0), (0.0, 60.0)])
+def test_ln_fold_rows_with_common_mode(dev, row_mean, outlier):
+    """the fold feeds un-normalised bf16(x) to the MFMA and subtracts mean * c1 afterwards, so its rounding error scales with
+    |x| instead of |x - mean|: rows with a common-mode offset (or a few outlier channels -- real checkpoints have both) lose precision
+    by ~sqrt(1 + mean^2 / var).  This test measures that on a residual stream with a chosen row mean / outlier channel, for the fold
+    AND for the three-kernel plan (`set_layernorm_fusion(False)`: layernorm_kernel -> bf16 -> GEMM), against the fp32 reference
+    LayerNorm -> Linear -> SwiGLU, and gates the fold at the predicted noise ratio (2x headroom)."""
+    _hip, lib = _lib()
+    m, d, inner = 300, 768, 768
+    x = _rand((m, d), 90) + row_mean
+    if outlier:
+        x[:, 5] += outlier
+        x[:, 300] -= outlier
+    w = _rand((2 * inner, d), 91) * 0.08
+    gamma = 0.8 + 0.2 * _rand((d,), 92)
+    beta = 0.1 * _rand((d,), 93)
+    bias = 0.1 * _rand((2 * inner,), 94)
+    val, gate = F.linear(F.layer_norm(x, (d,), gamma, beta, eps=1e-5), w, bias).chunk(2, dim=-1)
+    want = val * F.silu(gate)
+    xd, wd, gd, bd, bbd = x.to(dev), w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev)
+    # fold: bf16 image + partial statistics (what a producer epilogue writes), then the consumer
+    xb = xd.to(torch.bfloat16)
+    blocks = xb.float().view(m, d // 64, 64)
+    part = torch.stack([blocks.sum(-1), (blocks * blocks).sum(-1)], -1).contiguous()
+    wp = torch.empty((2 * inner, d), dtype=torch.bfloat16, device=dev)
+    c12 = torch.empty((4 * inner,), dtype=torch.float32, device=dev)
+    out_f = torch.full((m, inner), float("nan"), dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(bbd), _hip.ptr(wp),
+                                           _hip.ptr(c12), _hip.ptr(out_f), m, 2 * inner, d, 0, _hip.stream()))
+    # three-kernel plan: LayerNorm kernel (fp32 statistics of the fp32 rows, bf16 output) -> SwiGLU GEMM
+    y = torch.empty((m, d), dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_layernorm_bf16(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(y), m, d, _hip.stream()))
+    wp2 = torch.empty((2 * inner, d), dtype=torch.bfloat16, device=dev)
+    bp2 = torch.empty((2 * inner,), dtype=torch.float32, device=dev)
+    out_s = torch.full((m, inner), float("nan"), dtype=torch.bfloat16, device=dev)
+    _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(y), _hip.ptr(wd), _hip.ptr(bbd), _hip.ptr(wp2), _hip.ptr(bp2), _hip.ptr(out_s), m, 2 * inner, d, 0,
+                                        _hip.stream()))
+    e_f, e_s = rel_l2(out_f, want), rel_l2(out_s, want)
+    var = x.var(-1, unbiased=False).mean().item()
+    ratio = (1.0 + (x.mean(-1) ** 2).mean().item() / var) ** 0.5 if not outlier else (x.pow(2).mean().item() / _rand((m, d), 90).var().item()) ** 0.5
+    print(f"\n[ln-fold common mode] row mean {row_mean}, outlier {outlier}: fold {e_f:.2e}, three-kernel plan {e_s:.2e}, predicted noise ratio {ratio:.1f}")
+    assert e_s <= 1e-2, f"three-kernel plan: {e_s:.3e}"
+    assert e_f <= 1e-2 * max(1.0, ratio) * 2, f"fold: {e_f:.3e} exceeds 2 x 1e-2 x the predicted ratio {ratio:.1f}"
+
+
 @pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
 @pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (0, 0), (80, 80), (16, 80), (80, 15), (80 | 0x10000, 80 | 0x10000)])
 def test_ln_fold_qkv_rope(dev, prod, cons, s, s_pad):
