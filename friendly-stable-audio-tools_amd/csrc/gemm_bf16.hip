@@ -1298,7 +1298,17 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         // workgroups), to_out / FF-out 128x128 (204) and the cross-attention projections (M = 1025) 128x64 (216); from 4 prompts on
         // everything takes the 256x256 tile.
         if (a.K >= 192) {
-            const double s256 = score(256, 256, 1.0), s192 = score(256, 192, 0.95), s128 = score(128, 128, 0.7), s64 = score(128, 64, 0.6);
+            // The 256 x 256 tile is the 8-phase kernel where it applies; its rate relative to the 16-wave tile, measured at 8 prompts
+            // (profiles/r03_ph8_streamk.txt): SwiGLU 1.26, heads 1.07, fp32 output with a long reduction 1.02 -- and with the K-split of the
+            // remainder round (sat_gemm_ph8_splits) the last round costs ~0.35 of a round instead of 1.
+            double s256 = score(256, 256, 1.0);
+            if (g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) {
+                const double rate = EPI == EPI_SWIGLU ? 1.26 : EPI == EPI_HEADS ? 1.07 : 1.02;
+                const long t = (long)cdiv(a.M, 256) * (a.N / 256);
+                const double rounds = sat_gemm_ph8_splits(EPI, a) ? (double)(t / 256) + 0.35 : (double)((t + 255) / 256);
+                s256 = rate * (double)t / (rounds * 256.0);
+            }
+            const double s192 = score(256, 192, 0.95), s128 = score(128, 128, 0.7), s64 = score(128, 64, 0.6);
             const double best = s256 > s192 ? (s256 > s128 ? s256 : s128) : (s192 > s128 ? s192 : s128);
             if (best == 0.0 && s64 == 0.0) v = 15;      // N is not a tile multiple: let the launcher report it
             else if (s64 > best) v = 16;

@@ -773,6 +773,17 @@ struct DevState {
 std::mutex g_sched_mu;
 std::map<int, DevState> g_dev;
 
+// Measured policy (profiles/r03_ph8_streamk.txt): split only fp32-output GEMMs with a long reduction (K >= 4096: FF-out) behind at
+// least one whole round, and only when every remainder tile gets >= 2 parts (otherwise the whole tiles set the makespan and the slab
+// traffic -- 2 x 256 KiB per part at HBM speed, everybody at the same time -- is pure loss): SA-2.0 FF-out -25 %.  8 prompts (134
+// remainder tiles on 256 CUs) and every K = 1536 GEMM stay whole; below one whole round the 128 x 128 tiles of gemm_bf16.hip are
+// faster (FF-out at 1 prompt: 60 us against 67).
+bool ph8_auto_split(const GemmArgs& a, bool epi_f32, int cus) {
+    const long t_all = (long)cdiv(a.M, 256) * (a.N / 256);
+    const long rem = t_all % cus;
+    return epi_f32 && a.K >= 4096 && t_all > cus && rem > 0 && 2 * rem <= cus;
+}
+
 // split: 0 = the remainder round's tiles stay whole (one per workgroup, light tiles last), 1 = the remainder round is split along K,
 // -1 = the measured policy below
 int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, Ph8Sched& out) {
@@ -781,19 +792,7 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, Ph8Sched& out) {
     std::lock_guard<std::mutex> lock(g_sched_mu);
     DevState& d = g_dev[dev];
     if (!d.cus) SAT_HIP(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (split < 0) {
-        // Measured policy (profiles/r03_ph8_streamk.txt): split only fp32-output GEMMs with a long reduction (K >= 4096: FF-out) behind
-        // at least one whole round, and only when every remainder tile gets >= 2 parts (otherwise the whole tiles set the makespan and
-        // the slab traffic -- 2 x 256 KiB per part at HBM speed, everybody at the same time -- is pure loss): SA-2.0 FF-out -25 %.
-        // 8 prompts (134 remainder tiles on 256 CUs) and every K = 1536 GEMM stay whole; below one whole round the 128 x 128 tiles of
-        // gemm_bf16.hip are faster (FF-out at 1 prompt: 60 us against 67).
-        const int tm = cdiv(a.M, 256), tail_ = a.M % 256;
-        const long lights = (tail_ != 0 && tail_ <= 64 && tm > 1) ? a.N / 256 : 0;
-        const long t_all_ = (long)tm * (a.N / 256);
-        const long rem = t_all_ % d.cus;
-        split = (epi_f32 && a.K >= 4096 && t_all_ > d.cus && rem > 0 && 2 * rem <= d.cus) ? 1 : 0;
-        (void)lights;
-    }
+    if (split < 0) split = ph8_auto_split(a, epi_f32, d.cus) ? 1 : 0;
     auto key = std::make_tuple(a.M, a.N, a.K, split);
     auto it = d.shapes.find(key);
     if (it != d.shapes.end()) {
@@ -967,6 +966,10 @@ extern "C" int sat_gemm_ph8_timestamps(unsigned long long* out_host) {
     return 0;
 }
 #endif
+
+bool sat_gemm_ph8_splits(int epi, const GemmArgs& a) {
+    return ph8_auto_split(a, epi == EPI_F32 || epi == EPI_RESID, 256);
+}
 
 int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
     const int dbg = (a.variant & 0xfff) / 100;

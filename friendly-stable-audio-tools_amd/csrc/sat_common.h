@@ -249,6 +249,7 @@ struct GemmArgs {
 
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream);
 bool sat_gemm_ph8_supports(int epi, const GemmArgs& a);
+bool sat_gemm_ph8_splits(int epi, const GemmArgs& a);       // the automatic schedule would split the remainder round along K
 int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream);     // gemm_ph8.hip: the 8-wave / 8-phase 256x256 tile
 int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s);
 // adaLN: y = LN(x) * scale1p[b] + shift[b] with b = row / rows_per_seq and per-sequence vectors ld apart (transformer.py:671-672)

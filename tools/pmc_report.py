@@ -1,6 +1,6 @@
-"""Per-kernel PMC CSVs (tools/pmc_summarize.py output of the three passes of tools/gpu_run_final.sh) -> the committed artefacts:
+"""Per-kernel PMC CSVs (tools/pmc_summarize.py output of the three passes of `tools/gpu_session.sh pmc`) -> the committed artefacts:
    profiles/<tag>_pmc_fetch_write_per_kernel.csv, profiles/<tag>_pmc_sq_summary.md, profiles/<tag>_ffn_traffic.json.
-usage: python tools/pmc_report.py <tag> <dir with r2_pmc_*_per_kernel.csv>"""
+usage: python tools/pmc_report.py <tag> <dir with <tag>_pmc_*_per_kernel.csv>"""
 import csv
 import json
 import os
@@ -11,7 +11,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name):
-    return {r["kernel"]: r for r in csv.DictReader(open(os.path.join(src, f"r2_pmc_{name}_per_kernel.csv")))}
+    return {r["kernel"]: r for r in csv.DictReader(open(os.path.join(src, f"{tag}_pmc_{name}_per_kernel.csv")))}
 
 
 fetch, write, sq = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ_VALU_MFMA_BUSY_CYCLES")
@@ -23,7 +23,7 @@ with open(os.path.join(root, "profiles", f"{tag}_pmc_fetch_write_per_kernel.csv"
 
 lines = [f"# {tag} -- SQ / GRBM counters per kernel: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
          "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -- python tools/gpu_probe.py full` (12 CFG denoiser steps + "
-         "4 decodes, 1 prompt, bf16, LayerNorm fold on; tools/gpu_run_final.sh)", "",
+         "4 decodes, 1 prompt, bf16, LayerNorm fold on; tools/gpu_session.sh pmc)", "",
          "Derived per launch: busy cycles per shader engine = SQ_BUSY_CYCLES / 32; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy "
          "cycles per SE); wave-time split = SQ_WAIT_ANY (parked at s_waitcnt / s_barrier), SQ_WAIT_INST_ANY (ready, pipe busy / dependency), "
          "SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES.", "",
@@ -37,7 +37,7 @@ for k, r in sorted(sq.items(), key=lambda kv: -float(kv[1]["SQ_BUSY_CYCLES"]) * 
                  f"{100 * float(r['SQ_WAIT_ANY']) / wc:.1f} | {100 * float(r['SQ_WAIT_INST_ANY']) / wc:.1f} | {100 * float(r['SQ_ACTIVE_INST_ANY']) / wc:.1f} |")
 open(os.path.join(root, "profiles", f"{tag}_pmc_sq_summary.md"), "w").write("\n".join(lines) + "\n")
 
-ffn = [k for k in fetch if "gemm_pipe_kernel<256, 256, 64, 4, 4, 2, 2, 0, 0>" in k]
+ffn = [k for k in fetch if "gemm_ph8_kernel<2, 0>" in k] or [k for k in fetch if "gemm_pipe_kernel<256, 256, 64, 4, 4, 2, 2" in k]
 if ffn:
     k = ffn[0]
     fk, wk = float(fetch[k]["FETCH_SIZE"]), float(write[k]["WRITE_SIZE"])
@@ -46,7 +46,9 @@ if ffn:
                "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (counters only, with --kernel-trace) over `tools/gpu_probe.py "
                        "full` (12 CFG denoise steps, 1 prompt, M=2050 N=12288 K=1536, LayerNorm fold on: A = the bf16 image of the residual stream); "
                        "FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM (gfx950 reports half of a wide coalesced read stream); WRITE_SIZE as "
-                       "reported (= the 25.2 MB bf16 output).  Fabric-side bytes: most of the excess over the algorithmic 69.2 MB is the A panel "
-                       "re-read by each of the 8 XCD L2s and W panels evicted from a 4 MiB L2 between uses; the 256 MiB Infinity Cache absorbs them."},
+                       "reported (= the 25.2 MB bf16 output).  Fabric-side bytes: the excess over the algorithmic 69.2 MB is what 8 private L2s cost -- "
+                       "per round every XCD's 32 concurrent tiles (8 row tiles x 4 column tiles) pull 8 A panels + 4 W panels = 9.4 MB through its "
+                       "own L2, 8 XCDs x 1.69 rounds = 127 MB, + 25 MB written = 152 MB expected, matching the measurement; the 6.3 MB A operand does "
+                       "not fit a 4 MiB L2 next to the W stream, so it is re-fetched (from the 256 MiB Infinity Cache) every round."},
               open(os.path.join(root, "profiles", f"{tag}_ffn_traffic.json"), "w"), indent=1)
     print("FF-in traffic per launch: %.1f MB" % ((2 * fk + wk) * 1024 / 1e6))
