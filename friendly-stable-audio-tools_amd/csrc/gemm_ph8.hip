@@ -10,17 +10,21 @@
 //     two K-tiles are resident (128 KiB ring); rows are 128 B with the 16-byte chunk XOR ((row >> 1) & 7), applied on the
 //     SOURCE side of the LDS-DMA (buffer_load_dwordx4 ... lds writes lane-linear), so ds_read_b128 fragment reads are
 //     conflict-free;
-//   * a K-tile is four PHASES, one 64 x 32 quadrant of the wave tile (16 MFMAs) each:
-//         phase 0: read W-lo (4) + A-lo (8) fragments   -> A-lo x W-lo        phase 2: read A-hi (8)  -> A-hi x W-hi
-//         phase 1: read W-hi (4)                        -> A-lo x W-hi        phase 3: nothing        -> A-hi x W-lo
-//     every phase is { ds_reads ; one half-tile of LDS-DMA (2 instructions per wave) ; s_barrier ; lgkmcnt(0) ; 16 MFMA ; s_barrier };
+//   * a K-tile is TWO PHASES of 32 MFMAs (two 64 x 32 quadrants of the wave tile each), four barriers per K-tile:
+//         phase A: read W-lo, W-hi (4 + 4) and A-lo (8) fragments; issue W-hi, A-hi of tile t + 1   -> A-lo x W-lo, A-lo x W-hi
+//         phase B: read A-hi (8);                                  issue W-lo, A-lo of tile t + 2   -> A-hi x W-hi, A-hi x W-lo
+//     every phase is { ds_reads ; two half-tiles of LDS-DMA (4 instructions per wave) ; counted vmcnt ; lgkmcnt(0) ; s_barrier ;
+//     32 MFMA ; s_barrier };
 //   * the two wave rows run staggered by one barrier (wave row 1 passes one extra s_barrier up front), so on every SIMD one
 //     wave is in its MFMA section while its partner reads fragments and issues DMA;
-//   * half-tile h = 4 t + j is issued in phase h - 7 (seven half-tiles ahead); the only vector-memory wait of the loop is one
-//     COUNTED s_waitcnt vmcnt(6) in phase 3 of every K-tile (three half-tiles stay in flight across the barriers), and the
-//     K-tile it retires is first read one phase later.  Restaging is WAR-safe by construction: slot j of the current buffer is
-//     rewritten in phase j + 1 -- W-lo after an lgkmcnt that retired its reads before phase 0's first barrier, the others two
-//     phases after their last read.
+//   * the only vector-memory waits of the loop are COUNTED: vmcnt(8) in phase A (A-hi of this tile has landed: W-lo, A-lo, W-hi,
+//     A-hi of the next stay in flight), vmcnt(6) in phase B (W-lo, A-lo, W-hi of the next tile have landed); a half-tile is
+//     first read one barrier after the wait that covers it.  Every load section retires its ds_reads BEFORE its barrier, so a
+//     slot may be restaged by the partner wave row in the very next interval: W-lo / A-lo / W-hi of tile t (read in phase A) are
+//     rewritten from phase B on, A-hi from phase A of tile t + 1.
+//   (The first version of this kernel ran FOUR phases of 16 MFMAs, 8 barriers per K-tile, half-tiles issued seven ahead, one
+//   vmcnt(6) per K-tile -- the schedule of the in-image guide; two phases measured +5..7 % on the SwiGLU GEMM, +3 % on fp32 output
+//   (profiles/r03_ph8_two_phases.txt).  It is kept as `main_loop` for A/B, variant bit 18, experiments build.)
 //   Measured in the loop: 1.36 us per K-tile on 256 CUs = 1575 TFLOP/s (profiles/r03_ph8_ksweep_fixed_overhead.txt).
 //
 // Schedule (PERSISTENT workgroups, one per CU; Ph8Sched, built on the host).  With one 136-KiB workgroup per CU nothing overlaps a
@@ -181,7 +185,7 @@ __device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[
 // section -- 5 % slower.
 // DBG 9 (experiments build): per workgroup and K-range the 100 MHz timestamps (range start, main loop done, fix-up done, epilogue
 // done) + (whole, K-tiles, last arriver) -> tools/ph8_probe.py timeline
-template <int EPI, int DBG = 0>
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1>
 __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
     [[maybe_unused]] int ts_n = 0;
     constexpr int BUF_BYTES = 65536, HALF_BYTES = 16384, RING_BYTES = 131072;
@@ -379,6 +383,90 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two wave rows: every wave is done with the ring
     };
 
+    // PH2 (experiment): the same K-tile in TWO phases of 32 MFMAs -- 4 barriers per K-tile instead of 8.
+    //   phase A: read W-lo, W-hi (4 + 4) and A-lo (8); issue W-hi, A-hi of tile t + 1; vmcnt(8): A-hi of tile t has landed
+    //            -> A-lo x W-lo, A-lo x W-hi
+    //   phase B: read A-hi (8); issue W-lo, A-lo of tile t + 2; vmcnt(6): W-lo, A-lo, W-hi of tile t + 1 have landed
+    //            -> A-hi x W-hi, A-hi x W-lo
+    // every load section retires its ds_reads BEFORE its barrier, so a slot may be restaged by the partner wave row in the very next
+    // interval; a landed half-tile is first read one barrier after the wait that covers it.
+    auto main_loop2 = [&](auto swap_c, const int kt0, const int nk, const bool q_valid0, const bool q_valid1) {
+        constexpr bool SWAP = decltype(swap_c)::value;
+        auto mfma_half = [&](int mi, int ni_first) {
+            if (!(mi ? q_valid1 : q_valid0)) return;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ni = ni_first ^ h;
+                bf16x8 (&fw)[2][2] = ni ? fwh : fwl;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[mi * 4 + f][ni * 2 + n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[n][ks], fa[f][ks], acc[mi * 4 + f][ni * 2 + n], 0, 0, 0)
+                                                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f][ks], fw[n][ks], acc[mi * 4 + f][ni * 2 + n], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // MODE 0: steady state (tiles t + 1 and t + 2 exist); 1: tile t + 1 is the range's last; 2: tile t is the last
+        // EARLY_WHI: W-hi of tile t + 2 is issued in phase B of tile t together with W-lo and A-lo (its slot is free since phase A)
+        // instead of phase A of tile t + 1: one phase more of flight time, and the DMA issues balance the ds_reads (A: 16 + 2, B: 8 + 6)
+        constexpr bool EARLY_WHI = (PH2V == 2);
+        auto k_tile2 = [&](auto buf_c, auto mode_c, int t) {
+            constexpr int BUF = decltype(buf_c)::value;
+            constexpr int MODE = decltype(mode_c)::value;
+            // ---- phase A
+            read_w(BUF, 0, fwl);
+            read_w(BUF, 1, fwh);
+            read_a(BUF, 0);
+            if constexpr (MODE <= 1) {
+                if constexpr (!EARLY_WHI) issue(2, BUF ^ 1, t + 1);
+                issue(3, BUF ^ 1, t + 1);
+                wait_vmcnt<8>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase B
+            read_a(BUF, 1);
+            if constexpr (MODE == 0) {
+                issue(0, BUF, t + 2);
+                issue(1, BUF, t + 2);
+                if constexpr (EARLY_WHI) issue(2, BUF, t + 2);
+                wait_vmcnt<EARLY_WHI ? 8 : 6>();
+            } else if constexpr (MODE == 1) {
+                wait_vmcnt<2>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        const int kt_last = kt0 + nk - 2;
+        for (int t = kt0; t < kt_last; t += 2) {
+            k_tile2(I0{}, I0{}, t);
+            k_tile2(I1{}, I0{}, t + 1);
+        }
+        k_tile2(I0{}, I1{}, kt_last);
+        k_tile2(I1{}, I2{}, kt_last + 1);
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+    };
+
     // ---- LayerNorm fold, consumer side (GemmArgs): (mean, 1/std) of the tile's 256 rows from the producer's per-64-column partial
     // sums and the tile's 256 (c1, c2) channel constants go to LDS behind the ring (two buffers: the next K-range's are written
     // while the current epilogue still reads its own).  Without the fold the same epilogues run on (0, 1), 0, bias.
@@ -419,7 +507,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue(j, 0, s.kt0);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) issue(j, 1, s.kt0 + 1);
+        for (int j = 0; j < ((PH2 && PH2V != 2) ? 2 : 3); ++j) issue(j, 1, s.kt0 + 1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LN_CONS) {
             float2* lnst = reinterpret_cast<float2*>(smem + RING_BYTES + lb * LN_BYTES);
@@ -690,8 +778,13 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         if constexpr (DBG == 9) t0 = __builtin_amdgcn_s_memrealtime();
         const int mq = cur.m0 + wr * 128;
         const bool rows_valid = mq < M;
-        if (cur.tr) main_loop(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
-        else main_loop(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+        if constexpr (PH2) {
+            if (cur.tr) main_loop2(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+            else main_loop2(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+        } else {
+            if (cur.tr) main_loop(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+            else main_loop(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+        }
         if constexpr (DBG == 9) t1 = __builtin_amdgcn_s_memrealtime();
         const bool more = next_seg(nxt);
         if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
@@ -890,7 +983,7 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, Ph8Sched& out) {
 unsigned long long* g_ts_buf = nullptr;
 #endif
 
-template <int EPI, int DBG = 0>
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1>
 int launch_ph8(const GemmArgs& a, hipStream_t stream) {
     constexpr int LDS = 131072 + 2 * 4096 + 64;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column) + ticket
     SAT_CHECK_ARG(a.N % 256 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of 256", a.N);
@@ -928,7 +1021,7 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
             if (h) *h = Hit{dev, a.M, a.N, a.K, split, slab_of_device(dev), sc};
         }
     }
-    auto kern = gemm_ph8_kernel<EPI, DBG>;
+    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     unsigned long long* ts = nullptr;
 #ifdef SAT_GEMM_EXPERIMENTS
@@ -977,16 +1070,25 @@ int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
         case EPI_F32:
         case EPI_RESID:
             switch (dbg) {
-                case 0: return launch_ph8<EPI_F32>(a, stream);
+                case 0:
 #ifdef SAT_GEMM_EXPERIMENTS
-                case 1: return launch_ph8<EPI_F32, 1>(a, stream);
-                case 2: return launch_ph8<EPI_F32, 2>(a, stream);
-                case 3: return launch_ph8<EPI_F32, 3>(a, stream);
+                    if (a.variant & 0x40000) return launch_ph8<EPI_F32, 0, false>(a, stream);          // bit 18: the four-phase loop (A/B)
+                    if (a.variant & 0x80000) return launch_ph8<EPI_F32, 0, true, 2>(a, stream);        // bit 19: W-hi issued one phase earlier
+#endif
+                    return launch_ph8<EPI_F32>(a, stream);
+#ifdef SAT_GEMM_EXPERIMENTS
+                case 1: return launch_ph8<EPI_F32, 1, false>(a, stream);
+                case 2: return launch_ph8<EPI_F32, 2, false>(a, stream);
+                case 3: return launch_ph8<EPI_F32, 3, false>(a, stream);
                 case 9: return launch_ph8<EPI_F32, 9>(a, stream);
 #endif
             }
             break;
         case EPI_SWIGLU:
+#ifdef SAT_GEMM_EXPERIMENTS
+            if (dbg == 0 && (a.variant & 0x40000)) return launch_ph8<EPI_SWIGLU, 0, false>(a, stream);
+            if (dbg == 0 && (a.variant & 0x80000)) return launch_ph8<EPI_SWIGLU, 0, true, 2>(a, stream);
+#endif
             if (dbg == 0) return launch_ph8<EPI_SWIGLU>(a, stream);
 #ifdef SAT_GEMM_EXPERIMENTS
             if (dbg == 9) return launch_ph8<EPI_SWIGLU, 9>(a, stream);

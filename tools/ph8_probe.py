@@ -64,7 +64,7 @@ def arms_bench(label, m, n, k, variants, rounds=5, iters=10, blas=True, scale_w=
     c = torch.zeros(m, n, device=dev)
     fs = {}
     for v in variants:
-        fs[f"v{v & 0xffff}" + (f"o{v >> 16}" if v >> 16 else "")] = gemm_fn(a, w, c, m, n, k, v)
+        fs[f"v{v & 0xffff}" + (f"+{v >> 16:x}" if v >> 16 else "")] = gemm_fn(a, w, c, m, n, k, v)
     if blas:
         wt = w.t()
         out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
@@ -253,6 +253,54 @@ def timeline():
                 x = tt[sel]
                 print(f"  {lab:22s} n={int(sel.sum()):4d}  K-tiles {np.median(v[sel, 5]):5.1f}  main {np.median(x[:,1]-x[:,0]):6.2f} us  prepare+fixup {np.median(x[:,2]-x[:,1]):6.2f} (p90 {np.percentile(x[:,2]-x[:,1],90):6.2f})"
                       f"  epilogue {np.median(x[:,3]-x[:,2]):6.2f} (p90 {np.percentile(x[:,3]-x[:,2],90):6.2f})  end at {np.median(x[:,3]):6.1f} (max {x[:,3].max():6.1f})", flush=True)
+
+
+def ph2():
+    """A/B of the shipped two-phase K-tile (32 MFMAs per phase, 4 barriers) against a variant selected by PH2_BIT: 0x40000 = the first
+    version's four phases of 16 MFMAs (8 barriers), 0x80000 = W-hi issued one phase earlier"""
+    V2 = 80 | (int(os.environ.get("PH2_BIT", "0x40000"), 16))          # bit 18: the four-phase loop; bit 19: W-hi issued one phase earlier
+    for (m, n, k) in [(256, 256, 256), (512, 512, 512), (300, 512, 384), (2050, 1536, 1536), (257, 768, 6144)]:
+        check(m, n, k, V2)
+    for (m, n, k) in [(512, 512, 512), (4096, 4096, 4096), (2050, 12288, 1536)]:
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        As = [torch.randn(m, k, device=dev).to(torch.bfloat16), (torch.randn(m, k, device=dev) * 2 + 0.5).to(torch.bfloat16)]
+        first, diff = [None, None], 0
+        for i in range(40):
+            c = torch.full((m, n), float("nan"), device=dev)
+            gemm_fn(As[i & 1], w, c, m, n, k, V2)()
+            if first[i & 1] is None:
+                first[i & 1] = c
+            else:
+                diff += int(not torch.equal(c, first[i & 1]))
+        print(f"race(ph2) M={m} N={n} K={k}: {diff} of 38 repeats differ", flush=True)
+    for name, m, n, k in [("4096^3", 4096, 4096, 4096), ("1 round K=1536", 2048, 8192, 1536), ("ff_out B8", 16400, 1536, 6144), ("f32 ff_in-shape B8", 16400, 12288, 1536)]:
+        arms_bench("ph2 " + name, m, n, k, [80, V2], blas=False, rounds=5)
+    # SwiGLU + LayerNorm fold at the plan's shapes
+    for name, m in [("B1", 2050), ("B8", 16400)]:
+        n, k = 12288, 1536
+        xb = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        part = torch.stack([xb.float().view(m, k // 64, 64).sum(-1), (xb.float() ** 2).view(m, k // 64, 64).sum(-1)], -1).contiguous()
+        w = torch.randn(n, k, device=dev) * 0.05
+        gamma = 0.8 + 0.2 * torch.rand(k, device=dev)
+        beta = 0.1 * torch.randn(k, device=dev)
+        bias = torch.randn(n, device=dev) * 0.1
+        wp = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
+        c12 = torch.empty((2 * n,), dtype=torch.float32, device=dev)
+        outs = {}
+        res = {80: [], V2: []}
+        for v in res:
+            out = torch.empty((m, n // 2), dtype=torch.bfloat16, device=dev)
+            _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(bias), _hip.ptr(wp),
+                                                   _hip.ptr(c12), _hip.ptr(out), m, n, k, v, _hip.stream()))
+            outs[v] = out
+        print(f"ph2 swiglu {name}: outputs equal: {torch.equal(outs[80], outs[V2])}")
+        out = outs[80]
+        for _ in range(5):
+            for v in res:
+                res[v].append(timeit(lambda: _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(bias),
+                                                                                   _hip.ptr(wp), _hip.ptr(c12), _hip.ptr(out), m, n, k, v | 0x4000, _hip.stream())), iters=10, warm=2))
+        a, b = statistics.median(res[80]), statistics.median(res[V2])
+        print(f"ph2 swiglu+ln {name}: v80 {a*1e3:.1f} us  v80+{V2 >> 16:x} {b*1e3:.1f} us  x{a/b:.3f}", flush=True)
 
 
 def ablate():
