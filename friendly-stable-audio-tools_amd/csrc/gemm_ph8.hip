@@ -138,16 +138,21 @@ __device__ __forceinline__ void ph8_tile_of(const Ph8Sched& sc, int id, int& tm,
 // fp32 output / residual update of ONE token row piece (transformer.py:692-700), adaLN gate (:674, 688), and the producer side of the
 // LayerNorm fold: bf16 image of the updated row + (sum, sum of squares) of the ROUNDED values over the wave's 64-column block.
 // v[nb] = the accumulators of channels ncol0 + 16 nb + 4 q4 .. + 3 of token row m (lane (l15, q4) of a transposed 16 x 16 block).
-__device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[4], const f32x4_t (&bia)[4], int m, int ncol0, int q4) {
+// `old` = the residual values of the same pieces, loaded by the caller in batches (ph8_load_resid): one load -> use -> store round trip
+// per row block would serialise eight memory latencies per tile (measured: 17 us of epilogue per tile at 8 prompts).
+__device__ __forceinline__ void ph8_load_resid(const GemmArgs& g, f32x4_t (&old)[4], int m, int ncol0, int q4) {
+    const int mc = m < g.M ? m : g.M - 1;
+    const float* __restrict__ crow = g.C + (size_t)mc * g.ldc + ncol0 + 4 * q4;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) old[nb] = g.accumulate ? *reinterpret_cast<const f32x4_t*>(crow + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[4], const f32x4_t (&old)[4], const f32x4_t (&bia)[4], int m, int ncol0,
+                                                int q4) {
     const int M = g.M, N = g.N;
-    const bool accum = g.accumulate != 0;
     const bool prod = g.xb != nullptr;
     const int mc = m < M ? m : M - 1;
     float* __restrict__ crow = g.C + (size_t)mc * g.ldc + ncol0 + 4 * q4;
     const float* grow = g.gate ? g.gate + (size_t)(mc / g.gate_rows) * g.gate_ld + ncol0 + 4 * q4 : nullptr;
-    f32x4_t old[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) old[nb] = accum ? *reinterpret_cast<const f32x4_t*>(crow + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     float sum = 0.f, sq = 0.f;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -559,7 +564,13 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
             for (int nb = 0; nb < 4; ++nb)
                 bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mb = 0; mb < 8; ++mb) ph8_epi_f32_row(g, acc[mb], bia, mrow0 + mb * 16, ncol0, q4);
+            for (int h = 0; h < 4; ++h) {          // four batches of two row blocks: 8 residual loads in flight (a batch of four spills)
+                f32x4_t old[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ph8_load_resid(g, old[i], mrow0 + (h * 2 + i) * 16, ncol0, q4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ph8_epi_f32_row(g, acc[h * 2 + i], old[i], bia, mrow0 + (h * 2 + i) * 16, ncol0, q4);
+            }
         } else if constexpr (EPI == EPI_SWIGLU) {
             // H = (v + b_v) * silu(gate + b_g) (transformer.py:232-235): value rows are channels [0, 32) of the wave's 64, gate rows
             // [32, 64) (pack_rows interleave); PERM 1 puts value and gate of hidden columns hc0 + 8 q4 + 4 nf + r into this lane
@@ -758,6 +769,9 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
     // ---- the persistent loop
     Seg cur, nxt;
     if (!next_seg(cur)) return;
+    // (Starting the workgroups (i & 3) * {2, 4, 6} us apart, so that the fp32 epilogues of a round do not hit the memory system at the
+    // same moment, only adds the delay: profiles/r03_ph8_stagger_negative.txt -- the 17-us epilogue of a 256 x 256 fp32 tile is bound
+    // per CU, not by the sum.)
     int lb = 0;
     prepare(cur, lb);
     while (true) {
@@ -846,7 +860,9 @@ __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sche
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
         bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-    ph8_epi_f32_row(g, v, bia, m, ncol0, q4);
+    f32x4_t old[4];
+    ph8_load_resid(g, old, m, ncol0, q4);
+    ph8_epi_f32_row(g, v, old, bia, m, ncol0, q4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
