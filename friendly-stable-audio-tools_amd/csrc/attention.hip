@@ -53,7 +53,10 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_run, unsigned& hi_run) 
 // scale per 32 channels = half a head at `out_scales` [B*Sq][H*2]) instead of bf16
 // DBG (experiments build only, wrong results): 1 no exp / max / sum (P = bf16(S)); 2 no LDS-DMA in the loop; 3 no MFMA; 4 = 2 + no
 // barrier; 5 = 4 + K / V^T fragments read from LDS once
-template <bool MX8, int DBG = 0>
+// NGRP: 2 = the layout above (128 queries x 2 key ranges); 1 = 256 queries per workgroup, every wave walks ALL the KV tiles of one shared
+// ring (long sequences / many sequences: half the LDS-DMA and K / V^T traffic per query, no merge; chosen by the launcher when the grid
+// still fills the chip)
+template <bool MX8, int DBG = 0, int NGRP = 2>
 __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                            unsigned char* __restrict__ out_scales,
@@ -64,18 +67,20 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;            // KV group
-    const int wq = wave & 3;              // query sub-block of this wave
+    constexpr int WPG = 8 / NGRP;         // waves per KV group
+    constexpr int QB = 32 * WPG;          // queries per workgroup
+    const int grp = NGRP == 2 ? wave >> 2 : 0;            // KV group
+    const int wq = NGRP == 2 ? (wave & 3) : wave;         // query sub-block of this wave
     const int half = lane >> 5;
     const int l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
     const int kvh = h / (H / KVH);
-    const int qi = blockIdx.x * Q_BLOCK + wq * 32 + l31;   // < Sq_pad
+    const int qi = blockIdx.x * QB + wq * 32 + l31;        // NGRP == 2: < Sq_pad; NGRP == 1: the last workgroup may reach beyond it
 
     // Q fragments (B operand of S^T): Q[qi][16t + 8*half .. +8]
     bf16x8 qf[4];
     {
-        const bf16_t* qp = q + ((size_t)(b * H + h) * Sq_pad + qi) * 64 + half * 8;
+        const bf16_t* qp = q + ((size_t)(b * H + h) * Sq_pad + (qi < Sq_pad ? qi : Sq_pad - 1)) * 64 + half * 8;
 #pragma unroll
         for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(qp + t * 16);
     }
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
     const int ob = (b * Sk) & 3;
     const int k_end = ob + Sk;
     const int n_tiles = (k_end + KV_TILE - 1) / KV_TILE;
-    const int n0 = (n_tiles + 1) >> 1;                     // group 0: tiles [0, n0), group 1: [n0, n_tiles)
+    const int n0 = NGRP == 2 ? (n_tiles + 1) >> 1 : n_tiles;   // group 0: tiles [0, n0), group 1: [n0, n_tiles)
     const int t_first = grp ? n0 : 0;
     const int t_count = grp ? n_tiles - n0 : n0;
     const int n_iter = n0;                                 // >= the other group's count: both groups pass the same barriers
@@ -93,11 +98,12 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
     // V^T tile.  Lane l lands at row 8p + l/8, position l%8, so it fetches logical chunk (l%8) ^ ((row >> 1) & 7) of that row.
     const bf16_t* kbase = k + (size_t)(b * KVH + kvh) * Sk_pad * 64;
     const bf16_t* vbase = vt + (size_t)(b * KVH + kvh) * 64 * Sk_pad;
-    const bf16_t* ksrc[2];
-    const bf16_t* vsrc[2];
+    constexpr int PPW = 8 / WPG;          // 1-KiB pieces of the K tile (and of the V^T tile) this wave copies
+    const bf16_t* ksrc[PPW];
+    const bf16_t* vsrc[PPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wq + 4 * i) * 8 + (lane >> 3);
+    for (int i = 0; i < PPW; ++i) {
+        const int row = (wq + WPG * i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         ksrc[i] = kbase + (size_t)row * 64 + c * 8;                 // + tile * 64 rows
         vsrc[i] = vbase + (size_t)row * Sk_pad + c * 8;             // + tile * 64 keys
@@ -107,11 +113,11 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         char* sk = ring + stage * STAGE_BYTES;
         char* sv = sk + KV_TILE * 128;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PPW; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc[i] + (size_t)tile * KV_TILE * 64),
-                                             (__attribute__((address_space(3))) void*)(sk + (wq + 4 * i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sk + (wq + WPG * i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc[i] + (size_t)tile * KV_TILE),
-                                             (__attribute__((address_space(3))) void*)(sv + (wq + 4 * i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(sv + (wq + WPG * i) * 1024), 16, 0, 0);
         }
     };
 
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
 
     // a wave whose 32 queries are all beyond Sq (tail workgroup) still copies tiles and joins the barriers, but skips the matrix and
     // softmax work
-    const bool wave_active = __builtin_amdgcn_readfirstlane(blockIdx.x * Q_BLOCK + wq * 32) < Sq;
+    const bool wave_active = __builtin_amdgcn_readfirstlane(blockIdx.x * QB + wq * 32) < Sq;
 
     auto process = [&](int tile, int stage) {
         const char* sk = ring + stage * STAGE_BYTES;
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
     }
 
     // ---- merge the two key ranges: group 1 hands (m, l, O) to group 0 through LDS ([wave][34 values][64 lanes], conflict-free)
+    if constexpr (NGRP == 2) {
     __builtin_amdgcn_s_barrier();                 // the rings are free
     float* mg = reinterpret_cast<float*>(smem) + wq * (34 * 64) + lane;
     if (grp == 1) {
@@ -237,6 +244,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[i][r] = oacc[i][r] * a0 + mg[(i * 16 + r) * 64] * a1;
+    }
     }
 
     const float inv = 1.0f / half_sum(l_run);
@@ -309,6 +317,20 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
     SAT_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0, SAT_E_INVALID, "attention: pointers must be 16-byte aligned");
     const float scale_log2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
     dim3 grid(cdiv(sq, Q_BLOCK), h, b);
+    // One KV group (256 queries per workgroup, every wave walks all the KV tiles) when the grid still gives every CU its two workgroups
+    // twice over, or when there are too few keys to split (cross-attention: 130 keys = 3 tiles).  Measured (profiles/
+    // r03_attention_groups.txt): SA-2.0 self-attention 650 -> 617 us, 8 prompts 214 -> 205, cross 10.8 -> 9.8; at one prompt (240
+    // workgroups of 256 queries for 512 slots) the split stays: 31.1 vs 32.6 us.  SAT_ATTN_GROUPS = 1 | 2 forces a layout (A/B).
+    static const int force_grp = [] { const char* e = getenv("SAT_ATTN_GROUPS"); return e ? atoi(e) : 0; }();
+    const long wg1 = (long)cdiv(sq, 256) * h * b;
+    const bool one_group = force_grp ? force_grp == 1 : (wg1 >= 1024 || sk <= 512);
+    if (one_group && !out_scales) {
+        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 0, 1>), GROUP_BYTES));
+        hipLaunchKernelGGL((attention_kernel<false, 0, 1>), dim3(cdiv(sq, 256), h, b), dim3(512), GROUP_BYTES, s, q, k, vt, out, out_scales, h, kvh, sq, sk,
+                           sq_pad, sk_pad, scale_log2);
+        SAT_LAUNCH_CHECK();
+        return 0;
+    }
 #ifdef SAT_GEMM_EXPERIMENTS
     if (const char* dbg = getenv("SAT_ATTN_DBG")) {
         auto launch = [&](auto kern) {
