@@ -211,6 +211,24 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         }
     };
 
+    if constexpr (NGRP == 1) {
+        // three stages (48 KiB), prefetch distance 2: tile it + 1 stays in flight across the barrier (counted vmcnt: this wave issued
+        // 2 * PPW pieces for it); tile it + 2 goes into the stage tile it - 1 occupied, which every wave left before this barrier.
+        // (Measured, profiles/r03_attention_groups.txt: SA-2.0 609 -> 599 us against two stages; ONE barrier per pair of tiles with a
+        // 2 x 2-tile ring instead: 619 us -- the distance-1 prefetch costs more than the saved barriers.)
+        stage_in(t_first, 0);
+        if (t_count > 1) stage_in(t_first + 1, 1);
+        int st = 0;
+        for (int it = 0; it < n_iter; ++it) {
+            if (it + 1 < t_count) wait_vmcnt<2 * PPW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            const int st2 = st >= 1 ? st - 1 : 2;                 // (it + 2) % 3
+            if (it + 2 < t_count) stage_in(t_first + it + 2, st2);
+            if (wave_active) process(t_first + it, st);
+            st = st == 2 ? 0 : st + 1;
+        }
+    } else {
     if (t_count > 0) stage_in(t_first, 0);
     for (int it = 0; it < n_iter; ++it) {
         if constexpr (DBG < 4) {
@@ -219,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         }
         if (DBG != 2 && DBG < 4 && it + 1 < t_count) stage_in(t_first + it + 1, (it + 1) & 1);
         if (wave_active && it < t_count) process(t_first + it, it & 1);
+    }
     }
 
     // ---- merge the two key ranges: group 1 hands (m, l, O) to group 0 through LDS ([wave][34 values][64 lanes], conflict-free)
@@ -325,8 +344,8 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
     const long wg1 = (long)cdiv(sq, 256) * h * b;
     const bool one_group = force_grp ? force_grp == 1 : (wg1 >= 1024 || sk <= 512);
     if (one_group && !out_scales) {
-        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 0, 1>), GROUP_BYTES));
-        hipLaunchKernelGGL((attention_kernel<false, 0, 1>), dim3(cdiv(sq, 256), h, b), dim3(512), GROUP_BYTES, s, q, k, vt, out, out_scales, h, kvh, sq, sk,
+        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 0, 1>), 3 * STAGE_BYTES));
+        hipLaunchKernelGGL((attention_kernel<false, 0, 1>), dim3(cdiv(sq, 256), h, b), dim3(512), 3 * STAGE_BYTES, s, q, k, vt, out, out_scales, h, kvh, sq, sk,
                            sq_pad, sk_pad, scale_log2);
         SAT_LAUNCH_CHECK();
         return 0;
