@@ -139,7 +139,7 @@ def test_prepare_audio_and_padcrop_match_reference():
     a = synthetic.synth_input("pa", (1, 1000), 6)
     assert torch.equal(prepare_audio(a, 44100, 44100, 1500, 2, "cpu"), g["prepare_mono_to_stereo_pad"])
     assert torch.equal(prepare_audio(synthetic.synth_input("pa3", (3, 1000), 7), 44100, 44100, 600, 2, "cpu"), g["prepare_crop"])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # resampling runs on the device only (sat_resample_sinc; tests/test_resample.py)
         prepare_audio(a, 48000, 44100, 1500, 2, "cpu")
     x = torch.arange(12.0).view(2, 6)
     assert PadCrop(4, randomize=False)(x).tolist() == [[0, 1, 2, 3], [6, 7, 8, 9]]
