@@ -190,16 +190,28 @@ __device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[
 // section -- 5 % slower.
 // DBG 9 (experiments build): per workgroup and K-range the 100 MHz timestamps (range start, main loop done, fix-up done, epilogue
 // done) + (whole, K-tiles, last arriver) -> tools/ph8_probe.py timeline
-template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1>
-__global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
+// Tile geometry: 2 wave rows x WN wave columns, a wave = 2 quadrant rows of MFQ 16-row blocks x 64 columns.
+//   WN = 4, MFQ = 4: 256 x 256, 8 waves, 136 KiB of LDS, one workgroup per CU   (the tile everything above describes)
+//   WN = 2, MFQ = 2: 128 x 128, 4 waves,  68 KiB of LDS, two workgroups per CU  (experiment for the narrow one-prompt GEMMs: slower than
+//                    the 16-wave-family tiles everywhere, see sat_launch_gemm_ph8; compiled in the experiments build only)
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4>
+__global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
+    constexpr int NW = 2 * WN, NT = NW * 64;
+    constexpr int QR = MFQ * 16;                 // rows of one quadrant of a wave
+    constexpr int WR = 2 * QR;                   // rows of a wave
+    constexpr int BM = 2 * WR, BN = WN * 64;
+    constexpr int MB = 2 * MFQ;                  // 16-row blocks of a wave
+    constexpr int AH = (BM / 2) * 128, WH = (BN / 2) * 128;          // bytes of an A / W half-tile
+    static_assert(NT / 2 == BM, "two threads per row in the LayerNorm prologue");
     [[maybe_unused]] int ts_n = 0;
-    constexpr int BUF_BYTES = 65536, HALF_BYTES = 16384, RING_BYTES = 131072;
+    constexpr int BUF_BYTES = 2 * (AH + WH), RING_BYTES = 2 * BUF_BYTES;
+    auto koff = [](int kind) { return kind == 0 ? 0 : kind == 1 ? WH : kind == 2 ? WH + AH : 2 * WH + AH; };          // W-lo, A-lo, W-hi, A-hi
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid_ = threadIdx.x;
     const int lane = tid_ & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WN, wc = wave % WN;
     const int l15_ = lane & 15, q4_ = lane >> 4;
     const int M = g.M, N = g.N, K = g.K;
     const int wgi = xcd_remap(blockIdx.x, sc.G);          // consecutive logical workgroups share an XCD (and so the tiles they split)
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
             s.slot = (sk_u == sk_b) ? 0 : 1;
             sk_u += ue - ub;
         }
-        s.m0 = tm << 8; s.n0 = tn << 8;
+        s.m0 = tm * BM; s.n0 = tn * BN;
         // Accumulator orientation, uniform over the workgroup (a 256-column tile never straddles a q / k / v part): transposed
         // (lane = token) everywhere except for a V^T destination, whose token-contiguous stores want lane = channel.
         s.tr = true;
@@ -241,14 +253,14 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
     auto setup_dma = [&](const Seg& s) {
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
-        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)s.n0 * K), 0, 256 * K * 2, 0x00020000);
+        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)s.n0 * K), 0, BN * K * 2, 0x00020000);
         const int sub = lane_l >> 3, pos = lane_l & 7;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = i * 64 + wave * 8 + sub;                   // LDS row of the half-tile
+            const int r = i * (NW * 8) + wave * 8 + sub;             // LDS row of the half-tile
             const int c = pos ^ ((r >> 1) & 7);
             // A: LDS rows [0,64) belong to wave row 0, [64,128) to wave row 1; rows beyond M are out of range of rsA: zeros
-            voffA[i] = (s.m0 + (r >> 6) * 128 + (r & 63)) * (K * 2) + c * 16;
+            voffA[i] = (s.m0 + (r / QR) * WR + (r % QR)) * (K * 2) + c * 16;
             // W: LDS rows [32 w', 32 w' + 32) belong to wave column w'; row = 16 nf + fragment row
             const int wcol = r >> 5, nf = (r >> 4) & 1, fi = r & 15;
 #pragma unroll
@@ -261,16 +273,16 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
             }
         }
     };
-    const int hiA = 64 * K * 2;
+    const int hiA = QR * K * 2;
     auto issue = [&](int kind, int buf, int kt) {          // kind: 0 W-lo, 1 A-lo, 2 W-hi, 3 A-hi (compile-time after inlining)
-        char* dst = smem + buf * BUF_BYTES + kind * HALF_BYTES + wave * 1024;
+        char* dst = smem + buf * BUF_BYTES + koff(kind) + wave * 1024;
         const int soff = __builtin_amdgcn_readfirstlane(kt * 128);      // (stays scalar even if the K-tile counter was spilled to a VGPR lane)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (kind & 1)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_p)(dst + i * 8192), 16, voffA[i] + (kind == 3 ? hiA : 0), soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_p)(dst + i * (NW * 1024)), 16, voffA[i] + (kind == 3 ? hiA : 0), soff, 0, 0);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_p)(dst + i * 8192), 16, voffW[kind >> 1][i], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_p)(dst + i * (NW * 1024)), 16, voffW[kind >> 1][i], soff, 0, 0);
         }
     };
 
@@ -280,21 +292,21 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int ch = ((ks * 4 + q4_) ^ swz) << 4;
-        offA[ks] = (wr * 64 + l15_) * 128 + ch;
+        offA[ks] = (wr * QR + l15_) * 128 + ch;
         offW[ks] = (wc * 32 + l15_) * 128 + ch;
     }
 
-    f32x4_t acc[8][4];
-    bf16x8 fa[4][2], fwl[2][2], fwh[2][2];
+    f32x4_t acc[MB][4];
+    bf16x8 fa[MFQ][2], fwl[2][2], fwh[2][2];
     auto read_a = [&](int buf, int hi) {
-        const char* base = smem + buf * BUF_BYTES + (hi ? 3 : 1) * HALF_BYTES;
+        const char* base = smem + buf * BUF_BYTES + koff(hi ? 3 : 1);
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < MFQ; ++f)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[f][ks] = *reinterpret_cast<const bf16x8*>(base + offA[ks] + f * 2048);
     };
     auto read_w = [&](int buf, int hi, bf16x8 (&fw)[2][2]) {
-        const char* base = smem + buf * BUF_BYTES + (hi ? 2 : 0) * HALF_BYTES;
+        const char* base = smem + buf * BUF_BYTES + koff(hi ? 2 : 0);
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -313,11 +325,11 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
+                for (int f = 0; f < MFQ; ++f)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[mi * 4 + f][ni * 2 + n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[n][ks], fa[f][ks], acc[mi * 4 + f][ni * 2 + n], 0, 0, 0)
-                                                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f][ks], fw[n][ks], acc[mi * 4 + f][ni * 2 + n], 0, 0, 0);
+                        acc[mi * MFQ + f][ni * 2 + n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[n][ks], fa[f][ks], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0)
+                                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f][ks], fw[n][ks], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
         // One K-tile = four phases.  BUF is the LDS buffer of tile t; tile t + 2 restages the same buffer.
@@ -407,11 +419,11 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int f = 0; f < 4; ++f)
+                    for (int f = 0; f < MFQ; ++f)
 #pragma unroll
                         for (int n = 0; n < 2; ++n)
-                            acc[mi * 4 + f][ni * 2 + n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[n][ks], fa[f][ks], acc[mi * 4 + f][ni * 2 + n], 0, 0, 0)
-                                                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f][ks], fw[n][ks], acc[mi * 4 + f][ni * 2 + n], 0, 0, 0);
+                            acc[mi * MFQ + f][ni * 2 + n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[n][ks], fa[f][ks], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0)
+                                                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f][ks], fw[n][ks], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
         };
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
     // The loads are ISSUED in front of the range's LDS-DMA prologue and consumed behind it: the vector-memory counter retires in
     // order, so a load issued after the 14 DMA pieces could only be used once all of them have landed.
     constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS);
-    constexpr int LN_BYTES = 4096;
+    constexpr int LN_BYTES = (BM + BN) * 8;          // (mean, rstd) per row, then c1[BN], c2[BN]
     const bool ln_fold = LN_CONS && g.ln_part != nullptr;
     const int np = K >> 6;
     const bool ln_fast = ln_fold && np == 24;             // 12 partial pairs per thread, held in registers across the DMA issue
@@ -488,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         asm volatile("" : "+v"(tid));            // (keeps this block's address arithmetic inside the persistent loop, see the epilogue)
         [[maybe_unused]] float2 lnp[12];         // local: nothing of this is live across the main loop
         [[maybe_unused]] f32x4_t lncst = {0.f, 0.f, 0.f, 0.f};
-        [[maybe_unused]] const int ct = 511 - tid;           // the last 128 threads bring in the channel constants, 16 bytes each
+        [[maybe_unused]] const int ct = NT - 1 - tid;        // the last BN / 2 threads bring in the channel constants, 16 bytes each
         if constexpr (LN_CONS) {
             if (ln_fast) {
                 int m = s.m0 + (tid >> 1);
@@ -500,10 +512,10 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
 #pragma unroll
                 for (int i = 0; i < 12; ++i) lnp[i] = make_float2(0.f, 0.f);
             }
-            if (ct < 128) {
-                const bool first = ct < 64;
-                const float* src = ln_fold ? (first ? g.ln_c1 + s.n0 + ct * 4 : g.ln_c2 + s.n0 + (ct - 64) * 4)
-                                           : ((first || !g.bias) ? nullptr : g.bias + s.n0 + (ct - 64) * 4);
+            if (ct < BN / 2) {
+                const bool first = ct < BN / 4;
+                const float* src = ln_fold ? (first ? g.ln_c1 + s.n0 + ct * 4 : g.ln_c2 + s.n0 + (ct - BN / 4) * 4)
+                                           : ((first || !g.bias) ? nullptr : g.bias + s.n0 + (ct - BN / 4) * 4);
                 if (src) lncst = *reinterpret_cast<const f32x4_t*>(src);
             }
         }
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LN_CONS) {
             float2* lnst = reinterpret_cast<float2*>(smem + RING_BYTES + lb * LN_BYTES);
-            float* lnc = reinterpret_cast<float*>(smem + RING_BYTES + lb * LN_BYTES + 2048);
+            float* lnc = reinterpret_cast<float*>(smem + RING_BYTES + lb * LN_BYTES + BM * 8);
             const int r = tid >> 1, sub = tid & 1;           // two threads per row
             float sum = 0.f, sq = 0.f;
 #pragma unroll
@@ -542,7 +554,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
                 const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
                 lnst[r] = ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, 1.f);
             }
-            if (ct < 128) *reinterpret_cast<f32x4_t*>(lnc + ct * 4) = lncst;
+            if (ct < BN / 2) *reinterpret_cast<f32x4_t*>(lnc + ct * 4) = lncst;
         }
     };
 
@@ -553,18 +565,18 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         // loop, where it would stay live across the main loop and push its 128 + 64 registers into scratch)
         int l15 = l15_, q4 = q4_;
         asm volatile("" : "+v"(l15), "+v"(q4));
-        const int mrow0 = s.m0 + wr * 128 + l15;
+        const int mrow0 = s.m0 + wr * WR + l15;
         const int ncol0 = s.n0 + wc * 64;
-        [[maybe_unused]] const float2* ln = reinterpret_cast<const float2*>(smem + RING_BYTES + lb * LN_BYTES) + wr * 128;
-        [[maybe_unused]] const float* lc1 = reinterpret_cast<const float*>(smem + RING_BYTES + lb * LN_BYTES + 2048) + wc * 64;
-        [[maybe_unused]] const float* lc2 = lc1 + 256;
+        [[maybe_unused]] const float2* ln = reinterpret_cast<const float2*>(smem + RING_BYTES + lb * LN_BYTES) + wr * WR;
+        [[maybe_unused]] const float* lc1 = reinterpret_cast<const float*>(smem + RING_BYTES + lb * LN_BYTES + BM * 8) + wc * 64;
+        [[maybe_unused]] const float* lc2 = lc1 + BN;
         if constexpr (EPI == EPI_F32) {
             f32x4_t bia[4];
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
                 bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {          // four batches of two row blocks: 8 residual loads in flight (a batch of four spills)
+            for (int h = 0; h < MB / 2; ++h) {     // batches of two row blocks: 8 residual loads in flight (a batch of four spills)
                 f32x4_t old[2][4];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) ph8_load_resid(g, old[i], mrow0 + (h * 2 + i) * 16, ncol0, q4);
@@ -585,7 +597,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
             }
             bf16_t* __restrict__ hbase = g.H + (ncol0 >> 1) + q4 * 8;
 #pragma unroll
-            for (int mb = 0; mb < 8; ++mb) {
+            for (int mb = 0; mb < MB; ++mb) {
                 const int m = mrow0 + mb * 16;
                 const float2 st = ln[mb * 16 + l15];
                 unsigned pk[4];
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
                     c2[2 + nf] = *reinterpret_cast<const f32x4_t*>(lc2 + 32 + q4 * 8 + nf * 4);
                 }
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) {
+                for (int mb = 0; mb < MB; ++mb) {
                     const int m = mrow0 + mb * 16;
                     const int mc = m < M ? m : M - 1;
                     const int b = mc / S;
@@ -665,8 +677,8 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
                     c2[nb] = lc2[nb * 16 + l15];
                 }
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb) {
-                    const int mbase = s.m0 + wr * 128 + mb * 16 + 4 * q4;          // multiple of 4
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int mbase = s.m0 + wr * WR + mb * 16 + 4 * q4;          // multiple of 4
                     const f32x4_t* sp = reinterpret_cast<const f32x4_t*>(ln + mb * 16 + 4 * q4);
                     const f32x4_t st01 = sp[0], st23 = sp[1];                    // (mean, rstd) of rows e = 0, 1 / 2, 3
                     int bb[4], ss[4];
@@ -715,13 +727,13 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
-        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)sc.sk_slab, 0, sc.G * 2 * 262144, 0x00020000);
-        auto slab_off = [&](int w, int slot) { return (w * 2 + slot) * 262144 + wave * 32768 + lane_l * 16; };       // bytes
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)sc.sk_slab, 0, sc.G * 2 * (BM * BN * 4), 0x00020000);
+        auto slab_off = [&](int w, int slot) { return (w * 2 + slot) * (BM * BN * 4) + wave * (MB * 4096) + lane_l * 16; };       // bytes
         const int parts = sc.sk_parts[s.skj];
         const int first = sc.sk_first[s.skj];
         const int mine = slab_off(wgi, s.slot);
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[mb][nb]), rsS, mine + (mb * 4 + nb) * 1024, 0, 16);
@@ -738,11 +750,11 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         auto add_slab = [&](int off) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                u32x4_t t[16];
+                u32x4_t t[MB * 2];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rsS, off + (h * 16 + i) * 1024, 0, 16);
+                for (int i = 0; i < MB * 2; ++i) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rsS, off + (h * MB * 2 + i) * 1024, 0, 16);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[h * 4 + (i >> 2)][i & 3] += __builtin_bit_cast(f32x4_t, t[i]);
+                for (int i = 0; i < MB * 2; ++i) acc[h * (MB / 2) + (i >> 2)][i & 3] += __builtin_bit_cast(f32x4_t, t[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -752,7 +764,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         const bool two = parts == 2;
         const float keep = two ? 1.0f : 0.0f;
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) acc[mb][nb] *= keep;
         int seen = 0;
@@ -776,7 +788,7 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
     prepare(cur, lb);
     while (true) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         // the range's first tiles have landed (and the previous epilogue's stores are out); LayerNorm constants are visible
@@ -790,14 +802,14 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         }
         [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0;
         if constexpr (DBG == 9) t0 = __builtin_amdgcn_s_memrealtime();
-        const int mq = cur.m0 + wr * 128;
+        const int mq = cur.m0 + wr * WR;
         const bool rows_valid = mq < M;
         if constexpr (PH2) {
-            if (cur.tr) main_loop2(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
-            else main_loop2(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+            if (cur.tr) main_loop2(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + QR < M);
+            else main_loop2(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + QR < M);
         } else {
-            if (cur.tr) main_loop(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
-            else main_loop(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + 64 < M);
+            if (cur.tr) main_loop(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + QR < M);
+            else main_loop(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + QR < M);
         }
         if constexpr (DBG == 9) t1 = __builtin_amdgcn_s_memrealtime();
         const bool more = next_seg(nxt);
@@ -805,9 +817,9 @@ __global__ __launch_bounds__(512) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, 
         bool fin = true;
         if (!cur.whole) {
             if (sc.dump) {          // two-launch split (fp32 output): plain stores, the kernel boundary publishes them
-                float* mine = sc.sk_slab + ((size_t)wgi * 2 + cur.slot) * 65536 + (size_t)(wave * 32) * 256 + lane * 4;
+                float* mine = sc.sk_slab + ((size_t)wgi * 2 + cur.slot) * (BM * BN) + (size_t)(wave * MB * 4) * 256 + lane * 4;
 #pragma unroll
-                for (int mb = 0; mb < 8; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4_t*>(mine + (mb * 4 + nb) * 256) = acc[mb][nb];
                 fin = false;
@@ -877,7 +889,7 @@ struct DevState {
     int cus = 0;
     float* slab = nullptr;
     size_t slab_wgs = 0;
-    std::map<std::tuple<int, int, int, int>, Ph8Sched> shapes;
+    std::map<std::tuple<int, int, int, int, int>, Ph8Sched> shapes;          // (M, N, K, split, tile rows)
 };
 std::mutex g_sched_mu;
 std::map<int, DevState> g_dev;
@@ -895,14 +907,15 @@ bool ph8_auto_split(const GemmArgs& a, bool epi_f32, int cus) {
 
 // split: 0 = the remainder round's tiles stay whole (one per workgroup, light tiles last), 1 = the remainder round is split along K,
 // -1 = the measured policy below
-int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, Ph8Sched& out) {
+int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int wgs_per_cu, Ph8Sched& out) {
     int dev = 0;
     SAT_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_sched_mu);
     DevState& d = g_dev[dev];
     if (!d.cus) SAT_HIP(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (split < 0) split = ph8_auto_split(a, epi_f32, d.cus) ? 1 : 0;
-    auto key = std::make_tuple(a.M, a.N, a.K, split);
+    if (split < 0) split = (bm == 256 && ph8_auto_split(a, epi_f32, d.cus)) ? 1 : 0;
+    if (bm != 256) split = 0;          // the K-split machinery (slabs, reduce kernel) is built for the 256 x 256 tile
+    auto key = std::make_tuple(a.M, a.N, a.K, split, bm);
     auto it = d.shapes.find(key);
     if (it != d.shapes.end()) {
         out = it->second;
@@ -910,14 +923,14 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, Ph8Sched& out) {
         return 0;
     }
     Ph8Sched s{};
-    const int tiles_m = cdiv(a.M, 256), tail = a.M % 256;
-    s.tiles_n = a.N / 256;
-    s.light = (tail != 0 && tail <= 64 && tiles_m > 1) ? 1 : 0;
+    const int tiles_m = cdiv(a.M, bm), tail = a.M % bm;
+    s.tiles_n = a.N / bn;
+    s.light = (tail != 0 && tail <= bm / 4 && tiles_m > 1) ? 1 : 0;          // only the first quadrant of the first wave row has rows
     s.tiles_m_full = tiles_m - s.light;
     s.nkp = a.K / 128;
     const long t_full = (long)s.tiles_m_full * s.tiles_n, t_light = s.light ? s.tiles_n : 0;
     const long units_all = (t_full + t_light) * s.nkp;
-    s.G = (int)std::min<long>(d.cus, split ? units_all : t_full + t_light);
+    s.G = (int)std::min<long>((long)d.cus * wgs_per_cu, split ? units_all : t_full + t_light);
     const long t_all = t_full + t_light;
     s.dp_rounds = (int)((split ? t_all : t_full) / s.G);
     // K-split with at least one whole round: the light tiles go FIRST (they idle their workgroup for half of round 0 -- a handful of
@@ -999,10 +1012,11 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, Ph8Sched& out) {
 unsigned long long* g_ts_buf = nullptr;
 #endif
 
-template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1>
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4>
 int launch_ph8(const GemmArgs& a, hipStream_t stream) {
-    constexpr int LDS = 131072 + 2 * 4096 + 64;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column) + ticket
-    SAT_CHECK_ARG(a.N % 256 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of 256", a.N);
+    constexpr int BM = 64 * MFQ, BN = 64 * WN, NT = 2 * WN * 64;
+    constexpr int LDS = 2 * 2 * (BM / 2 + BN / 2) * 128 + 2 * (BM + BN) * 8 + 64;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column) + ticket
+    SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of %d", a.N, BN);
     SAT_CHECK_ARG(a.K % 128 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): K=%d must be a multiple of 128", a.K);
     SAT_CHECK_ARG((uint64_t)a.M * (uint64_t)a.K * 2u < (1ull << 31), SAT_E_UNSUPPORTED, "gemm(8-phase): A larger than 2 GiB");
     SAT_CHECK_ARG(!a.fp8 && !a.H8, SAT_E_UNSUPPORTED, "gemm(8-phase): bf16 operands only");
@@ -1011,8 +1025,8 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (EPI == EPI_F32 && a.xb && a.ln_part_out), SAT_E_UNSUPPORTED,
                   "gemm(8-phase): the bf16 image / row statistics come from the fp32-output epilogue");
     if constexpr (EPI == EPI_HEADS) {
-        SAT_CHECK_ARG((a.heads.heads * 64) % 256 == 0 && a.N == a.heads.parts * a.heads.heads * 64, SAT_E_UNSUPPORTED,
-                      "gemm(8-phase): a 256-column tile must not straddle q / k / v (heads=%d)", a.heads.heads);
+        SAT_CHECK_ARG((a.heads.heads * 64) % BN == 0 && a.N == a.heads.parts * a.heads.heads * 64, SAT_E_UNSUPPORTED,
+                      "gemm(8-phase): a %d-column tile must not straddle q / k / v (heads=%d)", BN, a.heads.heads);
         for (int p = 0; p < a.heads.parts; ++p)
             SAT_CHECK_ARG((a.heads.kind[p] & 3) != 3, SAT_E_UNSUPPORTED, "gemm(8-phase): no rotation on a transposed destination");
     }
@@ -1032,12 +1046,12 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
         if (h && h->slab == slab_of_device(dev)) {
             sc = h->s;
         } else {
-            SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, sc));
+            SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, BM, BN, BM == 256 ? 1 : 2, sc));
             if (!h && n_hits < 16) h = &hits[n_hits++];
             if (h) *h = Hit{dev, a.M, a.N, a.K, split, slab_of_device(dev), sc};
         }
     }
-    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V>;
+    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     unsigned long long* ts = nullptr;
 #ifdef SAT_GEMM_EXPERIMENTS
@@ -1048,7 +1062,7 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
     }
 #endif
     sc.dump = (EPI == EPI_F32 && sc.sk_slab != nullptr) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3(sc.G), dim3(512), LDS, stream, a, sc, ts);
+    hipLaunchKernelGGL(kern, dim3(sc.G), dim3(NT), LDS, stream, a, sc, ts);
     if (sc.dump && sc.any_split) hipLaunchKernelGGL(ph8_reduce_f32_kernel, dim3(sc.sk_tiles * 8), dim3(512), 0, stream, a, sc);
     SAT_LAUNCH_CHECK();
     return 0;
@@ -1082,6 +1096,19 @@ bool sat_gemm_ph8_splits(int epi, const GemmArgs& a) {
 
 int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
     const int dbg = (a.variant & 0xfff) / 100;
+#ifdef SAT_GEMM_EXPERIMENTS
+    // The 128 x 128 geometry (4 waves, two workgroups per CU), experiments build only: measured SLOWER than the 16-wave-family tiles at
+    // every one-prompt shape (FF-out 69.5 us vs 62.3, to_out 26.8 vs 22.4, cross 25.0 vs 16.2, QKV 68 vs 51;
+    // profiles/r03_ph8_128x128_geometry_negative.txt) -- 16 MFMAs between barriers and half the operand reuse per LDS byte.
+    if ((a.variant & 0xfff) % 100 == 81) {
+        switch (epi) {
+            case EPI_F32:
+            case EPI_RESID: return launch_ph8<EPI_F32, 0, true, 1, 2, 2>(a, stream);
+            case EPI_SWIGLU: return launch_ph8<EPI_SWIGLU, 0, true, 1, 2, 2>(a, stream);
+            case EPI_HEADS: return launch_ph8<EPI_HEADS, 0, true, 1, 2, 2>(a, stream);
+        }
+    }
+#endif
     switch (epi) {
         case EPI_F32:
         case EPI_RESID:

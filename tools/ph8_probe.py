@@ -303,6 +303,56 @@ def ph2():
         print(f"ph2 swiglu+ln {name}: v80 {a*1e3:.1f} us  v80+{V2 >> 16:x} {b*1e3:.1f} us  x{a/b:.3f}", flush=True)
 
 
+def small():
+    """the 128 x 128 geometry of the 8-phase kernel (variant 81: 4 waves, two workgroups per CU) against the 16-wave-family tiles the plan
+    uses at one prompt: 44 / 15 (128 x 128, 8 waves), 16 (128 x 64), 30 (256 x 192)"""
+    for (m, n, k) in [(128, 128, 128), (256, 256, 256), (300, 512, 384), (2050, 1536, 1536), (257, 768, 6144), (1025, 1536, 1536)]:
+        check(m, n, k, 81)
+        check(m, n, k, 81, fill="rows")
+    for (m, n, k) in [(512, 512, 512), (2050, 1536, 6144), (1025, 1536, 1536)]:
+        w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        As = [torch.randn(m, k, device=dev).to(torch.bfloat16), (torch.randn(m, k, device=dev) * 2 + 0.5).to(torch.bfloat16)]
+        first, diff = [None, None], 0
+        for i in range(40):
+            c = torch.full((m, n), float("nan"), device=dev)
+            gemm_fn(As[i & 1], w, c, m, n, k, 81)()
+            if first[i & 1] is None:
+                first[i & 1] = c
+            else:
+                diff += int(not torch.equal(c, first[i & 1]))
+        print(f"race(81) M={m} N={n} K={k}: {diff} of 38 repeats differ", flush=True)
+    for name, m, n, k, olds in [("ff_out B1", 2050, 1536, 6144, (44, 15)), ("to_out B1", 2050, 1536, 1536, (15, 16)), ("cross out B1", 1025, 1536, 1536, (16, 15))]:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w2 = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        b2 = torch.randn(n, device=dev)
+        c = torch.zeros(m, n, device=dev)
+        xo = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+        po = torch.empty((m, n // 64, 2), dtype=torch.float32, device=dev)
+        arms = {f"v{v}": v for v in olds}
+        arms["v81"] = 81
+        res = {kk: [] for kk in arms}
+        for _ in range(5):
+            for kk, v in arms.items():
+                res[kk].append(timeit(lambda: _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, n, k,
+                                                                                   v, _hip.stream())), iters=10, warm=2))
+        fl = 2.0 * m * n * k
+        print(f"small resid+ln {name} {m}x{n}x{k}: " + "  ".join(f"{kk} {statistics.median(vv)*1e3:.1f} us ({fl/statistics.median(vv)/1e9:.0f} TF)" for kk, vv in res.items()), flush=True)
+    b, s_len, s_pad, d = 2, 1025, 1152, 1536
+    a = torch.randn(b * s_len, d, device=dev).to(torch.bfloat16)
+    w = (torch.randn(3 * d, d, device=dev) * 0.05).to(torch.bfloat16)
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+    q = torch.empty((b, 24, s_pad, 64), dtype=torch.bfloat16, device=dev)
+    kk_ = torch.empty_like(q)
+    vt = torch.empty((b, 24, 64, s_pad), dtype=torch.bfloat16, device=dev)
+    scratch = torch.empty((2 * s_len * 16,), dtype=torch.float32, device=dev)
+    res = {30: [], 80: [], 81: []}
+    for _ in range(5):
+        for v in res:
+            res[v].append(timeit(lambda: _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(inv_freq), _hip.ptr(q), _hip.ptr(kk_), _hip.ptr(vt), _hip.ptr(scratch),
+                                                                       b, s_len, s_pad, d, v, _hip.stream())), iters=10, warm=2))
+    print("small qkv heads+rope B1 (+memsets): " + "  ".join(f"v{v} {statistics.median(t)*1e3:.1f} us" for v, t in res.items()), flush=True)
+
+
 def ablate():
     for name, m, n, k in [("4096^3", 4096, 4096, 4096), ("ff_in B8", 16400, 12288, 1536)]:
         arms_bench("ablate " + name, m, n, k, [80, 180, 280, 380], blas=False, rounds=3)
