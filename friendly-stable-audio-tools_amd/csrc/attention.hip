@@ -73,9 +73,15 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
     const int wq = NGRP == 2 ? (wave & 3) : wave;         // query sub-block of this wave
     const int half = lane >> 5;
     const int l31 = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
+    // XCD-aware placement: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, so the query blocks of one (batch, head)
+    // -- which all stream the SAME K / V^T -- would each pull their own copy through a different L2.  The linear id is remapped so that
+    // consecutive LOGICAL ids share an XCD; x (query block) is the fastest logical coordinate.
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int lid = xcd_remap(lin, gridDim.x * gridDim.y * gridDim.z);
+    const int bx = lid % gridDim.x;
+    const int h = (lid / gridDim.x) % gridDim.y, b = lid / (gridDim.x * gridDim.y);
     const int kvh = h / (H / KVH);
-    const int qi = blockIdx.x * QB + wq * 32 + l31;        // NGRP == 2: < Sq_pad; NGRP == 1: the last workgroup may reach beyond it
+    const int qi = bx * QB + wq * 32 + l31;                // NGRP == 2: < Sq_pad; NGRP == 1: the last workgroup may reach beyond it
 
     // Q fragments (B operand of S^T): Q[qi][16t + 8*half .. +8]
     bf16x8 qf[4];
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
 
     // a wave whose 32 queries are all beyond Sq (tail workgroup) still copies tiles and joins the barriers, but skips the matrix and
     // softmax work
-    const bool wave_active = __builtin_amdgcn_readfirstlane(blockIdx.x * QB + wq * 32) < Sq;
+    const bool wave_active = __builtin_amdgcn_readfirstlane(bx * QB + wq * 32) < Sq;
 
     auto process = [&](int tile, int stage) {
         const char* sk = ring + stage * STAGE_BYTES;
@@ -219,14 +225,27 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         stage_in(t_first, 0);
         if (t_count > 1) stage_in(t_first + 1, 1);
         int st = 0;
+        [[maybe_unused]] unsigned long long t_sync = 0, t_work = 0, t_a = 0, t_b = 0;
         for (int it = 0; it < n_iter; ++it) {
+            if constexpr (DBG == 9) t_a = __builtin_readcyclecounter();
             if (it + 1 < t_count) wait_vmcnt<2 * PPW>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
+            if constexpr (DBG == 9) { t_b = __builtin_readcyclecounter(); t_sync += t_b - t_a; }
             const int st2 = st >= 1 ? st - 1 : 2;                 // (it + 2) % 3
             if (it + 2 < t_count) stage_in(t_first + it + 2, st2);
             if (wave_active) process(t_first + it, st);
+            if constexpr (DBG == 9) t_work += __builtin_readcyclecounter() - t_b;
             st = st == 2 ? 0 : st + 1;
+        }
+        if constexpr (DBG == 9) {          // experiments build: per-wave cycles parked at the tile barrier vs issuing the tile's work
+            if (lane == 0 && wave_active) {
+                unsigned long long* dbg = reinterpret_cast<unsigned long long*>(out_scales);
+                atomicAdd(dbg, t_sync);
+                atomicAdd(dbg + 1, t_work);
+                atomicAdd(dbg + 2, 1ull);
+                atomicAdd(dbg + 3, (unsigned long long)n_iter);
+            }
         }
     } else {
     if (t_count > 0) stage_in(t_first, 0);
@@ -325,6 +344,17 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
 
 }  // namespace
 
+#ifdef SAT_GEMM_EXPERIMENTS
+static unsigned long long* g_attn_dbg = nullptr;
+extern "C" int sat_attention_dbg_read(unsigned long long* out4) {
+    SAT_CHECK_ARG(g_attn_dbg, SAT_E_INVALID, "no attention counters");
+    SAT_HIP(hipDeviceSynchronize());
+    SAT_HIP(hipMemcpy(out4, g_attn_dbg, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    SAT_HIP(hipMemset(g_attn_dbg, 0, 4 * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
+
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
                          int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales) {
     SAT_CHECK_ARG(q && k && vt && out, SAT_E_INVALID, "attention: null pointer");
@@ -343,6 +373,19 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
     static const int force_grp = [] { const char* e = getenv("SAT_ATTN_GROUPS"); return e ? atoi(e) : 0; }();
     const long wg1 = (long)cdiv(sq, 256) * h * b;
     const bool one_group = force_grp ? force_grp == 1 : (wg1 >= 1024 || sk <= 512);
+#ifdef SAT_GEMM_EXPERIMENTS
+    if (one_group && !out_scales && getenv("SAT_ATTN_DBG") && atoi(getenv("SAT_ATTN_DBG")) == 9) {
+        if (!g_attn_dbg) {
+            SAT_HIP(hipMalloc(&g_attn_dbg, 4 * sizeof(unsigned long long)));
+            SAT_HIP(hipMemset(g_attn_dbg, 0, 4 * sizeof(unsigned long long)));
+        }
+        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 9, 1>), 3 * STAGE_BYTES));
+        hipLaunchKernelGGL((attention_kernel<false, 9, 1>), dim3(cdiv(sq, 256), h, b), dim3(512), 3 * STAGE_BYTES, s, q, k, vt, out,
+                           reinterpret_cast<unsigned char*>(g_attn_dbg), h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
+        SAT_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
     if (one_group && !out_scales) {
         SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 0, 1>), 3 * STAGE_BYTES));
         hipLaunchKernelGGL((attention_kernel<false, 0, 1>), dim3(cdiv(sq, 256), h, b), dim3(512), 3 * STAGE_BYTES, s, q, k, vt, out, out_scales, h, kvh, sq, sk,
