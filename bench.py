@@ -34,6 +34,7 @@ DIT_STEPS = 100
 # process group, barrier, all-reduce and the final all-gather are exercised with world_size 1
 FORCE_DIST = os.environ.get("SAT_BENCH_FORCE_DIST") == "1"
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense, /opt/skills/guides/MI355X_MICROARCH.md
+FP8_MFMA_PEAK_TFLOPS = 5000.0     # dense e4m3 (the FF-in GEMM of --dtype fp8 runs v_mfma_scale_f32_16x16x128_f8f6f4)
 
 
 # --workload sa2_a2a = BASELINE config 4: Stable Audio 2.0 shape (285-s context, T = 6144 latent frames, S = 6145), audio-to-audio:
@@ -296,6 +297,7 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 traffic_source = f"profiles/{tname} (rocprofv3 --pmc passes of this command, not measured in this run)"
                 break
+        mfma_peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP8_MFMA_PEAK_TFLOPS
         line = {
             "metric": "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-Open-1.0 shape" if args.workload == "sa_open" else
                       "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-2.0 shape audio-to-audio (encode + sample + decode)",
@@ -316,7 +318,7 @@ def main():
                                     f"100 DPM-Solver++(3M) SDE steps from sigma 7 + decode, {args.batch} prompt(s)/GPU"), "prompts_per_gpu": args.batch,
                        "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "layernorm": args.layernorm, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
             "roofline": {"bound": "mfma", "kernel": f"FFN-in SwiGLU GEMM M={m.value} N={n.value} K={k.value} ({args.dtype} MFMA, fp32 acc)", "achieved": achieved,
-                         "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak, "traffic": traffic,
                          "traffic_source": traffic_source, "avg_launch_us": avg_ms * 1e3, "launches_timed": cnt.value},
             "rccl_ranks": world if use_dist else 0,
         }

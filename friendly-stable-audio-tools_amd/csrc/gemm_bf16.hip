@@ -1276,6 +1276,8 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
                 }
             }
         } else if (a.fp8 == 2) {      // block-scaled MFMA with unit scales: 2x the MFMA rate
+            const int fv = a.variant & 0xff;
+            if ((fv == 80 || (fv == 0 && v == 22 && g_wide_tile == 80)) && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
             switch (v) {
                 case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 2>(a, stream);
                 case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 2>(a, stream);

@@ -194,7 +194,12 @@ __device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[
 //   WN = 4, MFQ = 4: 256 x 256, 8 waves, 136 KiB of LDS, one workgroup per CU   (the tile everything above describes)
 //   WN = 2, MFQ = 2: 128 x 128, 4 waves,  68 KiB of LDS, two workgroups per CU  (experiment for the narrow one-prompt GEMMs: slower than
 //                    the 16-wave-family tiles everywhere, see sat_launch_gemm_ph8; compiled in the experiments build only)
-template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4>
+// FP8 = 2 (BASELINE config 5, the LayerNorm-fed GEMMs: to_qkv, cross to_q, FF-in): A and W hold e4m3 bytes; the launcher hands the kernel
+// K / 2 "16-bit columns", so DMA, LDS image and swizzle are byte-for-byte those of the bf16 kernel -- a 128-byte LDS row now carries 128 k.
+// One v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales, twice the bf16 MFMA rate) consumes a whole row of the K-tile: a lane's 32
+// operand bytes are logical chunks 2 q and 2 q + 1 of its row, loaded identically for A and W, so the instruction's internal k order does
+// not matter.  The fp32 accumulators are multiplied by a_scale[token] * w_scale[channel] in front of the epilogue.
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0>
 __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
     constexpr int NW = 2 * WN, NT = NW * 64;
     constexpr int QR = MFQ * 16;                 // rows of one quadrant of a wave
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 
     // ---- fragment addresses: row = (wave's first row of the half-tile) + 16 f + l15, chunk (4 ks + q4) ^ (l15 >> 1)
     const int swz = l15_ >> 1;
+    [[maybe_unused]] const int swz_ = swz;
     int offA[2], offW[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -298,6 +304,25 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 
     f32x4_t acc[MB][4];
     bf16x8 fa[MFQ][2], fwl[2][2], fwh[2][2];
+    typedef int i32x8_t __attribute__((ext_vector_type(8)));
+    [[maybe_unused]] i32x8_t fa8[MFQ], fw8l[2], fw8h[2];          // FP8: one 32-byte fragment per 16-row block and K-tile
+    // logical chunks 2 q4 and 2 q4 + 1 of the lane's row (the XOR swizzle may swap their physical order: put them back)
+    [[maybe_unused]] const int off8[2] = {(((2 * q4_) ^ swz_) << 4), (((2 * q4_ + 1) ^ swz_) << 4)};
+    auto read8 = [&](const char* rowbase) -> i32x8_t {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(rowbase + off8[0]);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(rowbase + off8[1]);
+        return i32x8_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+    [[maybe_unused]] auto read_a8 = [&](int buf, int hi) {
+        const char* base = smem + buf * BUF_BYTES + koff(hi ? 3 : 1) + (wr * QR + l15_) * 128;
+#pragma unroll
+        for (int f = 0; f < MFQ; ++f) fa8[f] = read8(base + f * 2048);
+    };
+    [[maybe_unused]] auto read_w8 = [&](int buf, int hi, i32x8_t (&fw)[2]) {
+        const char* base = smem + buf * BUF_BYTES + koff(hi ? 2 : 0) + (wc * 32 + l15_) * 128;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) fw[f] = read8(base + f * 2048);
+    };
     auto read_a = [&](int buf, int hi) {
         const char* base = smem + buf * BUF_BYTES + koff(hi ? 3 : 1);
 #pragma unroll
@@ -412,6 +437,22 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         auto mfma_half = [&](int mi, int ni_first) {
             if (!(mi ? q_valid1 : q_valid0)) return;
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (FP8 != 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ni = ni_first ^ h;
+                    i32x8_t (&fw)[2] = ni ? fw8h : fw8l;
+#pragma unroll
+                    for (int f = 0; f < MFQ; ++f)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[mi * MFQ + f][ni * 2 + n] =
+                                SWAP ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[n], fa8[f], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F)
+                                     : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa8[f], fw[n], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                return;
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int ni = ni_first ^ h;
@@ -435,9 +476,15 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             constexpr int BUF = decltype(buf_c)::value;
             constexpr int MODE = decltype(mode_c)::value;
             // ---- phase A
-            read_w(BUF, 0, fwl);
-            read_w(BUF, 1, fwh);
-            read_a(BUF, 0);
+            if constexpr (FP8 != 0) {
+                read_w8(BUF, 0, fw8l);
+                read_w8(BUF, 1, fw8h);
+                read_a8(BUF, 0);
+            } else {
+                read_w(BUF, 0, fwl);
+                read_w(BUF, 1, fwh);
+                read_a(BUF, 0);
+            }
             if constexpr (MODE <= 1) {
                 if constexpr (!EARLY_WHI) issue(2, BUF ^ 1, t + 1);
                 issue(3, BUF ^ 1, t + 1);
@@ -453,7 +500,8 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- phase B
-            read_a(BUF, 1);
+            if constexpr (FP8 != 0) read_a8(BUF, 1);
+            else read_a(BUF, 1);
             if constexpr (MODE == 0) {
                 issue(0, BUF, t + 2);
                 issue(1, BUF, t + 2);
@@ -494,12 +542,19 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     const bool ln_fold = LN_CONS && g.ln_part != nullptr;
     const int np = K >> 6;
     const bool ln_fast = ln_fold && np == 24;             // 12 partial pairs per thread, held in registers across the DMA issue
+    // bf16: rstd (acc - mean c1) + c2.  e4m3 (no fold): the same slots carry the dequantisation -- st = (-, a_scale[row]),
+    // c1 = w_scale[channel], c2 = bias -- and the epilogues compute a_scale w_scale acc + bias
+    auto fold = [](float a, float mean, float rstd, float c1, float c2) {
+        if constexpr (FP8 != 0) return fmaf(a * rstd, c1, c2);
+        else return rstd * (a - mean * c1) + c2;
+    };
     // everything a K-range needs before its main loop: LayerNorm loads, DMA addresses, half-tiles 0..6 in flight, LayerNorm constants
     auto prepare = [&](const Seg& s, int lb) {
         int tid = tid_;
         asm volatile("" : "+v"(tid));            // (keeps this block's address arithmetic inside the persistent loop, see the epilogue)
         [[maybe_unused]] float2 lnp[12];         // local: nothing of this is live across the main loop
         [[maybe_unused]] f32x4_t lncst = {0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] float a_sc = 1.f;
         [[maybe_unused]] const int ct = NT - 1 - tid;        // the last BN / 2 threads bring in the channel constants, 16 bytes each
         if constexpr (LN_CONS) {
             if (ln_fast) {
@@ -515,8 +570,13 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             if (ct < BN / 2) {
                 const bool first = ct < BN / 4;
                 const float* src = ln_fold ? (first ? g.ln_c1 + s.n0 + ct * 4 : g.ln_c2 + s.n0 + (ct - BN / 4) * 4)
-                                           : ((first || !g.bias) ? nullptr : g.bias + s.n0 + (ct - BN / 4) * 4);
+                                           : (first ? (FP8 != 0 ? g.w_scale + s.n0 + ct * 4 : nullptr)
+                                                    : (g.bias ? g.bias + s.n0 + (ct - BN / 4) * 4 : nullptr));
                 if (src) lncst = *reinterpret_cast<const f32x4_t*>(src);
+            }
+            if constexpr (FP8 != 0) {
+                const int m = s.m0 + (tid >> 1);
+                a_sc = g.a_scale[m < M ? m : M - 1];
             }
         }
         setup_dma(s);
@@ -552,7 +612,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 const float inv_k = 1.0f / (float)K;
                 const float mean = sum * inv_k;
                 const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
-                lnst[r] = ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, 1.f);
+                lnst[r] = ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, a_sc);
             }
             if (ct < BN / 2) *reinterpret_cast<f32x4_t*>(lnc + ct * 4) = lncst;
         }
@@ -601,17 +661,45 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 const int m = mrow0 + mb * 16;
                 const float2 st = ln[mb * 16 + l15];
                 unsigned pk[4];
+                [[maybe_unused]] float hv8[8];
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
                     float hv[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = st.y * (acc[mb][nf][e] - st.x * c1v[nf][e]) + c2v[nf][e];
-                        const float gt = st.y * (acc[mb][2 + nf][e] - st.x * c1g[nf][e]) + c2g[nf][e];
+                        const float v = fold(acc[mb][nf][e], st.x, st.y, c1v[nf][e], c2v[nf][e]);
+                        const float gt = fold(acc[mb][2 + nf][e], st.x, st.y, c1g[nf][e], c2g[nf][e]);
                         hv[e] = v * silu_fast(gt);
+                        if constexpr (FP8 != 0) hv8[4 * nf + e] = hv[e];
                     }
                     pk[2 * nf] = pack_bf16x2(hv[0], hv[1]);
                     pk[2 * nf + 1] = pack_bf16x2(hv[2], hv[3]);
+                }
+                if constexpr (FP8 != 0) {
+                    if (g.H8) {
+                        // MXFP8 (the A operand of FF-out): the wave's 32 hidden columns are ONE block of token row m, 8 values in each of the
+                        // four lanes q4 = 0..3; scale = 2^e, e = ceil(log2(amax / 448)), stored as E8M0 = e + 127
+                        float am = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) am = fmaxf(am, fabsf(hv8[i]));
+                        am = m < M ? am : 0.f;
+                        am = fmaxf(am, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(am), 0x401F)));              // lane ^ 16
+                        am = fmaxf(am, __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(am))));   // lane ^ 32
+                        const float t = am * (1.0f / 448.0f);
+                        const unsigned tb = __float_as_uint(t);
+                        int e = (int)((tb >> 23) & 0xff) - 127 + ((tb & 0x7fffff) ? 1 : 0);
+                        e = am > 0.f ? (e < -127 ? -127 : (e > 127 ? 127 : e)) : -127;
+                        const float inv = __uint_as_float((unsigned)(127 - e) << 23);
+                        unsigned q0 = __builtin_amdgcn_cvt_pk_fp8_f32(hv8[0] * inv, hv8[1] * inv, 0u, false);
+                        q0 = __builtin_amdgcn_cvt_pk_fp8_f32(hv8[2] * inv, hv8[3] * inv, q0, true);
+                        unsigned q1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv8[4] * inv, hv8[5] * inv, 0u, false);
+                        q1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv8[6] * inv, hv8[7] * inv, q1, true);
+                        if (m < M) {
+                            *reinterpret_cast<u32x2*>(g.H8 + (size_t)m * ldh + (ncol0 >> 1) + q4 * 8) = u32x2{q0, q1};
+                            if (q4 == 0) g.Hs[(size_t)m * (ldh >> 5) + (ncol0 >> 6)] = (unsigned char)(e + 127);
+                        }
+                        continue;
+                    }
                 }
                 if (m < M) *reinterpret_cast<u32x4*>(hbase + (size_t)m * ldh) = u32x4{pk[0], pk[1], pk[2], pk[3]};
             }
@@ -646,7 +734,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) x[nb][e] = st.y * (acc[mb][nb][e] - st.x * c1[nb][e]) + c2[nb][e];
+                        for (int e = 0; e < 4; ++e) x[nb][e] = fold(acc[mb][nb][e], st.x, st.y, c1[nb][e], c2[nb][e]);
                     if (kind & 2) {
                         const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(he.rope_cos + (size_t)sq_ * 16 + 4 * q4);
                         const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(he.rope_sin + (size_t)sq_ * 16 + 4 * q4);
@@ -699,7 +787,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         for (int e = 0; e < 4; ++e) {
                             const float mean = e < 2 ? st01[2 * e] : st23[2 * e - 4];
                             const float rstd = e < 2 ? st01[2 * e + 1] : st23[2 * e - 3];
-                            v[e] = rstd * (acc[mb][nb][e] - mean * c1[nb]) + c2[nb];
+                            v[e] = fold(acc[mb][nb][e], mean, rstd, c1[nb], c2[nb]);
                         }
                         const size_t drow = (size_t)(nb * 16 + l15) * Spad;
                         if (whole4 && shift) {         // aligned: (ss[0] + ob) % 4 == mbase % 4 == 0
@@ -1012,14 +1100,24 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
 unsigned long long* g_ts_buf = nullptr;
 #endif
 
-template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4>
-int launch_ph8(const GemmArgs& a, hipStream_t stream) {
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0>
+int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
+    GemmArgs a = a0;
+    if constexpr (FP8 != 0) {
+        // e4m3 operands with per-token / per-output-channel scales (unit block scales in the MFMA): the kernel counts 16-bit columns,
+        // one 128-byte LDS row = 128 e4m3 = one v_mfma_scale_f32_16x16x128_f8f6f4 step
+        SAT_CHECK_ARG(a0.fp8 == 2 && a0.K % 256 == 0 && a0.a_scale && a0.w_scale, SAT_E_UNSUPPORTED,
+                      "gemm(8-phase, e4m3): K=%d must be a multiple of 256 and both scale vectors given", a0.K);
+        SAT_CHECK_ARG(!a0.ln_part && (EPI == EPI_SWIGLU || !a0.H8), SAT_E_UNSUPPORTED, "gemm(8-phase, e4m3): no LayerNorm fold; MXFP8 output from SwiGLU only");
+        a.K = a0.K / 2;
+    } else {
+        SAT_CHECK_ARG(!a.fp8 && !a.H8, SAT_E_UNSUPPORTED, "gemm(8-phase): built for bf16 operands");
+    }
     constexpr int BM = 64 * MFQ, BN = 64 * WN, NT = 2 * WN * 64;
     constexpr int LDS = 2 * 2 * (BM / 2 + BN / 2) * 128 + 2 * (BM + BN) * 8 + 64;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column) + ticket
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of %d", a.N, BN);
     SAT_CHECK_ARG(a.K % 128 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): K=%d must be a multiple of 128", a.K);
     SAT_CHECK_ARG((uint64_t)a.M * (uint64_t)a.K * 2u < (1ull << 31), SAT_E_UNSUPPORTED, "gemm(8-phase): A larger than 2 GiB");
-    SAT_CHECK_ARG(!a.fp8 && !a.H8, SAT_E_UNSUPPORTED, "gemm(8-phase): bf16 operands only");
     constexpr bool LN_CONS = EPI == EPI_SWIGLU || EPI == EPI_HEADS;
     SAT_CHECK_ARG(LN_CONS || !a.ln_part, SAT_E_UNSUPPORTED, "gemm(8-phase): the LayerNorm fold is finished by the SwiGLU / heads epilogues");
     SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (EPI == EPI_F32 && a.xb && a.ln_part_out), SAT_E_UNSUPPORTED,
@@ -1051,7 +1149,7 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
             if (h) *h = Hit{dev, a.M, a.N, a.K, split, slab_of_device(dev), sc};
         }
     }
-    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ>;
+    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ, FP8>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     unsigned long long* ts = nullptr;
 #ifdef SAT_GEMM_EXPERIMENTS
@@ -1072,7 +1170,10 @@ int launch_ph8(const GemmArgs& a, hipStream_t stream) {
 
 // whether the launcher's automatic choice of the 256 x 256 tile should land here (a forced variant 80 always does)
 bool sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
-    if (a.fp8 || a.H8 || a.N % 256 || a.K % 128 || (uint64_t)a.M * (uint64_t)a.K * 2u >= (1ull << 31)) return false;
+    if (a.N % 256 || a.K % 128 || (uint64_t)a.M * (uint64_t)a.K * 2u >= (1ull << 31)) return false;
+    if (a.fp8 || a.H8) {      // e4m3: the LayerNorm-fed GEMMs (to_qkv, cross to_q, FF-in) with per-token scales
+        if (a.fp8 != 2 || a.K % 256 || a.ln_part || !(epi == EPI_SWIGLU || epi == EPI_HEADS) || (a.H8 && epi != EPI_SWIGLU)) return false;
+    }
     // fp32-output GEMMs with a short reduction (to_out, cross to_out: K = 1536) spend a third of their time in the residual
     // read-modify-write at HBM speed; persistent workgroups run those epilogues in lockstep, the 16-wave tile's independent workgroups
     // drift apart and overlap them with other tiles' main loops: measured 111 us against 122 at 8 prompts (profiles/r03_ph8_streamk.txt)
@@ -1132,12 +1233,14 @@ int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
             if (dbg == 0 && (a.variant & 0x40000)) return launch_ph8<EPI_SWIGLU, 0, false>(a, stream);
             if (dbg == 0 && (a.variant & 0x80000)) return launch_ph8<EPI_SWIGLU, 0, true, 2>(a, stream);
 #endif
+            if (dbg == 0 && a.fp8) return launch_ph8<EPI_SWIGLU, 0, true, 1, 4, 4, 2>(a, stream);
             if (dbg == 0) return launch_ph8<EPI_SWIGLU>(a, stream);
 #ifdef SAT_GEMM_EXPERIMENTS
             if (dbg == 9) return launch_ph8<EPI_SWIGLU, 9>(a, stream);
 #endif
             break;
         case EPI_HEADS:
+            if (dbg == 0 && a.fp8) return launch_ph8<EPI_HEADS, 0, true, 1, 4, 4, 2>(a, stream);
             if (dbg == 0) return launch_ph8<EPI_HEADS>(a, stream);
             break;
     }
