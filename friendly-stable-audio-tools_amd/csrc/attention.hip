@@ -56,7 +56,13 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_run, unsigned& hi_run) 
 // NGRP: 2 = the layout above (128 queries x 2 key ranges); 1 = 256 queries per workgroup, every wave walks ALL the KV tiles of one shared
 // ring (long sequences / many sequences: half the LDS-DMA and K / V^T traffic per query, no merge; chosen by the launcher when the grid
 // still fills the chip)
-template <bool MX8, int DBG = 0, int NGRP = 2>
+// OPT bit 0: lazy rescale -- the softmax reference m_run of a query moves only when a block maximum exceeds it by more than 2^8 (any
+// upper-bounded reference gives the same quotient; P <= 256 is exact territory for bf16 / fp32), so the 32 accumulator multiplies, the
+// extra exponential and the row-sum rescale run in the first tile or two instead of whenever any of the wave's 32 maxima moves;
+// bit 1: row sums from the bf16 probabilities with v_dot2c_f32_bf16 (8 instead of 16 VALU instructions per 32 keys, and the
+// denominator is the sum of exactly the numbers the second MFMA multiplies)
+constexpr int ATT_OPT_DEFAULT = 5;
+template <bool MX8, int DBG = 0, int NGRP = 2, int OPT = ATT_OPT_DEFAULT>
 __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                            unsigned char* __restrict__ out_scales,
@@ -89,6 +95,23 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         const bf16_t* qp = q + ((size_t)(b * H + h) * Sq_pad + (qi < Sq_pad ? qi : Sq_pad - 1)) * 64 + half * 8;
 #pragma unroll
         for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(qp + t * 16);
+    }
+
+    // OPT bit 4: the softmax reference rides in the matrix pipe.  Q is multiplied by scale * log2(e) once (bf16 again), and a fifth
+    // K-step [1, 0, ...] x [-m_ref, 0, ...] makes the S^T accumulator come out as log2-domain scores MINUS the query's reference:
+    // the 16 v_fma_f32 per 32 keys disappear from the (issue-bound) VALU stream, the matrix pipe has the slack.  m_ref is kept
+    // bf16-representable; any reference gives the same quotient.
+    [[maybe_unused]] bf16x8 ones_a, mref_b;
+    if constexpr ((OPT & 16) != 0) {
+        if (scale_log2 != 1.0f) {          // (experiments: a plain Q, rounded a second time)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[t][j] = f32_to_bf16(bf16_to_f32(qf[t][j]) * scale_log2);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ones_a[j] = f32_to_bf16(0.f); mref_b[j] = f32_to_bf16(0.f); }
+        if (half == 0) ones_a[0] = f32_to_bf16(1.0f);
     }
 
     // K rows / V^T columns of sequence b start at ob = (b*Sk) & 3 (see EPI_HEADS in gemm_bf16.hip)
@@ -132,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -1e30f;   // running max, in log2-scaled units
+    float m_run = (OPT & 16) ? 0.f : -1e30f;   // running max (reference), in log2-scaled units
     float l_run = 0.f;      // this lane's partial row sum (its 16 of every 32 keys)
 
     // a wave whose 32 queries are all beyond Sq (tail workgroup) still copies tiles and joins the barriers, but skips the matrix and
@@ -156,6 +179,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = DBG == 3 ? (float)kf[r & 3][r >> 2] : 0.f;
             if constexpr (DBG != 3) {
+                if constexpr ((OPT & 16) != 0) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_a, mref_b, sacc, 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[t], sacc, 0, 0, 0);
             }
@@ -180,7 +204,134 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
             float mloc = sacc[0];
             bf16x8 pb[2];
             float alpha = 1.0f;
-            if constexpr (DBG == 1) {
+            if constexpr (DBG != 1 && (OPT & 16) != 0) {
+                // sacc = log2-domain score - m_run already
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sacc[r]);
+                    psum += p;
+                    pb[r >> 3][r & 7] = f32_to_bf16(p);
+                }
+                const bool first = tile == t_first && kb == 0;          // the first block always fixes a real reference (underflow safety)
+                if (first || !__all(psum <= 4096.0f)) {
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+                    const float m_new = bf16_to_f32(f32_to_bf16(fmaxf(m_run, half_max(mloc) + m_run)));
+                    const float shift = m_run - m_new;                 // <= 0 up to the bf16 rounding of m_new
+                    alpha = __builtin_amdgcn_exp2f(shift);
+                    m_run = m_new;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                    psum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[r] + shift);
+                        psum += p;
+                        pb[r >> 3][r & 7] = f32_to_bf16(p);
+                    }
+                    mref_b[0] = f32_to_bf16(half == 0 ? -m_run : 0.f);
+                }
+                l_run += psum;
+            } else if constexpr (DBG != 1 && (OPT & 4) != 0) {
+                // fast path without a maximum: exponentials against the standing reference; the row sum itself is the overflow check
+                // (every p <= its lane's sum).  Only when some lane's sum leaves [0, 2^12] -- the first block (reference -1e30 -> inf),
+                // or a score more than 12 octaves above the reference -- the block is redone the classic way: true maximum, rescale.
+                float psum = 0.f;
+                if constexpr ((OPT & 8) != 0) {               // packed fp32 for the scale and the sum (v_pk_fma_f32 / v_pk_add_f32)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 sc2 = {scale_log2, scale_log2}, mm2 = {-m_run, -m_run};
+                    f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        f32x2 x = {sacc[r], sacc[r + 1]};
+                        x = __builtin_elementwise_fma(x, sc2, mm2);
+                        const f32x2 pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                        ps2 += pp;
+                        pb[r >> 3][r & 7] = f32_to_bf16(pp[0]);
+                        pb[r >> 3][(r & 7) + 1] = f32_to_bf16(pp[1]);
+                    }
+                    psum = ps2[0] + ps2[1];
+                } else if constexpr ((OPT & 2) != 0) {        // row sum of the bf16 probabilities: one v_dot2c_f32_bf16 per pair
+                    float psum2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = f32_to_bf16(__builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_run)));
+                    const unsigned ones = 0x3f803f80u;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const u32x4 w = __builtin_bit_cast(u32x4, pb[i]);
+                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum) : "v"(w[0]), "v"(ones));
+                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum2) : "v"(w[1]), "v"(ones));
+                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum) : "v"(w[2]), "v"(ones));
+                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum2) : "v"(w[3]), "v"(ones));
+                    }
+                    psum += psum2;
+                } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_run));
+                    psum += p;
+                    pb[r >> 3][r & 7] = f32_to_bf16(p);
+                }
+                }
+                if (!__all(psum <= 4096.0f)) {                 // wave-uniform (NaN-safe: inf - inf cannot arise, m_run is finite)
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+                    const float m_new = fmaxf(m_run, half_max(mloc) * scale_log2);
+                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                    psum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_run));
+                        psum += p;
+                        pb[r >> 3][r & 7] = f32_to_bf16(p);
+                    }
+                }
+                l_run += psum;
+            } else if constexpr (DBG != 1 && (OPT & 1) != 0) {
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+                mloc = half_max(mloc) * scale_log2;
+                if (!__all(mloc <= m_run + 8.0f)) {            // wave-uniform; masked keys (-inf) never trigger it
+                    const float m_new = fmaxf(m_run, mloc);
+                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m_run = m_new;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                }
+                float psum = 0.f, psum2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_run));
+                    if constexpr ((OPT & 2) == 0) psum += p;
+                    pb[r >> 3][r & 7] = f32_to_bf16(p);
+                }
+                if constexpr ((OPT & 2) != 0) {
+                    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+                    const bf2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const u32x4 w = __builtin_bit_cast(u32x4, pb[i]);
+                        psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w[0]), ones, psum, false);
+                        psum2 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w[1]), ones, psum2, false);
+                        psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w[2]), ones, psum, false);
+                        psum2 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w[3]), ones, psum2, false);
+                    }
+                }
+                l_run += psum + psum2;
+            } else if constexpr (DBG == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = f32_to_bf16(sacc[r]);
                 l_run += sacc[0];
@@ -200,11 +351,13 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
                 }
                 l_run = l_run * alpha + psum;
             }
-            if (!__all(alpha == 1.0f)) {
+            if constexpr ((OPT & 21) == 0) {
+                if (!__all(alpha == 1.0f)) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                }
             }
             // ---- O^T += V^T P^T
 #pragma unroll
@@ -356,7 +509,7 @@ extern "C" int sat_attention_dbg_read(unsigned long long* out4) {
 #endif
 
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
-                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales) {
+                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales, float q_scale) {
     SAT_CHECK_ARG(q && k && vt && out, SAT_E_INVALID, "attention: null pointer");
     SAT_CHECK_ARG(b > 0 && h > 0 && kvh > 0 && h % kvh == 0, SAT_E_INVALID, "attention: bad heads %d/%d", h, kvh);
     SAT_CHECK_ARG(sq > 0 && sk > 0 && sq_pad >= sq && sk_pad >= sk, SAT_E_INVALID, "attention: bad lengths");
@@ -364,13 +517,17 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
                   "attention: sq_pad %% 128 and sk_pad %% 64 must be 0 (got %d, %d)", sq_pad, sk_pad);
     SAT_CHECK_ARG(sk_pad >= sk + 3, SAT_E_INVALID, "attention: sk_pad must be >= sk + 3 (key-side shift), got %d for sk=%d", sk_pad, sk);
     SAT_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0, SAT_E_INVALID, "attention: pointers must be 16-byte aligned");
-    const float scale_log2 = 0.125f * 1.4426950408889634f;   // 1/sqrt(64) * log2(e)
+    const float scale_log2 = q_scale;       // SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e), or 1 for a pre-scaled Q
     dim3 grid(cdiv(sq, Q_BLOCK), h, b);
     // One KV group (256 queries per workgroup, every wave walks all the KV tiles) when the grid still gives every CU its two workgroups
     // twice over, or when there are too few keys to split (cross-attention: 130 keys = 3 tiles).  Measured (profiles/
     // r03_attention_groups.txt): SA-2.0 self-attention 650 -> 617 us, 8 prompts 214 -> 205, cross 10.8 -> 9.8; at one prompt (240
     // workgroups of 256 queries for 512 slots) the split stays: 31.1 vs 32.6 us.  SAT_ATTN_GROUPS = 1 | 2 forces a layout (A/B).
+#ifdef SAT_GEMM_EXPERIMENTS
+    const int force_grp = [] { const char* e = getenv("SAT_ATTN_GROUPS"); return e ? atoi(e) : 0; }();      // re-read per launch (A/B in one process)
+#else
     static const int force_grp = [] { const char* e = getenv("SAT_ATTN_GROUPS"); return e ? atoi(e) : 0; }();
+#endif
     const long wg1 = (long)cdiv(sq, 256) * h * b;
     const bool one_group = force_grp ? force_grp == 1 : (wg1 >= 1024 || sk <= 512);
 #ifdef SAT_GEMM_EXPERIMENTS
@@ -386,6 +543,40 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
         return 0;
     }
 #endif
+#ifdef SAT_GEMM_EXPERIMENTS
+    if (const char* eo = getenv("SAT_ATTN_OPT"); eo && !out_scales) {
+        auto launch = [&](auto kern, dim3 g, int lds) {
+            (void)sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+            hipLaunchKernelGGL(kern, g, dim3(512), lds, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
+        };
+        const dim3 g1(cdiv(sq, 256), h, b);
+        switch (atoi(eo) + (one_group ? 100 : 0)) {
+            case 0: launch(attention_kernel<false, 0, 2, 0>, grid, ATT_LDS); return 0;
+            case 1: launch(attention_kernel<false, 0, 2, 1>, grid, ATT_LDS); return 0;
+            case 2: launch(attention_kernel<false, 0, 2, 2>, grid, ATT_LDS); return 0;
+            case 3: launch(attention_kernel<false, 0, 2, 3>, grid, ATT_LDS); return 0;
+            case 5: launch(attention_kernel<false, 0, 2, 5>, grid, ATT_LDS); return 0;
+            case 13: launch(attention_kernel<false, 0, 2, 13>, grid, ATT_LDS); return 0;
+            case 7: launch(attention_kernel<false, 0, 2, 7>, grid, ATT_LDS); return 0;
+            case 16: launch(attention_kernel<false, 0, 2, 16>, grid, ATT_LDS); return 0;
+            case 100: launch(attention_kernel<false, 0, 1, 0>, g1, 3 * STAGE_BYTES); return 0;
+            case 101: launch(attention_kernel<false, 0, 1, 1>, g1, 3 * STAGE_BYTES); return 0;
+            case 102: launch(attention_kernel<false, 0, 1, 2>, g1, 3 * STAGE_BYTES); return 0;
+            case 103: launch(attention_kernel<false, 0, 1, 3>, g1, 3 * STAGE_BYTES); return 0;
+            case 105: launch(attention_kernel<false, 0, 1, 5>, g1, 3 * STAGE_BYTES); return 0;
+            case 113: launch(attention_kernel<false, 0, 1, 13>, g1, 3 * STAGE_BYTES); return 0;
+            case 107: launch(attention_kernel<false, 0, 1, 7>, g1, 3 * STAGE_BYTES); return 0;
+            case 116: launch(attention_kernel<false, 0, 1, 16>, g1, 3 * STAGE_BYTES); return 0;
+        }
+    }
+#endif
+    if (one_group && !out_scales && q_scale == 1.0f) {      // pre-scaled Q: the reference rides in the matrix pipe (OPT bit 4)
+        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 0, 1, 16>), 3 * STAGE_BYTES));
+        hipLaunchKernelGGL((attention_kernel<false, 0, 1, 16>), dim3(cdiv(sq, 256), h, b), dim3(512), 3 * STAGE_BYTES, s, q, k, vt, out, out_scales, h, kvh,
+                           sq, sk, sq_pad, sk_pad, scale_log2);
+        SAT_LAUNCH_CHECK();
+        return 0;
+    }
     if (one_group && !out_scales) {
         SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 0, 1>), 3 * STAGE_BYTES));
         hipLaunchKernelGGL((attention_kernel<false, 0, 1>), dim3(cdiv(sq, 256), h, b), dim3(512), 3 * STAGE_BYTES, s, q, k, vt, out, out_scales, h, kvh, sq, sk,

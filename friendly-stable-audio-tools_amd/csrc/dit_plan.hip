@@ -411,11 +411,11 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (L.fold_qkv) fold_in(g, L.c1_qkv, L.c2_qkv);
         if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_qkv; }
         g.heads.out[0] = w.Q; g.heads.out[1] = w.K; g.heads.out[2] = w.Vt;
-        g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
+        g.heads.kind[0] = 2 | 8; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4; g.heads.qscale = SAT_ATTN_QSCALE;
         g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
         g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
         SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
-        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, f8 ? w.AOs : nullptr));
+        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, f8 ? w.AOs : nullptr, 1.0f));
         g = GemmArgs{};
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
@@ -436,11 +436,12 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 g.A = w.A; g.W = L.w_cq; g.M = Mc; g.N = D; g.K = D;
                 if (lf) fold_in(g, L.c1_cq, L.c2_cq);
                 if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_cq; }
-                g.heads.out[0] = w.Q; g.heads.kind[0] = 0; g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
+                g.heads.out[0] = w.Q; g.heads.kind[0] = 8; g.heads.qscale = SAT_ATTN_QSCALE;
+                g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
                 SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
                 const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lcpad * 64;
                 SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
-                                             p->ctx_lc, Spad, p->ctx_lcpad, s, f8 ? w.AOs : nullptr));
+                                             p->ctx_lc, Spad, p->ctx_lcpad, s, f8 ? w.AOs : nullptr, 1.0f));
                 g = GemmArgs{};
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
                 if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
@@ -758,6 +759,13 @@ extern "C" int sat_attention_bf16(const void* q, const void* k, const void* vt, 
                                   int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
     return sat_launch_attention((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, b, h, kvh, sq, sk, sq_pad,
                                 sk_pad, (hipStream_t)stream);
+}
+
+// The layout the DiT plan runs: Q pre-scaled by 1/sqrt(64) * log2(e) by its producer (the QKV / to_q GEMM epilogue)
+extern "C" int sat_attention_prescaled_bf16(const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
+                                            int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
+    return sat_launch_attention((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, b, h, kvh, sq, sk, sq_pad,
+                                sk_pad, (hipStream_t)stream, nullptr, 1.0f);
 }
 
 extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_freq, void* q, void* k, void* vt,

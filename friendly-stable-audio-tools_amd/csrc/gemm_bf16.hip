@@ -190,13 +190,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                             }
                     }
                 } else {
+                    const float qs = (kind & 8) ? he.qscale : 1.0f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (mb + e < M) {
                             const int ob = shift ? ((bb[e] * S) & 3) : 0;
                             const size_t base = ((size_t)(bb[e] * he.heads + head) * Spad + ss[e] + ob) * 64;
-                            dst[base + l31] = f32_to_bf16(v0[e]);
-                            dst[base + 32 + l31] = f32_to_bf16(v1[e]);
+                            dst[base + l31] = f32_to_bf16(v0[e] * qs);
+                            dst[base + 32 + l31] = f32_to_bf16(v1[e] * qs);
                         }
                 }
             }
@@ -374,6 +375,12 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                     acc[i][0][r] = x1 * cs - x2 * sn;
                     acc[i][0][r + 8] = x2 * cs + x1 * sn;
                 }
+            }
+            if (kind & 8) {   // query: pre-scaled for the attention kernel (one rounding, here)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= he.qscale;
             }
             bf16_t* row = dst + ((size_t)(b * he.heads + head) * Spad + s + ob) * 64 + 8 * half;
 #pragma unroll

@@ -745,6 +745,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                             x[1][e] = x2 * cs[e] + x1 * sn[e];
                         }
                     }
+                    if (kind & 8) {   // query: pre-scaled for the attention kernel (one rounding, here)
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) x[nb] *= he.qscale;
+                    }
                     if (m < M) {
                         bf16_t* row = dst + ((size_t)(b * he.heads + head) * Spad + sq_ + ob) * 64;
                         *reinterpret_cast<u32x2*>(row + 4 * q4) = u32x2{pack_bf16x2(x[0][0], x[0][1]), pack_bf16x2(x[0][2], x[0][3])};

@@ -199,6 +199,9 @@ struct HeadsEpi {
     bf16_t* out[3];      // per part destination
     int kind[3];         // bit0: transposed ([B,Hh,64,Spad]) else [B,Hh,Spad,64]; bit1: apply RoPE;
                          // bit2: key-side tensor (K / V^T): rows/columns of sequence b shifted by (b*S)&3
+                         // bit3: query tensor written PRE-SCALED by `qscale` (row-major destinations only): the attention
+                         //       kernel then gets log2-domain scores straight out of its first MFMA (SAT_ATTN_QSCALE)
+    float qscale;
     int parts;           // N == parts * heads * 64
     int heads;           // heads per part
     int S;               // valid rows per sequence (row m -> b = m / S, s = m % S)
@@ -262,8 +265,13 @@ int sat_launch_layernorm_fp8(const float* x, const float* gamma, const float* be
 int sat_launch_quant_rows_fp8(const float* w, void* out8, float* row_scale, int n, int k, int swiglu_interleave, hipStream_t s);
 int sat_launch_quant_mx_rows(const float* x, void* out8, void* scales_e8m0, int rows, int k, hipStream_t s);
 // out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
+// q_scale: what the kernel still has to multiply in -- SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e) for a plain Q, 1.0f for a Q the
+// producer already wrote pre-scaled (HeadsEpi kind bit 3): only then the single-KV-group kernel carries its softmax reference
+// through the matrix pipe (a plain Q would have to be rounded to bf16 a second time).
+#define SAT_ATTN_QSCALE (0.125f * 1.4426950408889634f)
 int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
-                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales = nullptr);
+                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales = nullptr,
+                         float q_scale = SAT_ATTN_QSCALE);
 // fp32 verification path (f32_ref.hip)
 int sat_launch_gemm_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int ldc, int accumulate,
                         const float* gate, int gate_rows, int gate_ld, hipStream_t s);

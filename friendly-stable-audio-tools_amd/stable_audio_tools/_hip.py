@@ -84,6 +84,8 @@ _SIGNATURES = {
                                        c_int32, c_void_p]),
     "sat_attention_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                      c_int32, c_int32, c_void_p]),
+    "sat_attention_prescaled_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                               c_int32, c_int32, c_void_p]),
     "sat_qkv_rope_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                     c_int32, c_int32, c_int32, c_void_p]),
     "sat_gemm_resid_ln_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,

@@ -273,6 +273,13 @@ int sat_gemm_swiglu_bf16(const void* a_bf16_dev, const float* w_f32_dev, const f
 int sat_attention_bf16(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
                        int32_t b, int32_t h, int32_t kvh, int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad,
                        sat_stream_t stream);
+/* The same with q PRE-SCALED by its producer: q holds bf16(q_fp32 * log2(e) / 8), i.e. the scores come out of the first MFMA
+ * in the log2 domain.  This is the layout the DiT plan runs (its QKV / to_q GEMM epilogues write it with one rounding); it lets
+ * the single-KV-group kernel carry the softmax reference through the matrix pipe as a fifth K-step, which removes the per-score
+ * multiply-add from the issue-bound VALU stream (attention). */
+int sat_attention_prescaled_bf16(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
+                                 int32_t b, int32_t h, int32_t kvh, int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad,
+                                 sat_stream_t stream);
 /* Fused QKV projection + partial RoPE + head split (models/transformer.py:430-452):
  * a [b*s, d] bf16, w_qkv [3d, d] bf16 -> q,k [b,h,s_pad,64], vt [b,h,64,s_pad] bf16 (k / vt in the key-side
  * layout of sat_attention_bf16; s_pad % 128 == 0, s_pad >= s + 3).

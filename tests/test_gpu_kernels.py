@@ -120,26 +120,38 @@ def _pad_heads(x, s_pad, key_side=False):
     return out
 
 
-@pytest.mark.parametrize("b,h,kvh,sq,sk", [(2, 4, 4, 1025, 1025), (1, 4, 2, 300, 130), (2, 2, 2, 64, 64), (1, 2, 1, 129, 7)])
-def test_attention(dev, b, h, kvh, sq, sk):
+@pytest.mark.parametrize("prescaled", [False, True])
+@pytest.mark.parametrize("b,h,kvh,sq,sk", [(2, 4, 4, 1025, 1025), (1, 4, 2, 300, 130), (2, 2, 2, 64, 64), (1, 2, 1, 129, 7), (8, 64, 8, 300, 700)])
+def test_attention(dev, b, h, kvh, sq, sk, prescaled):
+    """prescaled: the layout the DiT plan runs -- Q carries log2(e)/8 (written so by the QKV epilogue); every shape with <= 512 keys or
+    >= 1024 workgroups of 256 queries then takes the single-KV-group kernel whose softmax reference rides in the matrix pipe."""
     from oracle import dit as odit
     _hip, lib = _lib()
+    if b * h > 16 and not prescaled:
+        pytest.skip("the 1024-workgroup grid is there for the pre-scaled single-group kernel on a long key range (11 tiles)")
     q = (_rand((b, h, sq, 64), 12) * 1.5).to(torch.bfloat16)
     k = (_rand((b, kvh, sk, 64), 13) * 1.5).to(torch.bfloat16)
     v = _rand((b, kvh, sk, 64), 14).to(torch.bfloat16)
     # spike one key against one query so that the running max jumps late in the sequence (rescale branch)
     k[0, 0, sk - 1] = q[0, 0, min(5, sq - 1)] * 3
-    want = odit._merge(odit.attention_core(q.float(), k.float(), v.float(), rnd=bf16_round))
+    fn = lib.sat_attention_bf16
+    if prescaled:
+        c = 0.125 * 1.4426950408889634
+        q = (q.float() * c).to(torch.bfloat16)          # what the producer stores ...
+        fn = lib.sat_attention_prescaled_bf16
+        q_eff = q.float() / c                           # ... and the query it stands for
+    else:
+        q_eff = q.float()
+    want = odit._merge(odit.attention_core(q_eff, k.float(), v.float(), rnd=bf16_round))
     sq_pad = (sq + 127) // 128 * 128
     sk_pad = (sk + 3 + 63) // 64 * 64
     qd = _pad_heads(q, sq_pad).to(dev)
     kd = _pad_heads(k, sk_pad, key_side=True).to(dev)
     vtd = _pad_heads(v, sk_pad, key_side=True).transpose(2, 3)[..., _vt_perm(sk_pad)].contiguous().to(dev)
     out = torch.empty((b * sq, h * 64), dtype=torch.bfloat16, device=dev)
-    _hip.check(lib.sat_attention_bf16(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, h, kvh, sq, sk, sq_pad, sk_pad,
-                                      _hip.stream()))
+    _hip.check(fn(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, h, kvh, sq, sk, sq_pad, sk_pad, _hip.stream()))
     assert_close(f"attention {b}x{h}x{sq}x{sk}", out.view(b, sq, h * 64), want, 5e-3)
-    exact = odit._merge(odit.attention_core(q.float(), k.float(), v.float()))
+    exact = odit._merge(odit.attention_core(q_eff, k.float(), v.float()))
     assert rel_l2(out.view(b, sq, h * 64), exact) < 1e-2
 
 
