@@ -1042,6 +1042,24 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
         if (!split) {
             const long q = s.sk_tiles / s.G, r = s.sk_tiles % s.G;
             for (int i = 0; i < s.G; ++i) share.push_back((int)((q + (i < r ? 1 : 0)) * s.nkp));
+        } else if (split == 2) {
+            // stream-K proper: the remainder's K-units in one line, cut into G equal contiguous shares (a share spans at most two
+            // tiles when it is shorter than a tile: two partial K-ranges, two slab slots).  Light tiles count half.
+            long cost2 = 0;
+            for (int j = 0; j < s.sk_tiles; ++j) cost2 += is_light(tile[j]) ? 1 : 2;
+            // walk the line in cost space: boundary i sits at cost i * cost2 * nkp / G (in half-units), mapped back to units
+            std::vector<long> cum(s.sk_tiles + 1, 0);          // cumulative cost (half-units x nkp) at tile starts
+            for (int j = 0; j < s.sk_tiles; ++j) cum[j + 1] = cum[j] + (is_light(tile[j]) ? 1 : 2) * (long)s.nkp;
+            long prev = 0;
+            int j = 0;
+            for (int i = 1; i <= s.G; ++i) {
+                const long target = cum[s.sk_tiles] * i / s.G;
+                while (j < s.sk_tiles && cum[j + 1] <= target) ++j;
+                long u = j < s.sk_tiles ? (long)j * s.nkp + (target - cum[j]) / (is_light(tile[j]) ? 1 : 2) : (long)s.sk_tiles * s.nkp;
+                if (i == s.G) u = (long)s.sk_tiles * s.nkp;
+                share.push_back((int)(u - prev));
+                prev = u;
+            }
         } else {
             long cost2 = 0;              // in halves of a full tile
             for (int j = 0; j < s.sk_tiles; ++j) cost2 += is_light(tile[j]) ? 1 : 2;
@@ -1133,8 +1151,8 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
             SAT_CHECK_ARG((a.heads.kind[p] & 3) != 3, SAT_E_UNSUPPORTED, "gemm(8-phase): no rotation on a transposed destination");
     }
     Ph8Sched sc;
-    // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements)
-    const int split = (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;
+    // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements); bit 20: contiguous stream-K shares
+    const int split = (a.variant & 0x100000) ? 2 : (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;
     {
         // launch path: the few shapes of a plan are found in a thread-local table without taking the lock
         struct Hit { int dev, M, N, K, split; float* slab; Ph8Sched s; };

@@ -358,6 +358,37 @@ def ablate():
         arms_bench("ablate " + name, m, n, k, [80, 180, 280, 380], blas=False, rounds=3)
 
 
+def ffout():
+    """FF-out (fp32 residual update + LayerNorm-fold producer, K = 6144): whole tiles vs per-tile K parts vs contiguous stream-K shares of
+    the remainder round, interleaved; the split results are checked against the whole-tile result"""
+    for name, m in [("B1", 2050), ("B4", 8200), ("B8", 16400), ("sa2", 12290)]:
+        nn, kk = 1536, 6144
+        a = torch.randn(m, kk, device=dev).to(torch.bfloat16)
+        w2 = (torch.randn(nn, kk, device=dev) * 0.05).to(torch.bfloat16)
+        b2 = torch.randn(nn, device=dev)
+        c = torch.zeros(m, nn, device=dev)
+        xo = torch.empty((m, nn), dtype=torch.bfloat16, device=dev)
+        po = torch.empty((m, nn // 64, 2), dtype=torch.float32, device=dev)
+        mk = lambda v: (lambda: _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, nn, kk, v,
+                                                                       _hip.stream())))
+        arms = {"v22": 22, "whole": 80 | 0x20000, "parts": 80 | 0x10000, "streamK": 80 | 0x100000, "auto": 0}
+        ref = None
+        for k_, v in arms.items():
+            c.zero_(); mk(v)(); torch.cuda.synchronize()
+            got = (c.clone(), xo.float().clone(), po.clone())
+            if k_ == "whole":
+                ref = got
+            elif ref is not None:
+                errs = [((g_ - r_).norm() / r_.norm()).item() for g_, r_ in zip(got, ref)]
+                assert max(errs) < 2e-3, (name, k_, errs)
+        res = {k_: [] for k_ in arms}
+        for _ in range(5):
+            for k_, v in arms.items():
+                res[k_].append(timeit(mk(v), iters=10, warm=2))
+        flops = 2.0 * m * nn * kk
+        print(f"ff_out {name:4s} {m}x{nn}x{kk}: " + " | ".join(f"{k_} {statistics.median(t)*1e3:6.1f} us {flops/statistics.median(t)/1e9:6.1f} TF" for k_, t in res.items()), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["calib", "race", "shapes"]
     print(torch.cuda.get_device_name(0), flush=True)
