@@ -169,6 +169,8 @@ def main():
                     help="GEMM operand type: bf16 (headline) or fp8 = BASELINE config 5 (e4m3 to_qkv / cross to_q / FF-in, rest bf16)")
     ap.add_argument("--layernorm", choices=("fused", "standalone"), default="fused",
                     help="LayerNorms of the blocks inside the GEMM epilogues (sat_dit_cfg.ln_fold, default) or as three kernels per block")
+    ap.add_argument("--cross-attention", choices=("fused", "separate"), default="fused",
+                    help="A/B: to_q + cross-attention core as one launch (where it applies: one prompt per GPU) or as two kernels")
     ap.add_argument("--workload", choices=("sa_open", "sa2_a2a"), default="sa_open",
                     help="sa_open: the headline (BASELINE config 2/3); sa2_a2a: config 4, SA-2.0 shape, audio-to-audio, 1 GPU")
     ap.add_argument("--dry-run", action="store_true", help="check the arguments and print the rank -> prompt plan as JSON; touches no GPU")
@@ -267,6 +269,8 @@ def main():
     dit = model.model.model
     dit.set_gemm_dtype(args.dtype)
     dit.set_layernorm_fusion(args.layernorm == "fused")
+    from stable_audio_tools import _hip
+    _hip.check(_hip.lib().sat_set_cross_attention_fusion(1 if args.cross_attention == "fused" else 0))
 
     from stable_audio_tools import _hip
     lib = _hip.lib()
@@ -316,7 +320,7 @@ def main():
                                     f"{args.batch} prompt(s)/GPU x 47.55 s, 100 DPM-Solver++(3M) SDE steps") if args.workload == "sa_open" else
                                    ("Stable Audio 2.0 shape (24 layers, D=1536, S=6145, CFG 7) audio-to-audio: Oobleck encode of 285.3 s init audio + "
                                     f"100 DPM-Solver++(3M) SDE steps from sigma 7 + decode, {args.batch} prompt(s)/GPU"), "prompts_per_gpu": args.batch,
-                       "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "layernorm": args.layernorm, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
+                       "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "layernorm": args.layernorm, "cross_attention": args.cross_attention, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
             "roofline": {"bound": "mfma", "kernel": f"FFN-in SwiGLU GEMM M={m.value} N={n.value} K={k.value} ({args.dtype} MFMA, fp32 acc)", "achieved": achieved,
                          "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak, "traffic": traffic,
                          "traffic_source": traffic_source, "avg_launch_us": avg_ms * 1e3, "launches_timed": cnt.value},

@@ -23,26 +23,19 @@
 // what lets the kernel run at 4 waves per SIMD (<= 128 VGPRs).
 #include <stdlib.h>
 
+#include "attn_core.h"
 #include "sat_common.h"
 
 namespace {
 
-constexpr int KV_TILE = 64;
+constexpr int KV_TILE = attn::KV_TILE;
 constexpr int Q_BLOCK = 128;
 constexpr int STAGE_BYTES = 2 * KV_TILE * 128;            // K tile + V^T tile
 constexpr int GROUP_BYTES = 2 * STAGE_BYTES;              // 2-stage ring per KV group
 constexpr int ATT_LDS = 2 * GROUP_BYTES;                  // 64 KiB: two workgroups per CU
 
-__device__ __forceinline__ float half_max(float v) {     // max over the lane pair (l, l ^ 32), in both lanes
-    unsigned a = __float_as_uint(v), b = a;
-    u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float half_sum(float v) {
-    unsigned a = __float_as_uint(v), b = a;
-    u32x2 r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
+using attn::half_max;
+using attn::half_sum;
 __device__ __forceinline__ void swap_halves(unsigned& lo_run, unsigned& hi_run) {
     u32x2 r = __builtin_amdgcn_permlane32_swap(lo_run, hi_run, false, false);
     lo_run = r[0];
@@ -56,13 +49,10 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_run, unsigned& hi_run) 
 // NGRP: 2 = the layout above (128 queries x 2 key ranges); 1 = 256 queries per workgroup, every wave walks ALL the KV tiles of one shared
 // ring (long sequences / many sequences: half the LDS-DMA and K / V^T traffic per query, no merge; chosen by the launcher when the grid
 // still fills the chip)
-// OPT bit 0: lazy rescale -- the softmax reference m_run of a query moves only when a block maximum exceeds it by more than 2^8 (any
-// upper-bounded reference gives the same quotient; P <= 256 is exact territory for bf16 / fp32), so the 32 accumulator multiplies, the
-// extra exponential and the row-sum rescale run in the first tile or two instead of whenever any of the wave's 32 maxima moves;
-// bit 1: row sums from the bf16 probabilities with v_dot2c_f32_bf16 (8 instead of 16 VALU instructions per 32 keys, and the
-// denominator is the sum of exactly the numbers the second MFMA multiplies)
-constexpr int ATT_OPT_DEFAULT = 5;
-template <bool MX8, int DBG = 0, int NGRP = 2, int OPT = ATT_OPT_DEFAULT>
+// MODE: the softmax recurrence of attn_core.h -- 1 (default): standing reference, the row sum is the overflow check; 2: the same with
+// the reference carried through the matrix pipe, for a Q its producer wrote pre-scaled (scale_log2 == 1; anything else is multiplied
+// into Q here and rounded to bf16 a second time: experiments); 0: the textbook recurrence (experiments build).
+template <bool MX8, int DBG = 0, int NGRP = 2, int MODE = 1>
 __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                            unsigned char* __restrict__ out_scales,
@@ -97,21 +87,13 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(qp + t * 16);
     }
 
-    // OPT bit 4: the softmax reference rides in the matrix pipe.  Q is multiplied by scale * log2(e) once (bf16 again), and a fifth
-    // K-step [1, 0, ...] x [-m_ref, 0, ...] makes the S^T accumulator come out as log2-domain scores MINUS the query's reference:
-    // the 16 v_fma_f32 per 32 keys disappear from the (issue-bound) VALU stream, the matrix pipe has the slack.  m_ref is kept
-    // bf16-representable; any reference gives the same quotient.
-    [[maybe_unused]] bf16x8 ones_a, mref_b;
-    if constexpr ((OPT & 16) != 0) {
+    if constexpr (MODE == 2) {
         if (scale_log2 != 1.0f) {          // (experiments: a plain Q, rounded a second time)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[t][j] = f32_to_bf16(bf16_to_f32(qf[t][j]) * scale_log2);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { ones_a[j] = f32_to_bf16(0.f); mref_b[j] = f32_to_bf16(0.f); }
-        if (half == 0) ones_a[0] = f32_to_bf16(1.0f);
     }
 
     // K rows / V^T columns of sequence b start at ob = (b*Sk) & 3 (see EPI_HEADS in gemm_bf16.hip)
@@ -150,13 +132,11 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         }
     };
 
-    f32x16 oacc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = (OPT & 16) ? 0.f : -1e30f;   // running max (reference), in log2-scaled units
-    float l_run = 0.f;      // this lane's partial row sum (its 16 of every 32 keys)
+    attn::State<MODE> st;
+    st.init(half);
+    f32x16 (&oacc)[2] = st.oacc;
+    float& m_run = st.m_run;
+    float& l_run = st.l_run;
 
     // a wave whose 32 queries are all beyond Sq (tail workgroup) still copies tiles and joins the barriers, but skips the matrix and
     // softmax work
@@ -166,208 +146,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
         const char* sk = ring + stage * STAGE_BYTES;
         const char* sv = sk + KV_TILE * 128;
         const bool edge = (tile == 0 && ob != 0) || (tile == n_tiles - 1 && (k_end & (KV_TILE - 1)) != 0);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            // ---- S^T = K Q^T for 32 keys
-            bf16x8 kf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if constexpr (DBG == 5) kf[t] = qf[t];
-                else kf[t] = *reinterpret_cast<const bf16x8*>(sk + lds_tile_off(kb * 32 + l31, t * 2 + half));
-            }
-            f32x16 sacc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = DBG == 3 ? (float)kf[r & 3][r >> 2] : 0.f;
-            if constexpr (DBG != 3) {
-                if constexpr ((OPT & 16) != 0) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_a, mref_b, sacc, 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[t], sacc, 0, 0, 0);
-            }
-            // V^T fragments do not depend on the softmax: request them now, their LDS latency hides behind the VALU work
-            bf16x8 vf[2][2];
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if constexpr (DBG == 5) vf[db][u] = qf[db * 2 + u];
-                    else vf[db][u] = *reinterpret_cast<const bf16x8*>(sv + lds_tile_off(db * 32 + l31, (kb * 2 + u) * 2 + half));
-            // ---- mask the keys outside [ob, ob + Sk) (wave-uniform branch: first and last tile only)
-            if (edge) {
-                const int key0 = tile * KV_TILE + kb * 32 + 4 * half;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + (r & 3) + 8 * (r >> 2);
-                    if (key < ob || key >= k_end) sacc[r] = -INFINITY;
-                }
-            }
-            // ---- online softmax step (per query = per lane pair)
-            float mloc = sacc[0];
-            bf16x8 pb[2];
-            float alpha = 1.0f;
-            if constexpr (DBG != 1 && (OPT & 16) != 0) {
-                // sacc = log2-domain score - m_run already
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(sacc[r]);
-                    psum += p;
-                    pb[r >> 3][r & 7] = f32_to_bf16(p);
-                }
-                const bool first = tile == t_first && kb == 0;          // the first block always fixes a real reference (underflow safety)
-                if (first || !__all(psum <= 4096.0f)) {
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-                    const float m_new = bf16_to_f32(f32_to_bf16(fmaxf(m_run, half_max(mloc) + m_run)));
-                    const float shift = m_run - m_new;                 // <= 0 up to the bf16 rounding of m_new
-                    alpha = __builtin_amdgcn_exp2f(shift);
-                    m_run = m_new;
-                    l_run *= alpha;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-                    psum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(sacc[r] + shift);
-                        psum += p;
-                        pb[r >> 3][r & 7] = f32_to_bf16(p);
-                    }
-                    mref_b[0] = f32_to_bf16(half == 0 ? -m_run : 0.f);
-                }
-                l_run += psum;
-            } else if constexpr (DBG != 1 && (OPT & 4) != 0) {
-                // fast path without a maximum: exponentials against the standing reference; the row sum itself is the overflow check
-                // (every p <= its lane's sum).  Only when some lane's sum leaves [0, 2^12] -- the first block (reference -1e30 -> inf),
-                // or a score more than 12 octaves above the reference -- the block is redone the classic way: true maximum, rescale.
-                float psum = 0.f;
-                if constexpr ((OPT & 8) != 0) {               // packed fp32 for the scale and the sum (v_pk_fma_f32 / v_pk_add_f32)
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const f32x2 sc2 = {scale_log2, scale_log2}, mm2 = {-m_run, -m_run};
-                    f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        f32x2 x = {sacc[r], sacc[r + 1]};
-                        x = __builtin_elementwise_fma(x, sc2, mm2);
-                        const f32x2 pp = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                        ps2 += pp;
-                        pb[r >> 3][r & 7] = f32_to_bf16(pp[0]);
-                        pb[r >> 3][(r & 7) + 1] = f32_to_bf16(pp[1]);
-                    }
-                    psum = ps2[0] + ps2[1];
-                } else if constexpr ((OPT & 2) != 0) {        // row sum of the bf16 probabilities: one v_dot2c_f32_bf16 per pair
-                    float psum2 = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = f32_to_bf16(__builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_run)));
-                    const unsigned ones = 0x3f803f80u;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const u32x4 w = __builtin_bit_cast(u32x4, pb[i]);
-                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum) : "v"(w[0]), "v"(ones));
-                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum2) : "v"(w[1]), "v"(ones));
-                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum) : "v"(w[2]), "v"(ones));
-                        asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(psum2) : "v"(w[3]), "v"(ones));
-                    }
-                    psum += psum2;
-                } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_run));
-                    psum += p;
-                    pb[r >> 3][r & 7] = f32_to_bf16(p);
-                }
-                }
-                if (!__all(psum <= 4096.0f)) {                 // wave-uniform (NaN-safe: inf - inf cannot arise, m_run is finite)
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-                    const float m_new = fmaxf(m_run, half_max(mloc) * scale_log2);
-                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    m_run = m_new;
-                    l_run *= alpha;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-                    psum = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_run));
-                        psum += p;
-                        pb[r >> 3][r & 7] = f32_to_bf16(p);
-                    }
-                }
-                l_run += psum;
-            } else if constexpr (DBG != 1 && (OPT & 1) != 0) {
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-                mloc = half_max(mloc) * scale_log2;
-                if (!__all(mloc <= m_run + 8.0f)) {            // wave-uniform; masked keys (-inf) never trigger it
-                    const float m_new = fmaxf(m_run, mloc);
-                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    m_run = m_new;
-                    l_run *= alpha;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-                }
-                float psum = 0.f, psum2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_run));
-                    if constexpr ((OPT & 2) == 0) psum += p;
-                    pb[r >> 3][r & 7] = f32_to_bf16(p);
-                }
-                if constexpr ((OPT & 2) != 0) {
-                    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
-                    const bf2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const u32x4 w = __builtin_bit_cast(u32x4, pb[i]);
-                        psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w[0]), ones, psum, false);
-                        psum2 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w[1]), ones, psum2, false);
-                        psum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w[2]), ones, psum, false);
-                        psum2 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, w[3]), ones, psum2, false);
-                    }
-                }
-                l_run += psum + psum2;
-            } else if constexpr (DBG == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = f32_to_bf16(sacc[r]);
-                l_run += sacc[0];
-            } else {
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-                mloc = half_max(mloc);
-                const float m_new = fmaxf(m_run, mloc * scale_log2);
-                alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                m_run = m_new;
-                float psum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_new));
-                    psum += p;
-                    pb[r >> 3][r & 7] = f32_to_bf16(p);
-                }
-                l_run = l_run * alpha + psum;
-            }
-            if constexpr ((OPT & 21) == 0) {
-                if (!__all(alpha == 1.0f)) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-                }
-            }
-            // ---- O^T += V^T P^T
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if constexpr (DBG == 3) oacc[db][u] += (float)vf[db][u][0] * (float)pb[u][0];
-                    else oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][u], pb[u], oacc[db], 0, 0, 0);
-                }
-        }
+        attn::tile<MODE, DBG>(st, qf, sk, sv, edge, tile * KV_TILE, ob, k_end, tile == t_first, scale_log2, l31, half);
     };
 
     if constexpr (NGRP == 1) {
@@ -544,7 +323,7 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
     }
 #endif
 #ifdef SAT_GEMM_EXPERIMENTS
-    if (const char* eo = getenv("SAT_ATTN_OPT"); eo && !out_scales) {
+    if (const char* eo = getenv("SAT_ATTN_MODE"); eo && !out_scales) {          // A/B of the softmax recurrences (tools/attn_opt_probe.py)
         auto launch = [&](auto kern, dim3 g, int lds) {
             (void)sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
             hipLaunchKernelGGL(kern, g, dim3(512), lds, s, q, k, vt, out, out_scales, h, kvh, sq, sk, sq_pad, sk_pad, scale_log2);
@@ -554,25 +333,15 @@ int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf1
             case 0: launch(attention_kernel<false, 0, 2, 0>, grid, ATT_LDS); return 0;
             case 1: launch(attention_kernel<false, 0, 2, 1>, grid, ATT_LDS); return 0;
             case 2: launch(attention_kernel<false, 0, 2, 2>, grid, ATT_LDS); return 0;
-            case 3: launch(attention_kernel<false, 0, 2, 3>, grid, ATT_LDS); return 0;
-            case 5: launch(attention_kernel<false, 0, 2, 5>, grid, ATT_LDS); return 0;
-            case 13: launch(attention_kernel<false, 0, 2, 13>, grid, ATT_LDS); return 0;
-            case 7: launch(attention_kernel<false, 0, 2, 7>, grid, ATT_LDS); return 0;
-            case 16: launch(attention_kernel<false, 0, 2, 16>, grid, ATT_LDS); return 0;
             case 100: launch(attention_kernel<false, 0, 1, 0>, g1, 3 * STAGE_BYTES); return 0;
             case 101: launch(attention_kernel<false, 0, 1, 1>, g1, 3 * STAGE_BYTES); return 0;
             case 102: launch(attention_kernel<false, 0, 1, 2>, g1, 3 * STAGE_BYTES); return 0;
-            case 103: launch(attention_kernel<false, 0, 1, 3>, g1, 3 * STAGE_BYTES); return 0;
-            case 105: launch(attention_kernel<false, 0, 1, 5>, g1, 3 * STAGE_BYTES); return 0;
-            case 113: launch(attention_kernel<false, 0, 1, 13>, g1, 3 * STAGE_BYTES); return 0;
-            case 107: launch(attention_kernel<false, 0, 1, 7>, g1, 3 * STAGE_BYTES); return 0;
-            case 116: launch(attention_kernel<false, 0, 1, 16>, g1, 3 * STAGE_BYTES); return 0;
         }
     }
 #endif
-    if (one_group && !out_scales && q_scale == 1.0f) {      // pre-scaled Q: the reference rides in the matrix pipe (OPT bit 4)
-        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 0, 1, 16>), 3 * STAGE_BYTES));
-        hipLaunchKernelGGL((attention_kernel<false, 0, 1, 16>), dim3(cdiv(sq, 256), h, b), dim3(512), 3 * STAGE_BYTES, s, q, k, vt, out, out_scales, h, kvh,
+    if (one_group && !out_scales && q_scale == 1.0f) {      // pre-scaled Q: the reference rides in the matrix pipe (MODE 2)
+        SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(attention_kernel<false, 0, 1, 2>), 3 * STAGE_BYTES));
+        hipLaunchKernelGGL((attention_kernel<false, 0, 1, 2>), dim3(cdiv(sq, 256), h, b), dim3(512), 3 * STAGE_BYTES, s, q, k, vt, out, out_scales, h, kvh,
                            sq, sk, sq_pad, sk_pad, scale_log2);
         SAT_LAUNCH_CHECK();
         return 0;

@@ -50,6 +50,13 @@ int sat_ensure_dynamic_lds(const void* kernel, int bytes) {
 }
 extern "C" int sat_version(void) { return 3; }
 
+// to_q + cross-attention in one launch where it applies (A/B switch; process-wide like sat_gemm_set_wide_tile)
+static int g_cross_fusion = 1;
+extern "C" int sat_set_cross_attention_fusion(int32_t on) {
+    g_cross_fusion = on ? 1 : 0;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ plan
 namespace {
 
@@ -438,10 +445,19 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_cq; }
                 g.heads.out[0] = w.Q; g.heads.kind[0] = 8; g.heads.qscale = SAT_ATTN_QSCALE;
                 g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
-                SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
                 const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lcpad * 64;
-                SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
-                                             p->ctx_lc, Spad, p->ctx_lcpad, s, f8 ? w.AOs : nullptr, 1.0f));
+                // One launch for to_q + softmax(q k^T) v where the 128 x 64 tile is the choice anyway and its workgroups fit one round
+                // (one prompt: 9 x 24 = 216): the projection's epilogue keeps Q in registers and attends to the <= 189 context keys
+                // staged in LDS (gemm_bf16.hip, XA_OK).  Saves the attention launch and the Q round trip.
+                const bool fuse = g_cross_fusion && !f8 && D >= 192 && p->ctx_lc + 3 <= 192 && cdiv(Mc, 128) * (D / 64) <= 256;
+                if (fuse) {
+                    g.heads.xa_k = p->kc + l * per_layer; g.heads.xa_vt = p->vct + l * per_layer; g.heads.xa_out = w.AO;
+                    g.heads.xa_kvh = p->kvh_cross; g.heads.xa_sk = p->ctx_lc; g.heads.xa_sk_pad = p->ctx_lcpad;
+                }
+                SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
+                if (!fuse)
+                    SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
+                                                 p->ctx_lc, Spad, p->ctx_lcpad, s, f8 ? w.AOs : nullptr, 1.0f));
                 g = GemmArgs{};
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
                 if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
@@ -759,6 +775,18 @@ extern "C" int sat_attention_bf16(const void* q, const void* k, const void* vt, 
                                   int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
     return sat_launch_attention((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, b, h, kvh, sq, sk, sq_pad,
                                 sk_pad, (hipStream_t)stream);
+}
+
+// to_q projection + cross-attention in ONE launch (what the plan runs per layer at one prompt): out [b*s, d] = attention(a wq^T, k, v)
+extern "C" int sat_cross_attention_fused_bf16(const void* a, const void* wq, const void* k, const void* vt, void* out, int32_t b, int32_t s_len,
+                                              int32_t d, int32_t kvh, int32_t sk, int32_t sk_pad, sat_stream_t stream) {
+    SAT_CHECK_ARG(a && wq && k && vt && out && b > 0 && s_len > 0 && d > 0 && d % 128 == 0 && kvh > 0, SAT_E_INVALID, "cross_attention_fused: bad argument");
+    GemmArgs g{};
+    g.A = (const bf16_t*)a; g.W = (const bf16_t*)wq; g.M = b * s_len; g.N = d; g.K = d;
+    g.heads.kind[0] = 8; g.heads.qscale = SAT_ATTN_QSCALE; g.heads.parts = 1; g.heads.heads = d / 64; g.heads.S = s_len; g.heads.Spad = s_len;
+    g.heads.xa_k = (const bf16_t*)k; g.heads.xa_vt = (const bf16_t*)vt; g.heads.xa_out = (bf16_t*)out;
+    g.heads.xa_kvh = kvh; g.heads.xa_sk = sk; g.heads.xa_sk_pad = sk_pad;
+    return sat_launch_gemm(EPI_HEADS, g, (hipStream_t)stream);
 }
 
 // The layout the DiT plan runs: Q pre-scaled by 1/sqrt(64) * log2(e) by its producer (the QKV / to_q GEMM epilogue)

@@ -15,6 +15,7 @@
 
 #include <type_traits>
 
+#include "attn_core.h"
 #include "sat_common.h"
 
 namespace {
@@ -220,7 +221,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 template <int EPI, int MI, int NI, bool LNC = false>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
                                                 const int l31, const float2* ln = nullptr, const float* lc1 = nullptr,
-                                                const float* lc2 = nullptr) {
+                                                const float* lc2 = nullptr, unsigned (*qfrag)[8] = nullptr) {
     const int M = g.M, N = g.N;
     (void)N;
     if constexpr (EPI == EPI_F32) {
@@ -395,6 +396,12 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                 half_swap(pk[1], pk[3]);
                 half_swap(pk[4], pk[6]);
                 half_swap(pk[5], pk[7]);
+                if (qfrag) {       // fused cross-attention (MI == 1): channels [32 j + 8 half, +8) and [32 j + 16 + 8 half, +8) of the lane's row
+                                   // ARE the B-operand fragments 2 j and 2 j + 1 of the score MFMA
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qfrag[j][e] = pk[e];
+                    continue;
+                }
                 if (m < M) {
                     *reinterpret_cast<u32x4*>(row + j * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
                     *reinterpret_cast<u32x4*>(row + j * 32 + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
@@ -786,6 +793,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // waves whose TM rows lie entirely beyond M (the M-tail tile: 2 valid rows of 256 at B=1) keep staging tiles and
     // joining barriers but skip their LDS reads, MFMAs and epilogue
     const bool wave_rows_valid = (m0 + wm * TM) < M;
+    // Fused cross-attention (HeadsEpi::xa_k, 128 x 64 tile: one head per workgroup column, one 32-query block per wave): the K / V^T
+    // tiles of the (sequence, kv-head) go to LDS behind the ring and the LayerNorm constants NOW -- they are the oldest entries of the
+    // vector-memory queue, so every counted vmcnt wait of the K loop still holds, and the loop's barriers publish them.
+    constexpr bool XA_OK = EPI == EPI_HEADS && MI == 1 && NI == 2 && NW == 4 && BN == 64 && BK == 64 && NS == 3 && FP8 == 0;
+    constexpr int XA_OFF = (NS * STAGE_BYTES + (BM + BN) * 8 + 1023) & ~1023;
+    [[maybe_unused]] bool xa_on = false;
+    [[maybe_unused]] auto xa_stage = [&](int b) {
+        const HeadsEpi& he = g.heads;
+        const int kvh = (n0 >> 6) / (he.heads / he.xa_kvh);
+        const bf16_t* kbase = he.xa_k + (size_t)(b * he.xa_kvh + kvh) * he.xa_sk_pad * 64;
+        const bf16_t* vbase = he.xa_vt + (size_t)(b * he.xa_kvh + kvh) * 64 * he.xa_sk_pad;
+        const int n_t = (((b * he.xa_sk) & 3) + he.xa_sk + 63) >> 6;
+        for (int t = 0; t < n_t; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = wave + 4 * i;                          // 1-KiB piece = 8 rows of 128 B
+                const int row = p * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);         // source-side XOR swizzle (lds_tile_off)
+                char* dst = smem + XA_OFF + t * 16384 + p * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (size_t)(t * 64 + row) * 64 + c * 8),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (size_t)row * he.xa_sk_pad + t * 64 + c * 8),
+                                                 (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+            }
+    };
+    if constexpr (XA_OK) {
+        xa_on = g.heads.xa_k != nullptr;
+        if (xa_on) xa_stage(m0 / g.heads.S);
+    }
     // fp32 residual epilogue of the small tiles (one 32-row block per wave, registers to spare): fetch the residual values NOW.
     // They are the oldest entries of the vector-memory queue, so every counted vmcnt wait of the K loop still holds.
     constexpr bool PRE_RESID = EPI == EPI_F32 && MI == 1 && NI == 2 && NT <= 512;
@@ -1132,6 +1168,68 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         else main_loop(std::false_type{});
     }
 
+    if constexpr (XA_OK) {
+        if (xa_on) {
+            const HeadsEpi& he = g.heads;
+            unsigned qp[2][8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qp[j][e] = 0u;
+            if (wave_rows_valid) gemm_epilogue_t<EPI, MI, NI, LN_CONS>(g, acc, m0 + wm * TM, n0, half, l31, lnst + wm * TM, lnc, lnc + BN, qp);
+            bf16x8 qf[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qf[2 * j] = __builtin_bit_cast(bf16x8, u32x4{qp[j][0], qp[j][1], qp[j][2], qp[j][3]});
+                qf[2 * j + 1] = __builtin_bit_cast(bf16x8, u32x4{qp[j][4], qp[j][5], qp[j][6], qp[j][7]});
+            }
+            const int S = he.S;
+            const int m = m0 + wm * TM + l31;
+            const int b_me = (m < M ? m : M - 1) / S;
+            const int last = (m0 + BM - 1 < M ? m0 + BM - 1 : M - 1);
+            const int b_lo = m0 / S, b_hi = last / S;
+            const int wlast = (m0 + wm * TM + 31 < M ? m0 + wm * TM + 31 : M - 1);
+            const int w_lo = (m0 + wm * TM) / S, w_hi = wlast / S;
+            for (int bb = b_lo; bb <= b_hi; ++bb) {
+                if (bb > b_lo) {        // the tile's rows straddle two sequences: second pass on the next sequence's keys
+                    __builtin_amdgcn_s_barrier();
+                    xa_stage(bb);
+                    wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (!(wave_rows_valid && w_lo <= bb && bb <= w_hi)) continue;
+                const int ob = (bb * he.xa_sk) & 3, k_end = ob + he.xa_sk;
+                const int n_t = (k_end + 63) >> 6;
+                attn::State<2> st;
+                st.init(half);
+                for (int t = 0; t < n_t; ++t) {
+                    const char* sk = smem + XA_OFF + t * 16384;
+                    const bool edge = (t == 0 && ob != 0) || (t == n_t - 1 && (k_end & 63) != 0);
+                    attn::tile<2>(st, qf, sk, sk + 8192, edge, t * 64, ob, k_end, t == 0, 1.0f, l31, half);
+                }
+                const float inv = 1.0f / attn::half_sum(st.l_run);
+                bf16_t* op = he.xa_out + (size_t)m * ((size_t)he.heads * 64) + n0 + 8 * half;      // out row = b * S + s = m
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    unsigned pk[8];
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        pk[2 * rq] = pack_bf16x2(st.oacc[db][rq * 4] * inv, st.oacc[db][rq * 4 + 1] * inv);
+                        pk[2 * rq + 1] = pack_bf16x2(st.oacc[db][rq * 4 + 2] * inv, st.oacc[db][rq * 4 + 3] * inv);
+                    }
+                    half_swap(pk[0], pk[2]);            // 8 consecutive channels per lane: 16-byte stores
+                    half_swap(pk[1], pk[3]);
+                    half_swap(pk[4], pk[6]);
+                    half_swap(pk[5], pk[7]);
+                    if (m < M && b_me == bb) {
+                        *reinterpret_cast<u32x4*>(op + db * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                        *reinterpret_cast<u32x4*>(op + db * 32 + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+                    }
+                }
+            }
+            return;
+        }
+    }
     if constexpr (FP8 != 0) {
         // dequantise: per-token scale of A x per-output-channel scale of W (kept out of the last K-tile's MFMA schedule)
         __builtin_amdgcn_sched_barrier(0);
@@ -1201,7 +1299,22 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
                   "gemm: the bf16 image / row statistics come from the bf16 fp32-output tiles with 64-column wave tiles");
     static_assert(EPI != EPI_F32 || BN / WN != 64 || LDS >= WM * WN * 8192, "the staged fp32 epilogue needs 8 KiB of LDS per wave");
     auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, FP8>;
-    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
+    // fused cross-attention (HeadsEpi::xa_k): three K / V^T tiles of 64 keys behind the ring and the LayerNorm constants
+    constexpr bool XA_OK = EPI == EPI_HEADS && BM == 128 && BN == 64 && BK == 64 && WM == 4 && WN == 1 && NS == 3 && FP8 == 0;
+    constexpr int XA_LDS = XA_OK ? ((NS * (BM + BN) * BK * 2 + (BM + BN) * 8 + 1023) & ~1023) + 3 * 16384 : LDS;
+    static_assert(XA_LDS <= 160 * 1024, "fused cross-attention: K / V^T tiles do not fit behind the ring");
+    bool xa = false;
+    if constexpr (EPI == EPI_HEADS) {
+        xa = a.heads.xa_k != nullptr;
+        if (xa) {
+            const HeadsEpi& he = a.heads;
+            SAT_CHECK_ARG(XA_OK, SAT_E_UNSUPPORTED, "gemm: the fused cross-attention epilogue lives in the 128 x 64 tile (variant 16)");
+            SAT_CHECK_ARG(he.parts == 1 && he.kind[0] == 8 && he.qscale == SAT_ATTN_QSCALE && he.xa_vt && he.xa_out && he.xa_kvh > 0 &&
+                              he.heads % he.xa_kvh == 0 && he.xa_sk > 0 && he.xa_sk + 3 <= 192 && he.xa_sk_pad >= he.xa_sk + 3 && he.xa_sk_pad % 64 == 0,
+                          SAT_E_UNSUPPORTED, "gemm: fused cross-attention needs one pre-scaled row-major part and at most 189 keys (got %d)", he.xa_sk);
+        }
+    }
+    SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), XA_LDS));
     GemmArgs b = a;
     if (FP8) {
         SAT_CHECK_ARG(a.K % 128 == 0 && a.w_scale && (FP8 == 3 ? (const void*)a.a_bscale : (const void*)a.a_scale), SAT_E_UNSUPPORTED,
@@ -1211,7 +1324,7 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG(b.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", b.N, BN);
     SAT_CHECK_ARG(b.K % BK == 0 && b.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
     int tiles = cdiv(b.M, BM) * (b.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), LDS, stream, b);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), xa ? XA_LDS : LDS, stream, b);
     SAT_LAUNCH_CHECK();
     return 0;
 }
@@ -1260,6 +1373,12 @@ int g_wide_tile = 80;
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
     int v = a.variant & 0xff;
+    if constexpr (EPI == EPI_HEADS) {
+        if (a.heads.xa_k) {       // fused cross-attention: built into the 128 x 64 tile only (the caller asks for it where that tile is the choice)
+            SAT_CHECK_ARG(!a.fp8 && a.K >= 192, SAT_E_UNSUPPORTED, "gemm: fused cross-attention needs bf16 operands and K >= 192");
+            return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);
+        }
+    }
     // fill of the last round of 256 CUs x measured in-kernel rate of the tile, relative to the 256x256 tile
     auto score = [&](int bm, int bn, double rate) {
         if (a.N % bn) return 0.0;

@@ -1149,6 +1149,7 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
                       "gemm(8-phase): a %d-column tile must not straddle q / k / v (heads=%d)", BN, a.heads.heads);
         for (int p = 0; p < a.heads.parts; ++p)
             SAT_CHECK_ARG((a.heads.kind[p] & 3) != 3, SAT_E_UNSUPPORTED, "gemm(8-phase): no rotation on a transposed destination");
+        SAT_CHECK_ARG(!a.heads.xa_k, SAT_E_UNSUPPORTED, "gemm(8-phase): the fused cross-attention epilogue lives in the 128 x 64 tile");
     }
     Ph8Sched sc;
     // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements); bit 20: contiguous stream-K shares

@@ -202,6 +202,14 @@ struct HeadsEpi {
                          // bit3: query tensor written PRE-SCALED by `qscale` (row-major destinations only): the attention
                          //       kernel then gets log2-domain scores straight out of its first MFMA (SAT_ATTN_QSCALE)
     float qscale;
+    // Fused cross-attention (one part, row-major, pre-scaled, 128 x 64 tile = one head per workgroup column): the epilogue does not
+    // store Q at all -- each wave keeps its 32 queries x 64 channels as MFMA fragments and runs softmax(q k^T) v against the
+    // (batch, kv-head)'s keys / values, which the workgroup staged in LDS behind the GEMM ring at kernel start
+    // (models/transformer.py:496-536 behind :430-437).  xa_k == nullptr: off.
+    const bf16_t* xa_k;      // [B, kvh, sk_pad, 64], key-side layout of sat_attention_bf16
+    const bf16_t* xa_vt;     // [B, kvh, 64, sk_pad]
+    bf16_t* xa_out;          // [M, heads * 64]
+    int xa_kvh, xa_sk, xa_sk_pad;
     int parts;           // N == parts * heads * 64
     int heads;           // heads per part
     int S;               // valid rows per sequence (row m -> b = m / S, s = m % S)

@@ -77,6 +77,9 @@ _SIGNATURES = {
     "sat_layernorm_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sat_cast_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "sat_gemm_set_wide_tile": (c_int32, [c_int32]),
+    "sat_set_cross_attention_fusion": (c_int32, [c_int32]),
+    "sat_cross_attention_fused_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                                 c_int32, c_int32, c_void_p]),
     "sat_resample_sinc": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "sat_gemm_bf16_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_void_p]),

@@ -280,6 +280,14 @@ int sat_attention_bf16(const void* q_dev, const void* k_dev, const void* vt_dev,
 int sat_attention_prescaled_bf16(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
                                  int32_t b, int32_t h, int32_t kvh, int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad,
                                  sat_stream_t stream);
+/* Cross-attention query projection and attention core in one launch (models/transformer.py:430-437 + 496-536; what the DiT plan
+ * runs per layer while the 128 x 64 GEMM tiles of the projection fit one round of workgroups, i.e. at one prompt):
+ * out [b*s, d] bf16 = softmax((a wq^T) k^T / 8) v per head of 64, a [b*s, d] bf16, wq [d, d] bf16, k / vt in the key-side layout of
+ * sat_attention_bf16 with sk + 3 <= 192 keys (they are staged in LDS as a whole); GQA d/64 over kvh.  Q never reaches memory. */
+int sat_cross_attention_fused_bf16(const void* a_bf16_dev, const void* wq_bf16_dev, const void* k_dev, const void* vt_dev, void* out_dev,
+                                   int32_t b, int32_t s, int32_t d, int32_t kvh, int32_t sk, int32_t sk_pad, sat_stream_t stream);
+/* A/B switch of that fusion inside the plans (default on); process-wide like sat_gemm_set_wide_tile. */
+int sat_set_cross_attention_fusion(int32_t on);
 /* Fused QKV projection + partial RoPE + head split (models/transformer.py:430-452):
  * a [b*s, d] bf16, w_qkv [3d, d] bf16 -> q,k [b,h,s_pad,64], vt [b,h,64,s_pad] bf16 (k / vt in the key-side
  * layout of sat_attention_bf16; s_pad % 128 == 0, s_pad >= s + 3).

@@ -155,6 +155,32 @@ def test_attention(dev, b, h, kvh, sq, sk, prescaled):
     assert rel_l2(out.view(b, sq, h * 64), exact) < 1e-2
 
 
+@pytest.mark.parametrize("b,s,d,kvh,sk", [(1, 1025, 256, 2, 130), (3, 300, 256, 4, 7), (2, 129, 256, 1, 189), (1, 50, 1536, 12, 130)])
+def test_cross_attention_fused(dev, b, s, d, kvh, sk):
+    """to_q projection + cross-attention core in one launch (the 128 x 64 GEMM tile keeps Q in registers and attends to the context keys
+    staged in LDS; transformer.py:430-437 + 496-536) against the oracle on the query the epilogue stands for (pre-scaled by log2(e)/8,
+    one bf16 rounding).  s = 300 / 129: tiles and waves whose rows straddle two sequences (second pass on the next sequence's keys)."""
+    from oracle import dit as odit
+    _hip, lib = _lib()
+    h = d // 64
+    a = _rand((b * s, d), 31).to(torch.bfloat16)
+    wq = (_rand((d, d), 32) * (1.5 / d ** 0.5)).to(torch.bfloat16)
+    k = (_rand((b, kvh, sk, 64), 33) * 1.5).to(torch.bfloat16)
+    v = _rand((b, kvh, sk, 64), 34).to(torch.bfloat16)
+    c = 0.125 * 1.4426950408889634
+    q = (a.float() @ wq.float().T).view(b, s, h, 64).permute(0, 2, 1, 3)
+    q_eff = (q * c).to(torch.bfloat16).float() / c
+    want = odit._merge(odit.attention_core(q_eff, k.float(), v.float(), rnd=bf16_round))
+    sk_pad = (sk + 3 + 63) // 64 * 64
+    kd = _pad_heads(k, sk_pad, key_side=True).to(dev)
+    vtd = _pad_heads(v, sk_pad, key_side=True).transpose(2, 3)[..., _vt_perm(sk_pad)].contiguous().to(dev)
+    out = torch.zeros((b * s, d), dtype=torch.bfloat16, device=dev)
+    ad, wd = a.to(dev), wq.to(dev)          # (named: a temporary would be freed before the launch reads it)
+    _hip.check(lib.sat_cross_attention_fused_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, s, d,
+                                                  kvh, sk, sk_pad, _hip.stream()))
+    assert_close(f"fused cross-attention {b}x{s}x{d} kv{kvh} sk{sk}", out.view(b, s, d), want, 5e-3)
+
+
 @pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
 @pytest.mark.parametrize("variant", [0] + GEMM_VARIANTS)
 def test_qkv_rope(dev, variant, s, s_pad):

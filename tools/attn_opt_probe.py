@@ -1,4 +1,4 @@
-"""A/B of the attention kernel's OPT bits (experiments build, SAT_ATTN_OPT read at every launch): time at the four shipped shapes and
+"""A/B of the attention kernel's softmax recurrences (attn_core.h MODE 0 / 1 / 2; experiments build, SAT_ATTN_MODE read at every launch): time at the four shipped shapes and
 error against an fp32 softmax(QK^T/8)V of the same bf16 inputs.    python tools/attn_opt_probe.py [opts...]"""
 import os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/friendly-stable-audio-tools_amd")
@@ -6,7 +6,7 @@ import torch
 from stable_audio_tools import _hip
 _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libsat_hip_exp.so")
 lib = _hip.lib(); dev = torch.device("cuda:0")
-opts = [int(a) for a in sys.argv[1:]] or [0, 1, 3]
+opts = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
 
 
 def timeit(fn, iters=20, warm=3):
@@ -52,7 +52,7 @@ for gain, label in [(1.0, "unit-variance scores"), (6.0, "peaky scores (std 6)")
         for grp in (1, 2):
             os.environ["SAT_ATTN_GROUPS"] = str(grp)
             for opt in opts:
-                os.environ["SAT_ATTN_OPT"] = str(opt)
+                os.environ["SAT_ATTN_MODE"] = str(opt)
                 o.zero_(); f(); torch.cuda.synchronize()
                 err = ((o.float() - want).norm() / want.norm()).item()
                 print(f"{label:22s} b{b} h{h}/{kvh} sq{sq} sk{sk} groups={grp} opt={opt}: rel-L2 {err:.3e}", flush=True)
@@ -62,7 +62,7 @@ for name, b, h, kvh, sq, sk in [("self B1", 2, 24, 24, 1025, 1025), ("cross B1",
     q, k, vt, o, f = make(b, h, kvh, sq, sk)
     line = f"attention {name:9s}:"
     for opt in opts:
-        os.environ["SAT_ATTN_OPT"] = str(opt)
+        os.environ["SAT_ATTN_MODE"] = str(opt)
         ms = timeit(f)
         line += f"   opt={opt} {ms*1e3:7.1f} us {4.0*b*h*sq*sk*64/ms/1e9:7.1f} TF"
     print(line, flush=True)
