@@ -37,7 +37,7 @@ for k, r in sorted(sq.items(), key=lambda kv: -float(kv[1]["SQ_BUSY_CYCLES"]) * 
                  f"{100 * float(r['SQ_WAIT_ANY']) / wc:.1f} | {100 * float(r['SQ_WAIT_INST_ANY']) / wc:.1f} | {100 * float(r['SQ_ACTIVE_INST_ANY']) / wc:.1f} |")
 open(os.path.join(root, "profiles", f"{tag}_pmc_sq_summary.md"), "w").write("\n".join(lines) + "\n")
 
-ffn = [k for k in fetch if "gemm_ph8_kernel<2, 0>" in k] or [k for k in fetch if "gemm_pipe_kernel<256, 256, 64, 4, 4, 2, 2" in k]
+ffn = [k for k in fetch if "gemm_ph8_kernel<2, 0" in k] or [k for k in fetch if "gemm_pipe_kernel<256, 256, 64, 4, 4, 2, 2" in k]
 if ffn:
     k = ffn[0]
     fk, wk = float(fetch[k]["FETCH_SIZE"]), float(write[k]["WRITE_SIZE"])
