@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/friendly-stable-audio-tools_amd")
 import torch
 from stable_audio_tools import _hip
-_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libsat_hip_exp.so")
+_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), os.environ.get("SAT_PROBE_LIB", "libsat_hip_exp.so"))
 lib = _hip.lib(); dev = torch.device("cuda:0")
 opts = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
 
