@@ -57,6 +57,33 @@ def _inputs(b, t_len, cond_dim, seed=1):
     return x, c, g
 
 
+def test_cross_attention_fusion_on_off(dev, small_dit):
+    """to_q + cross-attention as ONE launch (the plan's default where the projection's 128 x 64 tiles fit one round) against the same plan
+    with two kernels (sat_set_cross_attention_fusion(0)).  Both keep Q pre-scaled with one bf16 rounding and run the same per-wave step on
+    the same K / V^T tiles (attn_core.h).  One sequence: a wave holds the same 32 queries either way, so the outputs are bit-identical.
+    Three sequences of 78 rows: the fused tiles straddle sequences (second pass on the next sequence's keys) and group the queries
+    into waves differently -- the wave-wide "redo this block" decision may differ, the results agree to rounding."""
+    from stable_audio_tools import _hip
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    for b in (1, 3):
+        x, c, g = _inputs(b, 77, dc["cond_token_dim"], seed=7)
+        t = torch.tensor([0.31, 0.87, 0.5][:b])
+        run = lambda: model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0).cpu()
+        fused = run()
+        try:
+            _hip.check(_hip.lib().sat_set_cross_attention_fusion(0))
+            separate = run()
+        finally:
+            _hip.check(_hip.lib().sat_set_cross_attention_fusion(1))
+        assert torch.isfinite(fused).all()
+        assert torch.equal(fused, run()), "the fused path is not repeatable"
+        if b == 1:
+            assert torch.equal(fused, separate), f"fused vs separate cross-attention: max abs diff {(fused - separate).abs().max().item():.3e}"
+        else:
+            assert_close("fused vs separate cross-attention, 3 sequences", fused, separate, 2e-3)
+
+
 def test_layernorm_fusion_on_off(dev, small_dit):
     """The standalone-LayerNorm plan (sat_dit_cfg.ln_fold = 0) against ITS matched oracle (plain bf16 rounding points), and the two
     plans against each other: they differ only in where the activation is rounded (before / after the normalisation)."""
