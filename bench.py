@@ -78,8 +78,11 @@ def one_generation(model, cond, seed, dev, world):
         _hip.check(_hip.lib().sat_float_to_int16(_hip.ptr(audio[i]), _hip.ptr(out[i]), c * n, 0, _hip.ptr(scratch), _hip.stream()))
     if world > 1 or FORCE_DIST:
         from stable_audio_tools.inference.distributed import gather_sharded
-        return gather_sharded(out, world * b)          # the single RCCL collective (xGMI)
-    return out
+        out = gather_sharded(out, world * b)           # the single RCCL collective (xGMI)
+    # the reference's float_to_int16_audio ends in .cpu() (utils/audio_utils.py:21-26): the int16 audio leaves the device inside the
+    # timed step (8.4 MB per prompt; rank 0 takes the gathered batch, the other ranks their own prompts)
+    rank = int(os.environ.get("RANK", "0"))
+    return (out if rank == 0 else out[rank::world]).cpu()
 
 
 def cpu_baseline(sd):
@@ -163,10 +166,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="prompts per GPU (BASELINE config 2: 1; config 3: 8)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="prompts per GPU; default 1 at --gpus 1 (BASELINE config 2) and 8 at --gpus > 1 (config 3: 64 prompts on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=("bf16", "fp8"), default="bf16",
-                    help="GEMM operand type: bf16 (headline) or fp8 = BASELINE config 5 (e4m3 to_qkv / cross to_q / FF-in, rest bf16)")
+    ap.add_argument("--dtype", choices=("bf16", "fp16", "fp8"), default="bf16",
+                    help="GEMM / attention operand type: bf16, fp16 (the same kernels on the fp16 MFMAs: same rate, 8x less operand rounding, "
+                         "the reference's own GPU arithmetic) or fp8 = BASELINE config 5 (e4m3 to_qkv / cross to_q / FF-in, rest bf16)")
     ap.add_argument("--layernorm", choices=("fused", "standalone"), default="fused",
                     help="LayerNorms of the blocks inside the GEMM epilogues (sat_dit_cfg.ln_fold, default) or as three kernels per block")
     ap.add_argument("--cross-attention", choices=("fused", "separate"), default="fused",
@@ -175,6 +180,8 @@ def main():
                     help="sa_open: the headline (BASELINE config 2/3); sa2_a2a: config 4, SA-2.0 shape, audio-to-audio, 1 GPU")
     ap.add_argument("--dry-run", action="store_true", help="check the arguments and print the rank -> prompt plan as JSON; touches no GPU")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 1 if args.gpus == 1 else 8
     if args.gpus < 1 or args.batch < 1 or args.steps < 1 or args.warmup < 0:
         raise SystemExit("bench.py: --gpus / --batch / --steps must be >= 1 and --warmup >= 0")
     if args.dry_run:
@@ -301,7 +308,7 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 traffic_source = f"profiles/{tname} (rocprofv3 --pmc passes of this command, not measured in this run)"
                 break
-        mfma_peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == "bf16" else FP8_MFMA_PEAK_TFLOPS
+        mfma_peak = FP8_MFMA_PEAK_TFLOPS if args.dtype == "fp8" else BF16_MFMA_PEAK_TFLOPS          # fp16 and bf16 MFMAs: the same dense peak
         line = {
             "metric": "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-Open-1.0 shape" if args.workload == "sa_open" else
                       "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-2.0 shape audio-to-audio (encode + sample + decode)",
@@ -314,7 +321,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 (to_qkv, cross to_q, FF-in; per-token x per-channel scales) + bf16, fp32 accumulate",
+            "dtype": args.dtype if args.dtype != "fp8" else "fp8 e4m3 (to_qkv, cross to_q, FF-in; per-token x per-channel scales) + bf16, fp32 accumulate",
             "data": "synthetic (random-init weights of the SA-Open-1.0 / SA-2.0 DiT + Oobleck architecture, random text embeddings)",
             "config": {"workload": ("Stable-Audio-Open-1.0 DiT shape (24 layers, D=1536, S=1025, CFG 7 -> 2 sequences/prompt) + Oobleck decode, "
                                     f"{args.batch} prompt(s)/GPU x 47.55 s, 100 DPM-Solver++(3M) SDE steps") if args.workload == "sa_open" else

@@ -53,11 +53,12 @@ __device__ __forceinline__ void swap_halves(unsigned& lo_run, unsigned& hi_run) 
 // the reference carried through the matrix pipe, for a Q its producer wrote pre-scaled (scale_log2 == 1; anything else is multiplied
 // into Q here and rounded to bf16 a second time: experiments); 0: the textbook recurrence (experiments build).
 template <bool MX8, int DBG = 0, int NGRP = 2, int MODE = 1>
-__global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                           const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(512, 2) void attention_kernel(const op_t* __restrict__ q, const op_t* __restrict__ k,
+                                                           const op_t* __restrict__ vt, op_t* __restrict__ out,
                                                            unsigned char* __restrict__ out_scales,
                                                            int H, int KVH, int Sq, int Sk, int Sq_pad, int Sk_pad,
                                                            float scale_log2) {
+    sat_f16_saturate();
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -80,11 +81,11 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
     const int qi = bx * QB + wq * 32 + l31;                // NGRP == 2: < Sq_pad; NGRP == 1: the last workgroup may reach beyond it
 
     // Q fragments (B operand of S^T): Q[qi][16t + 8*half .. +8]
-    bf16x8 qf[4];
+    opx8 qf[4];
     {
-        const bf16_t* qp = q + ((size_t)(b * H + h) * Sq_pad + (qi < Sq_pad ? qi : Sq_pad - 1)) * 64 + half * 8;
+        const op_t* qp = q + ((size_t)(b * H + h) * Sq_pad + (qi < Sq_pad ? qi : Sq_pad - 1)) * 64 + half * 8;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const bf16x8*>(qp + t * 16);
+        for (int t = 0; t < 4; ++t) qf[t] = *reinterpret_cast<const opx8*>(qp + t * 16);
     }
 
     if constexpr (MODE == 2) {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) qf[t][j] = f32_to_bf16(bf16_to_f32(qf[t][j]) * scale_log2);
+                for (int j = 0; j < 8; ++j) qf[t][j] = f32_to_op(op_to_f32(qf[t][j]) * scale_log2);
         }
     }
 
@@ -107,11 +108,11 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
 
     // LDS-DMA pieces of this wave: 1 KiB = 8 rows of 128 B; wave wq of the group copies pieces wq and wq + 4 of the K tile and of the
     // V^T tile.  Lane l lands at row 8p + l/8, position l%8, so it fetches logical chunk (l%8) ^ ((row >> 1) & 7) of that row.
-    const bf16_t* kbase = k + (size_t)(b * KVH + kvh) * Sk_pad * 64;
-    const bf16_t* vbase = vt + (size_t)(b * KVH + kvh) * 64 * Sk_pad;
+    const op_t* kbase = k + (size_t)(b * KVH + kvh) * Sk_pad * 64;
+    const op_t* vbase = vt + (size_t)(b * KVH + kvh) * 64 * Sk_pad;
     constexpr int PPW = 8 / WPG;          // 1-KiB pieces of the K tile (and of the V^T tile) this wave copies
-    const bf16_t* ksrc[PPW];
-    const bf16_t* vsrc[PPW];
+    const op_t* ksrc[PPW];
+    const op_t* vsrc[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int row = (wq + WPG * i) * 8 + (lane >> 3);
@@ -248,17 +249,17 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
             }
         }
     } else {
-        bf16_t* op = out + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64 + 8 * half;
+        op_t* op = out + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64 + 8 * half;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
             unsigned pk[8];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                bf16x2 lo, hi;
-                lo[0] = f32_to_bf16(oacc[db][rq * 4] * inv);
-                lo[1] = f32_to_bf16(oacc[db][rq * 4 + 1] * inv);
-                hi[0] = f32_to_bf16(oacc[db][rq * 4 + 2] * inv);
-                hi[1] = f32_to_bf16(oacc[db][rq * 4 + 3] * inv);
+                opx2 lo, hi;
+                lo[0] = f32_to_op(oacc[db][rq * 4] * inv);
+                lo[1] = f32_to_op(oacc[db][rq * 4 + 1] * inv);
+                hi[0] = f32_to_op(oacc[db][rq * 4 + 2] * inv);
+                hi[1] = f32_to_op(oacc[db][rq * 4 + 3] * inv);
                 pk[2 * rq] = __builtin_bit_cast(unsigned, lo);
                 pk[2 * rq + 1] = __builtin_bit_cast(unsigned, hi);
             }
@@ -278,6 +279,8 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const bf16_t* __restr
 
 #ifdef SAT_GEMM_EXPERIMENTS
 static unsigned long long* g_attn_dbg = nullptr;
+#endif
+#if defined(SAT_GEMM_EXPERIMENTS) && !defined(SAT_OPERAND_F16)
 extern "C" int sat_attention_dbg_read(unsigned long long* out4) {
     SAT_CHECK_ARG(g_attn_dbg, SAT_E_INVALID, "no attention counters");
     SAT_HIP(hipDeviceSynchronize());
@@ -287,8 +290,21 @@ extern "C" int sat_attention_dbg_read(unsigned long long* out4) {
 }
 #endif
 
-int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
-                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales, float q_scale) {
+#ifdef SAT_OPERAND_F16
+int sat_launch_attention_f16(const void* q, const void* k, const void* vt, void* out, int b, int h, int kvh, int sq, int sk, int sq_pad,
+                             int sk_pad, hipStream_t s, unsigned char* out_scales, float q_scale) {
+    return f16::sat_launch_attention((const op_t*)q, (const op_t*)k, (const op_t*)vt, (op_t*)out, b, h, kvh, sq, sk, sq_pad, sk_pad, s, out_scales,
+                                     q_scale, 1);
+}
+#endif
+
+int SAT_OPNS::sat_launch_attention(const op_t* q, const op_t* k, const op_t* vt, op_t* out, int b, int h, int kvh,
+                                   int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales, float q_scale, int f16) {
+#ifndef SAT_OPERAND_F16
+    if (f16) return sat_launch_attention_f16(q, k, vt, out, b, h, kvh, sq, sk, sq_pad, sk_pad, s, out_scales, q_scale);
+#else
+    SAT_CHECK_ARG(f16 && !out_scales, SAT_E_INVALID, "attention: the fp16 build takes fp16 tensors and writes fp16");
+#endif
     SAT_CHECK_ARG(q && k && vt && out, SAT_E_INVALID, "attention: null pointer");
     SAT_CHECK_ARG(b > 0 && h > 0 && kvh > 0 && h % kvh == 0, SAT_E_INVALID, "attention: bad heads %d/%d", h, kvh);
     SAT_CHECK_ARG(sq > 0 && sk > 0 && sq_pad >= sq && sk_pad >= sk, SAT_E_INVALID, "attention: bad lengths");

@@ -15,7 +15,7 @@
 //   MODE 1: p = exp2(fma(s, scale_log2, -m_ref)).
 //   MODE 2 (Q pre-scaled by scale_log2 by its producer): the reference rides in the matrix pipe -- a fifth K-step
 //           [1, 0, ...] x [-m_ref, 0, ...] makes the accumulator come out as log2-domain score minus reference, p = exp2(acc): the 16
-//           v_fma_f32 disappear from the VALU stream, the matrix pipe has the slack.  m_ref is kept bf16-representable.
+//           v_fma_f32 disappear from the VALU stream, the matrix pipe has the slack.  m_ref is kept representable in the operand type (bf16 / fp16).
 //   MODE 0: the textbook recurrence (experiments build, A/B).
 #pragma once
 #include "sat_common.h"
@@ -40,7 +40,7 @@ struct State {
     f32x16 oacc[2];         // O^T: channels d = db*32 + 8*(r>>2) + 4*half + (r&3) of the lane's query
     float m_run;            // reference, log2-scaled units
     float l_run;            // this lane's partial row sum (its 16 of every 32 keys)
-    bf16x8 ones_a, mref_b;  // MODE 2: the fifth K-step
+    opx8 ones_a, mref_b;  // MODE 2: the fifth K-step
 
     __device__ __forceinline__ void init(int half) {
 #pragma unroll
@@ -52,10 +52,10 @@ struct State {
         if constexpr (MODE == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                ones_a[j] = f32_to_bf16(0.f);
-                mref_b[j] = f32_to_bf16(0.f);
+                ones_a[j] = f32_to_op(0.f);
+                mref_b[j] = f32_to_op(0.f);
             }
-            if (half == 0) ones_a[0] = f32_to_bf16(1.0f);
+            if (half == 0) ones_a[0] = f32_to_op(1.0f);
         }
     }
 };
@@ -65,33 +65,33 @@ struct State {
 // first: the sequence's first tile for this wave (MODE 2 fixes a real reference there whatever the sums say: underflow safety).
 // DBG (experiments build, wrong results): 1 no exp / max / sum; 3 no MFMA; 5 fragments not read from LDS.
 template <int MODE, int DBG = 0>
-__device__ __forceinline__ void tile(State<MODE>& st, const bf16x8 (&qf)[4], const char* sk, const char* sv, const bool edge, const int key_base,
+__device__ __forceinline__ void tile(State<MODE>& st, const opx8 (&qf)[4], const char* sk, const char* sv, const bool edge, const int key_base,
                                      const int k_lo, const int k_hi, const bool first, const float scale_log2, const int l31, const int half) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         // ---- S^T = K Q^T for 32 keys
-        bf16x8 kf[4];
+        opx8 kf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if constexpr (DBG == 5) kf[t] = qf[t];
-            else kf[t] = *reinterpret_cast<const bf16x8*>(sk + lds_tile_off(kb * 32 + l31, t * 2 + half));
+            else kf[t] = *reinterpret_cast<const opx8*>(sk + lds_tile_off(kb * 32 + l31, t * 2 + half));
         }
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = DBG == 3 ? (float)kf[r & 3][r >> 2] : 0.f;
         if constexpr (DBG != 3) {
-            if constexpr (MODE == 2) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.ones_a, st.mref_b, sacc, 0, 0, 0);
+            if constexpr (MODE == 2) sacc = mfma_32x32x16(st.ones_a, st.mref_b, sacc);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t], qf[t], sacc, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) sacc = mfma_32x32x16(kf[t], qf[t], sacc);
         }
         // V^T fragments do not depend on the softmax: request them now, their LDS latency hides behind the VALU work
-        bf16x8 vf[2][2];
+        opx8 vf[2][2];
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if constexpr (DBG == 5) vf[db][u] = qf[db * 2 + u];
-                else vf[db][u] = *reinterpret_cast<const bf16x8*>(sv + lds_tile_off(db * 32 + l31, (kb * 2 + u) * 2 + half));
+                else vf[db][u] = *reinterpret_cast<const opx8*>(sv + lds_tile_off(db * 32 + l31, (kb * 2 + u) * 2 + half));
         // ---- mask the keys outside [k_lo, k_hi) (wave-uniform branch: first and last tile only)
         if (edge) {
             const int key0 = key_base + kb * 32 + 4 * half;
@@ -102,10 +102,10 @@ __device__ __forceinline__ void tile(State<MODE>& st, const bf16x8 (&qf)[4], con
             }
         }
         // ---- online softmax step (per query = per lane pair)
-        bf16x8 pb[2];
+        opx8 pb[2];
         if constexpr (DBG == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = f32_to_bf16(sacc[r]);
+            for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = f32_to_op(sacc[r]);
             st.l_run += sacc[0];
         } else if constexpr (MODE == 0) {
             float mloc = sacc[0];
@@ -120,7 +120,7 @@ __device__ __forceinline__ void tile(State<MODE>& st, const bf16x8 (&qf)[4], con
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -m_new));
                 psum += p;
-                pb[r >> 3][r & 7] = f32_to_bf16(p);
+                pb[r >> 3][r & 7] = f32_to_op(p);
             }
             st.l_run = st.l_run * alpha + psum;
             if (!__all(alpha == 1.0f)) {
@@ -136,7 +136,7 @@ __device__ __forceinline__ void tile(State<MODE>& st, const bf16x8 (&qf)[4], con
             for (int r = 0; r < 16; ++r) {
                 const float p = MODE == 2 ? __builtin_amdgcn_exp2f(sacc[r]) : __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -st.m_run));
                 psum += p;
-                pb[r >> 3][r & 7] = f32_to_bf16(p);
+                pb[r >> 3][r & 7] = f32_to_op(p);
             }
             const bool redo = (MODE == 2 && first && kb == 0) || !__all(psum <= 4096.0f);       // wave-uniform; NaN-safe (inf - inf cannot arise)
             if (redo) {
@@ -145,16 +145,21 @@ __device__ __forceinline__ void tile(State<MODE>& st, const bf16x8 (&qf)[4], con
                 for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
                 float shift;              // what to add to the fast path's exponent
                 if constexpr (MODE == 2) {
-                    const float m_new = bf16_to_f32(f32_to_bf16(fmaxf(st.m_run, half_max(mloc) + st.m_run)));
-                    shift = st.m_run - m_new;                      // <= 0 up to the bf16 rounding of m_new
+                    // the sequence's first block SETS the reference to the true maximum (the initial 0 is not a lower bound: a query whose
+                    // log2-domain scores all lie below -126 would otherwise flush every p to 0 and divide by a zero row sum);
+                    // later blocks only ever raise it
+                    const float cand = half_max(mloc) + st.m_run;
+                    const float m_new = op_to_f32(f32_to_op((first && kb == 0) ? cand : fmaxf(st.m_run, cand)));
+                    shift = st.m_run - m_new;                      // <= 0 up to the operand-type rounding of m_new (first block: any sign)
                     st.m_run = m_new;
-                    st.mref_b[0] = f32_to_bf16(half == 0 ? -m_new : 0.f);
+                    st.mref_b[0] = f32_to_op(half == 0 ? -m_new : 0.f);
                 } else {
                     const float m_new = fmaxf(st.m_run, half_max(mloc) * scale_log2);
                     shift = st.m_run - m_new;
                     st.m_run = m_new;
                 }
-                const float alpha = __builtin_amdgcn_exp2f(shift);
+                // (MODE 2, first block: nothing is accumulated yet and the shift may have either sign -- 0 * 2^shift must not become 0 * inf)
+                const float alpha = (MODE == 2 && first && kb == 0) ? 1.0f : __builtin_amdgcn_exp2f(shift);
                 st.l_run *= alpha;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -165,7 +170,7 @@ __device__ __forceinline__ void tile(State<MODE>& st, const bf16x8 (&qf)[4], con
                 for (int r = 0; r < 16; ++r) {
                     const float p = MODE == 2 ? __builtin_amdgcn_exp2f(sacc[r] + shift) : __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2, -st.m_run));
                     psum += p;
-                    pb[r >> 3][r & 7] = f32_to_bf16(p);
+                    pb[r >> 3][r & 7] = f32_to_op(p);
                 }
             }
             st.l_run += psum;
@@ -176,7 +181,7 @@ __device__ __forceinline__ void tile(State<MODE>& st, const bf16x8 (&qf)[4], con
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if constexpr (DBG == 3) st.oacc[db][u] += (float)vf[db][u][0] * (float)pb[u][0];
-                else st.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][u], pb[u], st.oacc[db], 0, 0, 0);
+                else st.oacc[db] = mfma_32x32x16(vf[db][u], pb[u], st.oacc[db]);
             }
     }
 }

@@ -2,7 +2,7 @@
 #include "sat_common.h"
 
 int glue_small_linear(const float* x, int ldx, const float* W, const float* bias, const float* add, int ldadd, void* y,
-                      int ldy, int R, int N, int K, int act, bool out_bf16, hipStream_t s);
+                      int ldy, int R, int N, int K, int act, int out16, hipStream_t s);      // out16: 0 fp32, 1 bf16, 2 fp16
 int glue_adaln_finish(float* ssg, int64_t n, int D, hipStream_t s);
 int glue_fourier(const float* t, float t_const, const float* w, float* out, int B, int half_feat, hipStream_t s);
 int glue_fold_in(const float* Win, const float* Wpre, float* Weff, int D, int C, hipStream_t s);

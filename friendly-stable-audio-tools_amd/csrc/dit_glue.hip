@@ -9,12 +9,13 @@ namespace {
 
 // y[r][n] = act( sum_k x[r][k] * W[n][k] + bias[n] ) (+ add[r][n]) ; one wave per n, RB rows
 // per wave.  x row stride ldx, y row stride ldy (lets the caller write straight into the
-// prepend-token rows of the residual stream).  OUT_BF16: y is bf16 (GEMM A operand).
-template <int RB, bool OUT_BF16>
+// prepend-token rows of the residual stream).  OUT16: 0 = y is fp32; 1 = bf16, 2 = IEEE fp16 (GEMM A operand).
+template <int RB, int OUT16>
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ add,
                                                            int ldadd, void* __restrict__ yv, int ldy, int R, int N, int K,
                                                            int act) {
+    if constexpr (OUT16 == 2) sat_f16_saturate_on();
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int r0 = blockIdx.y * RB;
@@ -45,8 +46,10 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
                 if (act == 1) v = silu_f(v);
                 if (add) v += add[(size_t)r * ldadd + n];
                 if (act == 2) v = silu_f(v);       // SiLU after the add (input of to_scale_shift_gate, transformer.py:653)
-                if (OUT_BF16)
+                if constexpr (OUT16 == 1)
                     reinterpret_cast<bf16_t*>(yv)[(size_t)r * ldy + n] = f32_to_bf16(v);
+                else if constexpr (OUT16 == 2)
+                    reinterpret_cast<_Float16*>(yv)[(size_t)r * ldy + n] = (_Float16)v;
                 else
                     reinterpret_cast<float*>(yv)[(size_t)r * ldy + n] = v;
             }
@@ -339,15 +342,17 @@ __global__ __launch_bounds__(256) void snake_kernel(const float* __restrict__ x,
 }  // namespace
 
 int glue_small_linear(const float* x, int ldx, const float* W, const float* bias, const float* add, int ldadd, void* y,
-                      int ldy, int R, int N, int K, int act, bool out_bf16, hipStream_t s) {
+                      int ldy, int R, int N, int K, int act, int out16, hipStream_t s) {
     SAT_CHECK_ARG(x && W && y && R > 0 && N > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0, SAT_E_INVALID,
                   "small_linear: bad args R=%d N=%d K=%d", R, N, K);
     constexpr int RB = 8;
     dim3 grid(cdiv(N, 4), cdiv(R, RB));
-    if (out_bf16)
-        hipLaunchKernelGGL((small_linear_kernel<RB, true>), grid, dim3(256), 0, s, x, ldx, W, bias, add, ldadd, y, ldy, R, N, K, act);
+    if (out16 == 1)
+        hipLaunchKernelGGL((small_linear_kernel<RB, 1>), grid, dim3(256), 0, s, x, ldx, W, bias, add, ldadd, y, ldy, R, N, K, act);
+    else if (out16 == 2)
+        hipLaunchKernelGGL((small_linear_kernel<RB, 2>), grid, dim3(256), 0, s, x, ldx, W, bias, add, ldadd, y, ldy, R, N, K, act);
     else
-        hipLaunchKernelGGL((small_linear_kernel<RB, false>), grid, dim3(256), 0, s, x, ldx, W, bias, add, ldadd, y, ldy, R, N, K, act);
+        hipLaunchKernelGGL((small_linear_kernel<RB, 0>), grid, dim3(256), 0, s, x, ldx, W, bias, add, ldadd, y, ldy, R, N, K, act);
     SAT_LAUNCH_CHECK();
     return 0;
 }

@@ -48,7 +48,7 @@ int sat_ensure_dynamic_lds(const void* kernel, int bytes) {
     if (n_seen < 64) seen[n_seen++] = Seen{kernel, dev};
     return 0;
 }
-extern "C" int sat_version(void) { return 3; }
+extern "C" int sat_version(void) { return 4; }
 
 // to_q + cross-attention in one launch where it applies (A/B switch; process-wide like sat_gemm_set_wide_tile)
 static int g_cross_fusion = 1;
@@ -73,9 +73,9 @@ struct Arena {
 
 struct LayerW {
     float *pre_g, *pre_b, *cross_g, *cross_b, *ff_g, *ff_b;
-    bf16_t *w_qkv, *w_o, *w_cq, *w_ckv, *w_co, *w_ff1, *w_ff2;
+    op_t *w_qkv, *w_o, *w_cq, *w_ckv, *w_co, *w_ff1, *w_ff2;
     float *b_ff1, *b_ff2;
-    float *s_qkv, *s_cq, *s_ff1, *s_ff2, *s_o, *s_co;      // fp8_gemm: per-output-channel scales (the weights above then hold e4m3 bytes)
+    float *s_qkv, *s_cq, *s_ff1, *s_ff2, *s_o, *s_co;      // gemm_dtype: per-output-channel scales (the weights above then hold e4m3 bytes)
     // LayerNorm folded into the GEMM behind it (plan->ln_fold): the weights above are bf16(gamma (.) W); GemmArgs::ln_c1 / ln_c2
     float *c1_qkv, *c2_qkv, *c1_cq, *c2_cq, *c1_ff1, *c2_ff1;
     bool fold_qkv;      // false for layer 0: its pre_norm reads rows written by the input projection, not by a GEMM epilogue
@@ -95,7 +95,8 @@ struct sat_dit_plan {
     float *ce0_w, *ce2_w, *ge0_w, *ge2_w;
     float *win_eff, *wout_eff;
     float *rope_cos, *rope_sin, *inv_freq;
-    bool ln_fold = false;           // cfg.ln_fold, bf16 operands, "prepend" conditioning: LayerNorms run inside the GEMM epilogues
+    int f16 = 0;                    // cfg.gemm_dtype == 3: every 16-bit operand buffer holds IEEE fp16 and the fp16 build of the kernels runs
+    bool ln_fold = false;           // cfg.ln_fold, bf16 / fp16 operands, "prepend" conditioning: LayerNorms run inside the GEMM epilogues
     int fp8_mode = 2;               // 2: v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, 2x rate); 1: v_mfma_f32_32x32x16_fp8_fp8
     float* ssg_w = nullptr;         // adaLN: [depth * 6D, D] stacked to_scale_shift_gate weights
     // per-generation context (sat_dit_prepare_context)
@@ -105,8 +106,8 @@ struct sat_dit_plan {
     bool has_global = false;
     int ctx_null_from = -1;         // sequences >= this index have an all-zero context (sat_dit_set_null_context_from)
     float* ge = nullptr;            // [bf, D] projected global embedding
-    bf16_t* kc = nullptr;           // [depth][bf, kvh, lcpad, 64]
-    bf16_t* vct = nullptr;          // [depth][bf, kvh, 64, lcpad]
+    op_t* kc = nullptr;           // [depth][bf, kvh, lcpad, 64]
+    op_t* vct = nullptr;          // [depth][bf, kvh, 64, lcpad]
     float* kc32 = nullptr;          // fp32 verification mode: [depth][bf, kvh, lc, 64]
     float* vc32 = nullptr;
     // optional HIP-event timing of the FFN-in (SwiGLU) GEMM of one layer per forward (sat_dit_profile)
@@ -137,31 +138,31 @@ int copy_f32(sat_dit_plan* p, Arena& ar, const std::string& name, int64_t numel,
     return 0;
 }
 
-int pack_w(sat_dit_plan* p, Arena& ar, const std::string& name, int n, int k, int interleave, bf16_t** dst, hipStream_t s) {
-    *dst = (bf16_t*)ar.take((size_t)n * k * 2);
+int pack_w(sat_dit_plan* p, Arena& ar, const std::string& name, int n, int k, int interleave, op_t** dst, hipStream_t s) {
+    *dst = (op_t*)ar.take((size_t)n * k * 2);
     if (ar.dry) return 0;
     const float* src;
     SAT_TRY(get_tensor(p, name, (int64_t)n * k, &src));
-    return sat_launch_pack_rows_bf16(src, *dst, n, k, interleave, s);
+    return sat_launch_pack_rows_bf16(src, *dst, n, k, interleave, s, p->f16);
 }
 
 // LayerNorm fold: bf16(gamma (.) W) + the two correction vectors of GemmArgs::ln_c1 / ln_c2 (bias folded into c2)
 int pack_w_ln(sat_dit_plan* p, Arena& ar, const std::string& name, const float* gamma, const float* beta, const std::string& bias_name, int n,
-              int k, int interleave, bf16_t** dst, float** c1, float** c2, hipStream_t s) {
-    *dst = (bf16_t*)ar.take((size_t)n * k * 2);
+              int k, int interleave, op_t** dst, float** c1, float** c2, hipStream_t s) {
+    *dst = (op_t*)ar.take((size_t)n * k * 2);
     *c1 = (float*)ar.take((size_t)n * 4);
     *c2 = (float*)ar.take((size_t)n * 4);
     if (ar.dry) return 0;
     const float *src, *bias = nullptr;
     SAT_TRY(get_tensor(p, name, (int64_t)n * k, &src));
     if (!bias_name.empty()) SAT_TRY(get_tensor(p, bias_name, n, &bias));
-    return sat_launch_pack_rows_ln(src, gamma, beta, bias, *dst, *c1, *c2, n, k, interleave, s);
+    return sat_launch_pack_rows_ln(src, gamma, beta, bias, *dst, *c1, *c2, n, k, interleave, s, p->f16);
 }
 
-// fp8_gemm: e4m3 bytes + one scale per output channel instead of bf16
-int pack_w8(sat_dit_plan* p, Arena& ar, const std::string& name, int n, int k, int interleave, bf16_t** dst, float** scale,
+// gemm_dtype: e4m3 bytes + one scale per output channel instead of bf16
+int pack_w8(sat_dit_plan* p, Arena& ar, const std::string& name, int n, int k, int interleave, op_t** dst, float** scale,
             hipStream_t s) {
-    *dst = (bf16_t*)ar.take((size_t)n * k);
+    *dst = (op_t*)ar.take((size_t)n * k);
     *scale = (float*)ar.take((size_t)n * 4);
     if (ar.dry) return 0;
     const float* src;
@@ -216,9 +217,9 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
         SAT_TRY(copy_f32(p, ar, pf + "pre_norm.beta", D, &L.pre_b, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.gamma", D, &L.ff_g, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.beta", D, &L.ff_b, s));
-        const bool f8 = c.fp8_gemm == 1;
-        if (c.fp8_gemm == 2) {      // fp32 verification mode: the reference's own fp32 weights, no re-packing (f32_ref.hip)
-            auto w32 = [&](const std::string& name, int64_t numel, bf16_t** dst) { return copy_f32(p, ar, pf + name, numel, (float**)dst, s); };
+        const bool f8 = c.gemm_dtype == 1;
+        if (c.gemm_dtype == 2) {      // fp32 verification mode: the reference's own fp32 weights, no re-packing (f32_ref.hip)
+            auto w32 = [&](const std::string& name, int64_t numel, op_t** dst) { return copy_f32(p, ar, pf + name, numel, (float**)dst, s); };
             SAT_TRY(w32("self_attn.to_qkv.weight", (int64_t)3 * D * D, &L.w_qkv));
             SAT_TRY(w32("self_attn.to_out.weight", (int64_t)D * D, &L.w_o));
             if (Dct > 0) {
@@ -270,11 +271,11 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
 
 struct Workspace {
     float* X;
-    bf16_t *A, *AO, *Q, *K, *Vt, *Hh;
+    op_t *A, *AO, *Q, *K, *Vt, *Hh;
     float *ff, *h1, *mo;
-    float* As;              // fp8_gemm: per-row scale of the quantised LayerNorm output in A
-    unsigned char* Hs;      // fp8_gemm: E8M0 block scales of the MXFP8 hidden activation in Hh, [M][inner / 32]
-    unsigned char* AOs;     // fp8_gemm: E8M0 block scales of the MXFP8 attention output in AO, [M][D / 32]
+    float* As;              // gemm_dtype: per-row scale of the quantised LayerNorm output in A
+    unsigned char* Hs;      // gemm_dtype: E8M0 block scales of the MXFP8 hidden activation in Hh, [M][inner / 32]
+    unsigned char* AOs;     // gemm_dtype: E8M0 block scales of the MXFP8 attention output in AO, [M][D / 32]
     float *gsum, *ssg;      // adaLN: silu(global + timestep embed) [bf, D]; per-layer modulation [bf, depth, 6, D]
     float* ln_part = nullptr;    // ln_fold: [M][D / 64][2] partial (sum, sum of squares) of the bf16 image of X kept in A
     float* f32_wide = nullptr;   // fp32 verification mode: [M, max(3D, 2 inner)] GEMM output before the head split / SwiGLU
@@ -296,14 +297,14 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
         return ptr;
     };
     w.X = (float*)take(M * D * 4);
-    if (c.fp8_gemm == 2) {      // fp32 verification mode: every intermediate is fp32, q / k / v un-padded [bf, H, S, 64]
-        w.A = (bf16_t*)take(M * D * 4);
-        w.AO = (bf16_t*)take(M * D * 4);
+    if (c.gemm_dtype == 2) {      // fp32 verification mode: every intermediate is fp32, q / k / v un-padded [bf, H, S, 64]
+        w.A = (op_t*)take(M * D * 4);
+        w.AO = (op_t*)take(M * D * 4);
         w.qkv_bytes = M * D * 4;
-        w.Q = (bf16_t*)take(w.qkv_bytes);
-        w.K = (bf16_t*)take(w.qkv_bytes);
-        w.Vt = (bf16_t*)take(w.qkv_bytes);
-        w.Hh = (bf16_t*)take(M * (size_t)p->inner * 4);
+        w.Q = (op_t*)take(w.qkv_bytes);
+        w.K = (op_t*)take(w.qkv_bytes);
+        w.Vt = (op_t*)take(w.qkv_bytes);
+        w.Hh = (op_t*)take(M * (size_t)p->inner * 4);
         w.f32_wide = (float*)take(M * (size_t)(2 * p->inner > 3 * D ? 2 * p->inner : 3 * D) * 4);     // [M, 3D] qkv / [M, 2 inner] FF-in
         w.ff = (float*)take((size_t)bf * 256 * 4);
         w.h1 = (float*)take((size_t)bf * D * 4);
@@ -314,20 +315,20 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
         w.total = off;
         return w;
     }
-    w.A = (bf16_t*)take(M * D * 2);
-    w.AO = (bf16_t*)take(M * D * 2);
+    w.A = (op_t*)take(M * D * 2);
+    w.AO = (op_t*)take(M * D * 2);
     w.qkv_bytes = (size_t)bf * H * Spad * 64 * 2;
     // Q, K, Vt contiguous so that one memset clears all pads
-    w.Q = (bf16_t*)take(w.qkv_bytes);
-    w.K = (bf16_t*)take(w.qkv_bytes);
-    w.Vt = (bf16_t*)take(w.qkv_bytes);
-    w.Hh = (bf16_t*)take(M * (size_t)p->inner * 2);
+    w.Q = (op_t*)take(w.qkv_bytes);
+    w.K = (op_t*)take(w.qkv_bytes);
+    w.Vt = (op_t*)take(w.qkv_bytes);
+    w.Hh = (op_t*)take(M * (size_t)p->inner * 2);
     w.ff = (float*)take((size_t)bf * 256 * 4);
     w.h1 = (float*)take((size_t)bf * D * 4);
     w.mo = (float*)take((size_t)bf * c.io_channels * T * 4);
-    w.As = c.fp8_gemm == 1 ? (float*)take(M * 4) : nullptr;
-    w.Hs = c.fp8_gemm == 1 ? (unsigned char*)take(M * (size_t)(p->inner / 32)) : nullptr;
-    w.AOs = c.fp8_gemm == 1 ? (unsigned char*)take(M * (size_t)(D / 32)) : nullptr;
+    w.As = c.gemm_dtype == 1 ? (float*)take(M * 4) : nullptr;
+    w.Hs = c.gemm_dtype == 1 ? (unsigned char*)take(M * (size_t)(p->inner / 32)) : nullptr;
+    w.AOs = c.gemm_dtype == 1 ? (unsigned char*)take(M * (size_t)(D / 32)) : nullptr;
     w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
     w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
     w.ln_part = p->ln_fold ? (float*)take(M * (size_t)(D / 64) * 2 * 4) : nullptr;
@@ -348,7 +349,8 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     Workspace w = carve(p, bf, T, (char*)ws);
     SAT_CHECK_ARG(ws_bytes >= w.total, SAT_E_WORKSPACE, "dit forward: workspace %zu < required %zu", ws_bytes, w.total);
     const int D = c.embed_dim, H = c.num_heads, C = c.io_channels;
-    const bool adaln = c.adaln != 0, f8 = c.fp8_gemm == 1, f32 = c.fp8_gemm == 2;
+    const bool adaln = c.adaln != 0, f8 = c.gemm_dtype == 1, f32 = c.gemm_dtype == 2;
+    const int f16 = p->f16;
     const int S = T + (adaln ? 0 : 1), M = bf * S, Spad = (int)round_up(S + 3, 128);
     const int ssg_ld = c.depth * 6 * D;      // per-sequence stride of the adaLN modulation vectors
 
@@ -357,14 +359,14 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
 
     // timestep embedding (dit.py:176) + global embed (dit.py:179-182) -> prepend token rows X[b,0,:]
     SAT_TRY(glue_fourier(t_dev, t_const, p->ts_w, w.ff, bf, 128, s));
-    SAT_TRY(glue_small_linear(w.ff, 256, p->te0_w, p->te0_b, nullptr, 0, w.h1, D, bf, D, 256, 1, false, s));
+    SAT_TRY(glue_small_linear(w.ff, 256, p->te0_w, p->te0_b, nullptr, 0, w.h1, D, bf, D, 256, 1, 0, s));
     if (!adaln) {
-        SAT_TRY(glue_small_linear(w.h1, D, p->te2_w, p->te2_b, p->has_global ? p->ge : nullptr, D, w.X, S * D, bf, D, D, 0, false, s));
+        SAT_TRY(glue_small_linear(w.h1, D, p->te2_w, p->te2_b, p->has_global ? p->ge : nullptr, D, w.X, S * D, bf, D, D, 0, 0, s));
     } else {
         // dit.py:205-206: the summed embedding conditions every block instead of being prepended; transformer.py:667:
         // (scale, shift, gate) x (self, ff) = Linear(SiLU(global)) for all layers in one launch
-        SAT_TRY(glue_small_linear(w.h1, D, p->te2_w, p->te2_b, p->has_global ? p->ge : nullptr, D, w.gsum, D, bf, D, D, 2, false, s));
-        SAT_TRY(glue_small_linear(w.gsum, D, p->ssg_w, nullptr, nullptr, 0, w.ssg, ssg_ld, bf, ssg_ld, D, 0, false, s));
+        SAT_TRY(glue_small_linear(w.h1, D, p->te2_w, p->te2_b, p->has_global ? p->ge : nullptr, D, w.gsum, D, bf, D, D, 2, 0, s));
+        SAT_TRY(glue_small_linear(w.gsum, D, p->ssg_w, nullptr, nullptr, 0, w.ssg, ssg_ld, bf, ssg_ld, D, 0, 0, s));
         SAT_TRY(glue_adaln_finish(w.ssg, (int64_t)bf * ssg_ld, D, s));
     }
     // preprocess_conv + residual + project_in (dit.py:197-199, transformer.py:778)
@@ -412,8 +414,8 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             if (lf) { ga.xb = w.A; ga.ln_part_out = w.ln_part; }
         };
         if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.pre_g, L.pre_b, w.A, w.As, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
-        else if (!L.fold_qkv) SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
-        g = GemmArgs{};
+        else if (!L.fold_qkv) SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s, f16));
+        g = GemmArgs{}; g.f16 = f16;
         g.A = w.A; g.W = L.w_qkv; g.M = M; g.N = 3 * D; g.K = D;
         if (L.fold_qkv) fold_in(g, L.c1_qkv, L.c2_qkv);
         if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_qkv; }
@@ -422,8 +424,8 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
         g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
         SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
-        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, f8 ? w.AOs : nullptr, 1.0f));
-        g = GemmArgs{};
+        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, f8 ? w.AOs : nullptr, 1.0f, f16));
+        g = GemmArgs{}; g.f16 = f16;
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
@@ -438,8 +440,8 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             const int Mc = bc * S;
             if (bc > 0) {
                 if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.cross_g, L.cross_b, w.A, w.As, Mc, D, nullptr, nullptr, 1, 0, s));
-                else if (!lf) SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s));
-                g = GemmArgs{};
+                else if (!lf) SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s, f16));
+                g = GemmArgs{}; g.f16 = f16;
                 g.A = w.A; g.W = L.w_cq; g.M = Mc; g.N = D; g.K = D;
                 if (lf) fold_in(g, L.c1_cq, L.c2_cq);
                 if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_cq; }
@@ -457,8 +459,8 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
                 if (!fuse)
                     SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
-                                                 p->ctx_lc, Spad, p->ctx_lcpad, s, f8 ? w.AOs : nullptr, 1.0f));
-                g = GemmArgs{};
+                                                 p->ctx_lc, Spad, p->ctx_lcpad, s, f8 ? w.AOs : nullptr, 1.0f, f16));
+                g = GemmArgs{}; g.f16 = f16;
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
                 if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
                 fold_out(g);
@@ -469,8 +471,8 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.ff_g, L.ff_b, w.A, w.As, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr,
                                                  S, ssg_ld, s));
         else if (!lf) SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
-                                                       ssg_ld, s));
-        g = GemmArgs{};
+                                                       ssg_ld, s, f16));
+        g = GemmArgs{}; g.f16 = f16;
         g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
         if (lf) { g.bias = nullptr; fold_in(g, L.c1_ff1, L.c2_ff1); }
         if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_ff1; g.H8 = (unsigned char*)w.Hh; g.Hs = w.Hs; }
@@ -491,7 +493,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             p->prof_n++;
             p->prof_m = g.M; p->prof_nn = g.N; p->prof_k = g.K;
         }
-        g = GemmArgs{};
+        g = GemmArgs{}; g.f16 = f16;
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.Hs; g.w_scale = L.s_ff2; }
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
@@ -524,15 +526,17 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
                       cfg->num_heads, kvh);
     }
     SAT_CHECK_ARG(cfg->global_cond_dim % 4 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: global_cond_dim must be a multiple of 4");
-    SAT_CHECK_ARG(cfg->fp8_gemm >= 0 && cfg->fp8_gemm <= 2, SAT_E_INVALID, "dit_plan_create: fp8_gemm must be 0 (bf16), 1 (e4m3) or 2 (fp32 verification)");
-    SAT_CHECK_ARG(cfg->fp8_gemm != 1 || cfg->embed_dim % 256 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: fp8_gemm needs embed_dim %% 256 == 0");
+    SAT_CHECK_ARG(cfg->gemm_dtype >= 0 && cfg->gemm_dtype <= 3, SAT_E_INVALID,
+                  "dit_plan_create: gemm_dtype must be 0 (bf16), 1 (e4m3), 2 (fp32 verification) or 3 (fp16)");
+    SAT_CHECK_ARG(cfg->gemm_dtype != 1 || cfg->embed_dim % 256 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: gemm_dtype needs embed_dim %% 256 == 0");
     sat_dit_plan* p = new (std::nothrow) sat_dit_plan();
     SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_plan_create: out of host memory");
     p->cfg = *cfg;
     p->kvh_cross = cfg->cond_token_dim > 0 ? cfg->cond_embed_dim / 64 : 0;
     // the fold lives in the bf16 pipelined GEMM tiles (K >= 192); adaLN modulates between LayerNorm and GEMM per sequence, the e4m3
     // path quantises the LayerNorm output per token: both keep the standalone kernels
-    p->ln_fold = cfg->ln_fold != 0 && cfg->fp8_gemm == 0 && !cfg->adaln && cfg->embed_dim >= 256;
+    p->f16 = cfg->gemm_dtype == 3 ? 1 : 0;
+    p->ln_fold = cfg->ln_fold != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
     return 0;
 }
@@ -560,7 +564,7 @@ extern "C" int sat_dit_plan_finalize(sat_dit_plan* p, sat_stream_t stream) {
     SAT_CHECK_ARG(it->second.second % (2 * (int64_t)D) == 0, SAT_E_INVALID, "dit plan: FF weight size not divisible by 2*embed_dim");
     p->inner = (int)(it->second.second / (2 * (int64_t)D));
     SAT_CHECK_ARG(p->inner % 64 == 0, SAT_E_UNSUPPORTED, "dit plan: FF inner dim %d must be a multiple of 64", p->inner);
-    SAT_CHECK_ARG(p->cfg.fp8_gemm != 1 || p->inner % 128 == 0, SAT_E_UNSUPPORTED, "dit plan: fp8_gemm needs an FF inner dim that is a multiple of 128");
+    SAT_CHECK_ARG(p->cfg.gemm_dtype != 1 || p->inner % 128 == 0, SAT_E_UNSUPPORTED, "dit plan: gemm_dtype needs an FF inner dim that is a multiple of 128");
     if (p->arena) {
         (void)hipFree(p->arena);
         p->arena = nullptr;
@@ -609,7 +613,7 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
     const size_t o_gh = take((size_t)bf * D * 4);
     const size_t o_ch = cross ? take((size_t)R * Dc * 4) : 0;
     const size_t o_ce = cross ? take((size_t)R * Dc * 2) : 0;
-    const bool f32 = c.fp8_gemm == 2;
+    const bool f32 = c.gemm_dtype == 2;
     const size_t kv_elems = cross ? (size_t)c.depth * bf * p->kvh_cross * (f32 ? lc : lcpad) * 64 : 0;
     const size_t o_kc = take(kv_elems * (f32 ? 4 : 2));
     const size_t o_vc = take(kv_elems * (f32 ? 4 : 2));
@@ -625,12 +629,12 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
     }
     p->ge = (float*)(p->ctx_buf + o_ge);
     float* gh = (float*)(p->ctx_buf + o_gh);
-    p->kc = (bf16_t*)(p->ctx_buf + o_kc);
-    p->vct = (bf16_t*)(p->ctx_buf + o_vc);
+    p->kc = (op_t*)(p->ctx_buf + o_kc);
+    p->vct = (op_t*)(p->ctx_buf + o_vc);
     p->has_global = global_cond != nullptr;
     if (global_cond) {   // dit.py:154
-        SAT_TRY(glue_small_linear(global_cond, Dg, p->ge0_w, nullptr, nullptr, 0, gh, D, bf, D, Dg, 1, false, s));
-        SAT_TRY(glue_small_linear(gh, D, p->ge2_w, nullptr, nullptr, 0, p->ge, D, bf, D, D, 0, false, s));
+        SAT_TRY(glue_small_linear(global_cond, Dg, p->ge0_w, nullptr, nullptr, 0, gh, D, bf, D, Dg, 1, 0, s));
+        SAT_TRY(glue_small_linear(gh, D, p->ge2_w, nullptr, nullptr, 0, p->ge, D, bf, D, D, 0, 0, s));
     }
     if (cross && f32) {   // fp32 verification mode: fp32 context embedding, fp32 K / V [bf, kvh, lc, 64] per layer
         float* ch = (float*)(p->ctx_buf + o_ch);
@@ -638,8 +642,8 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
         float* kv32 = (float*)(p->ctx_buf + o_kv32);
         p->kc32 = (float*)(p->ctx_buf + o_kc);
         p->vc32 = (float*)(p->ctx_buf + o_vc);
-        SAT_TRY(glue_small_linear(cond, Dct, p->ce0_w, nullptr, nullptr, 0, ch, Dc, R, Dc, Dct, 1, false, s));
-        SAT_TRY(glue_small_linear(ch, Dc, p->ce2_w, nullptr, nullptr, 0, ce32, Dc, R, Dc, Dc, 0, false, s));
+        SAT_TRY(glue_small_linear(cond, Dct, p->ce0_w, nullptr, nullptr, 0, ch, Dc, R, Dc, Dct, 1, 0, s));
+        SAT_TRY(glue_small_linear(ch, Dc, p->ce2_w, nullptr, nullptr, 0, ce32, Dc, R, Dc, Dc, 0, 0, s));
         const size_t per_layer = (size_t)bf * p->kvh_cross * lc * 64;
         for (int l = 0; l < c.depth; ++l) {
             SAT_TRY(sat_launch_gemm_f32(ce32, (const float*)p->layers[l].w_ckv, nullptr, kv32, R, 2 * Dc, Dc, 2 * Dc, 0, nullptr, 1, 0, s));
@@ -648,14 +652,15 @@ extern "C" int sat_dit_prepare_context(sat_dit_plan* p, const float* cond, int32
         }
     } else if (cross) {   // dit.py:150 then per-layer to_kv (transformer.py:420-427)
         float* ch = (float*)(p->ctx_buf + o_ch);
-        bf16_t* ce = (bf16_t*)(p->ctx_buf + o_ce);
-        SAT_TRY(glue_small_linear(cond, Dct, p->ce0_w, nullptr, nullptr, 0, ch, Dc, R, Dc, Dct, 1, false, s));
-        SAT_TRY(glue_small_linear(ch, Dc, p->ce2_w, nullptr, nullptr, 0, ce, Dc, R, Dc, Dc, 0, true, s));
+        op_t* ce = (op_t*)(p->ctx_buf + o_ce);
+        SAT_TRY(glue_small_linear(cond, Dct, p->ce0_w, nullptr, nullptr, 0, ch, Dc, R, Dc, Dct, 1, 0, s));
+        SAT_TRY(glue_small_linear(ch, Dc, p->ce2_w, nullptr, nullptr, 0, ce, Dc, R, Dc, Dc, 0, p->f16 ? 2 : 1, s));
         SAT_HIP(hipMemsetAsync(p->kc, 0, kv_elems * 2, s));
         SAT_HIP(hipMemsetAsync(p->vct, 0, kv_elems * 2, s));
         const size_t per_layer = (size_t)bf * p->kvh_cross * lcpad * 64;
         for (int l = 0; l < c.depth; ++l) {
             GemmArgs g{};
+            g.f16 = p->f16;
             g.A = ce; g.W = p->layers[l].w_ckv; g.M = R; g.N = 2 * Dc; g.K = Dc;
             g.heads.out[0] = p->kc + l * per_layer; g.heads.out[1] = p->vct + l * per_layer;
             g.heads.kind[0] = 4; g.heads.kind[1] = 1 | 4; g.heads.parts = 2; g.heads.heads = p->kvh_cross;
@@ -739,64 +744,121 @@ extern "C" int sat_cfg_combine(const float* model_out_dev, float* out_dev, int32
 }
 
 // ------------------------------------------------------------------------------ unit-level entry points
+static int layernorm_bf16_impl(int f16, const float* x, const float* gamma, const float* beta, void* y, int32_t m, int32_t d,
+                                  sat_stream_t stream) {
+    return sat_launch_layernorm(x, gamma, beta, (op_t*)y, m, d, (hipStream_t)stream, f16);
+}
 extern "C" int sat_layernorm_bf16(const float* x, const float* gamma, const float* beta, void* y, int32_t m, int32_t d,
                                   sat_stream_t stream) {
-    return sat_launch_layernorm(x, gamma, beta, (bf16_t*)y, m, d, (hipStream_t)stream);
+    return layernorm_bf16_impl(0, x, gamma, beta, y, m, d, stream);
+}
+extern "C" int sat_layernorm_f16(const float* x, const float* gamma, const float* beta, void* y, int32_t m, int32_t d,
+                                  sat_stream_t stream) {
+    return layernorm_bf16_impl(1, x, gamma, beta, y, m, d, stream);
 }
 
+static int cast_bf16_impl(int f16, const float* x, void* y, int64_t n, sat_stream_t stream) {
+    return sat_launch_cast_bf16(x, (op_t*)y, n, (hipStream_t)stream, f16);
+}
 extern "C" int sat_cast_bf16(const float* x, void* y, int64_t n, sat_stream_t stream) {
-    return sat_launch_cast_bf16(x, (bf16_t*)y, n, (hipStream_t)stream);
+    return cast_bf16_impl(0, x, y, n, stream);
+}
+extern "C" int sat_cast_f16(const float* x, void* y, int64_t n, sat_stream_t stream) {
+    return cast_bf16_impl(1, x, y, n, stream);
 }
 
-extern "C" int sat_gemm_bf16_f32(const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
+static int gemm_bf16_f32_impl(int f16, const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
                                  int32_t accumulate, int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(c, SAT_E_INVALID, "gemm: null output");
     GemmArgs g{};
-    g.A = (const bf16_t*)a; g.W = (const bf16_t*)w; g.bias = bias; g.M = m; g.N = n; g.K = k;
+    g.f16 = f16;
+    g.A = (const op_t*)a; g.W = (const op_t*)w; g.bias = bias; g.M = m; g.N = n; g.K = k;
     g.C = c; g.ldc = n; g.accumulate = accumulate; g.variant = variant;
     return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);
 }
+extern "C" int sat_gemm_bf16_f32(const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
+                                 int32_t accumulate, int32_t variant, sat_stream_t stream) {
+    return gemm_bf16_f32_impl(0, a, w, bias, c, m, n, k, accumulate, variant, stream);
+}
+extern "C" int sat_gemm_f16_f32(const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
+                                 int32_t accumulate, int32_t variant, sat_stream_t stream) {
+    return gemm_bf16_f32_impl(1, a, w, bias, c, m, n, k, accumulate, variant, stream);
+}
 
-extern "C" int sat_gemm_swiglu_bf16(const void* a, const float* w_f32, const float* bias_f32, void* wpack, float* bpack,
+static int gemm_swiglu_bf16_impl(int f16, const void* a, const float* w_f32, const float* bias_f32, void* wpack, float* bpack,
                                     void* h, int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(w_f32 && wpack && bpack && h, SAT_E_INVALID, "gemm_swiglu: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (!(variant & 0x4000)) {     // bit 14: wpack / bpack already hold the packed operands of a previous call (benchmarks)
-        SAT_TRY(sat_launch_pack_rows_bf16(w_f32, (bf16_t*)wpack, n, k, 1, s));
+        SAT_TRY(sat_launch_pack_rows_bf16(w_f32, (op_t*)wpack, n, k, 1, s, f16));
         if (bias_f32) SAT_TRY(sat_launch_pack_bias(bias_f32, bpack, n, 1, s));
     }
     GemmArgs g{};
-    g.A = (const bf16_t*)a; g.W = (const bf16_t*)wpack; g.bias = bias_f32 ? bpack : nullptr; g.M = m; g.N = n; g.K = k;
-    g.H = (bf16_t*)h; g.variant = variant;
+    g.f16 = f16;
+    g.A = (const op_t*)a; g.W = (const op_t*)wpack; g.bias = bias_f32 ? bpack : nullptr; g.M = m; g.N = n; g.K = k;
+    g.H = (op_t*)h; g.variant = variant;
     return sat_launch_gemm(EPI_SWIGLU, g, s);
 }
+extern "C" int sat_gemm_swiglu_bf16(const void* a, const float* w_f32, const float* bias_f32, void* wpack, float* bpack,
+                                    void* h, int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
+    return gemm_swiglu_bf16_impl(0, a, w_f32, bias_f32, wpack, bpack, h, m, n, k, variant, stream);
+}
+extern "C" int sat_gemm_swiglu_f16(const void* a, const float* w_f32, const float* bias_f32, void* wpack, float* bpack,
+                                    void* h, int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
+    return gemm_swiglu_bf16_impl(1, a, w_f32, bias_f32, wpack, bpack, h, m, n, k, variant, stream);
+}
 
+static int attention_bf16_impl(int f16, const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
+                                  int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
+    return sat_launch_attention((const op_t*)q, (const op_t*)k, (const op_t*)vt, (op_t*)out, b, h, kvh, sq, sk, sq_pad,
+                                sk_pad, (hipStream_t)stream, nullptr, SAT_ATTN_QSCALE, f16);
+}
 extern "C" int sat_attention_bf16(const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
                                   int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
-    return sat_launch_attention((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, b, h, kvh, sq, sk, sq_pad,
-                                sk_pad, (hipStream_t)stream);
+    return attention_bf16_impl(0, q, k, vt, out, b, h, kvh, sq, sk, sq_pad, sk_pad, stream);
+}
+extern "C" int sat_attention_f16(const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
+                                  int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
+    return attention_bf16_impl(1, q, k, vt, out, b, h, kvh, sq, sk, sq_pad, sk_pad, stream);
 }
 
 // to_q projection + cross-attention in ONE launch (what the plan runs per layer at one prompt): out [b*s, d] = attention(a wq^T, k, v)
-extern "C" int sat_cross_attention_fused_bf16(const void* a, const void* wq, const void* k, const void* vt, void* out, int32_t b, int32_t s_len,
+static int cross_attention_fused_bf16_impl(int f16, const void* a, const void* wq, const void* k, const void* vt, void* out, int32_t b, int32_t s_len,
                                               int32_t d, int32_t kvh, int32_t sk, int32_t sk_pad, sat_stream_t stream) {
     SAT_CHECK_ARG(a && wq && k && vt && out && b > 0 && s_len > 0 && d > 0 && d % 128 == 0 && kvh > 0, SAT_E_INVALID, "cross_attention_fused: bad argument");
     GemmArgs g{};
-    g.A = (const bf16_t*)a; g.W = (const bf16_t*)wq; g.M = b * s_len; g.N = d; g.K = d;
+    g.f16 = f16;
+    g.A = (const op_t*)a; g.W = (const op_t*)wq; g.M = b * s_len; g.N = d; g.K = d;
     g.heads.kind[0] = 8; g.heads.qscale = SAT_ATTN_QSCALE; g.heads.parts = 1; g.heads.heads = d / 64; g.heads.S = s_len; g.heads.Spad = s_len;
-    g.heads.xa_k = (const bf16_t*)k; g.heads.xa_vt = (const bf16_t*)vt; g.heads.xa_out = (bf16_t*)out;
+    g.heads.xa_k = (const op_t*)k; g.heads.xa_vt = (const op_t*)vt; g.heads.xa_out = (op_t*)out;
     g.heads.xa_kvh = kvh; g.heads.xa_sk = sk; g.heads.xa_sk_pad = sk_pad;
     return sat_launch_gemm(EPI_HEADS, g, (hipStream_t)stream);
 }
-
-// The layout the DiT plan runs: Q pre-scaled by 1/sqrt(64) * log2(e) by its producer (the QKV / to_q GEMM epilogue)
-extern "C" int sat_attention_prescaled_bf16(const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
-                                            int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
-    return sat_launch_attention((const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, b, h, kvh, sq, sk, sq_pad,
-                                sk_pad, (hipStream_t)stream, nullptr, 1.0f);
+extern "C" int sat_cross_attention_fused_bf16(const void* a, const void* wq, const void* k, const void* vt, void* out, int32_t b, int32_t s_len,
+                                              int32_t d, int32_t kvh, int32_t sk, int32_t sk_pad, sat_stream_t stream) {
+    return cross_attention_fused_bf16_impl(0, a, wq, k, vt, out, b, s_len, d, kvh, sk, sk_pad, stream);
+}
+extern "C" int sat_cross_attention_fused_f16(const void* a, const void* wq, const void* k, const void* vt, void* out, int32_t b, int32_t s_len,
+                                              int32_t d, int32_t kvh, int32_t sk, int32_t sk_pad, sat_stream_t stream) {
+    return cross_attention_fused_bf16_impl(1, a, wq, k, vt, out, b, s_len, d, kvh, sk, sk_pad, stream);
 }
 
-extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_freq, void* q, void* k, void* vt,
+// The layout the DiT plan runs: Q pre-scaled by 1/sqrt(64) * log2(e) by its producer (the QKV / to_q GEMM epilogue)
+static int attention_prescaled_bf16_impl(int f16, const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
+                                            int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
+    return sat_launch_attention((const op_t*)q, (const op_t*)k, (const op_t*)vt, (op_t*)out, b, h, kvh, sq, sk, sq_pad,
+                                sk_pad, (hipStream_t)stream, nullptr, 1.0f, f16);
+}
+extern "C" int sat_attention_prescaled_bf16(const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
+                                            int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
+    return attention_prescaled_bf16_impl(0, q, k, vt, out, b, h, kvh, sq, sk, sq_pad, sk_pad, stream);
+}
+extern "C" int sat_attention_prescaled_f16(const void* q, const void* k, const void* vt, void* out, int32_t b, int32_t h, int32_t kvh,
+                                            int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad, sat_stream_t stream) {
+    return attention_prescaled_bf16_impl(1, q, k, vt, out, b, h, kvh, sq, sk, sq_pad, sk_pad, stream);
+}
+
+static int qkv_rope_bf16_impl(int f16, const void* a, const void* w, const float* inv_freq, void* q, void* k, void* vt,
                                  float* rope_scratch, int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant,
                                  sat_stream_t stream) {
     SAT_CHECK_ARG(a && w && inv_freq && q && k && vt && rope_scratch, SAT_E_INVALID, "qkv_rope: null pointer");
@@ -811,38 +873,69 @@ extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_
     float* sn = rope_scratch + (size_t)s_len * 16;
     SAT_TRY(sat_launch_rope_table(inv_freq, cs, sn, s_len, s));
     GemmArgs g{};
-    g.A = (const bf16_t*)a; g.W = (const bf16_t*)w; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant;
-    g.heads.out[0] = (bf16_t*)q; g.heads.out[1] = (bf16_t*)k; g.heads.out[2] = (bf16_t*)vt;
+    g.f16 = f16;
+    g.A = (const op_t*)a; g.W = (const op_t*)w; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant;
+    g.heads.out[0] = (op_t*)q; g.heads.out[1] = (op_t*)k; g.heads.out[2] = (op_t*)vt;
     g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
     g.heads.parts = 3; g.heads.heads = H; g.heads.S = s_len; g.heads.Spad = s_pad;
     g.heads.rope_cos = cs; g.heads.rope_sin = sn;
     return sat_launch_gemm(EPI_HEADS, g, s);
 }
+extern "C" int sat_qkv_rope_bf16(const void* a, const void* w, const float* inv_freq, void* q, void* k, void* vt,
+                                 float* rope_scratch, int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant,
+                                 sat_stream_t stream) {
+    return qkv_rope_bf16_impl(0, a, w, inv_freq, q, k, vt, rope_scratch, b, s_len, s_pad, d, variant, stream);
+}
+extern "C" int sat_qkv_rope_f16(const void* a, const void* w, const float* inv_freq, void* q, void* k, void* vt,
+                                 float* rope_scratch, int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant,
+                                 sat_stream_t stream) {
+    return qkv_rope_bf16_impl(1, a, w, inv_freq, q, k, vt, rope_scratch, b, s_len, s_pad, d, variant, stream);
+}
 
 // ---- LayerNorm folded into the neighbouring GEMMs (sat_dit_cfg.ln_fold), one entry per role
-extern "C" int sat_gemm_resid_ln_bf16(const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
+static int gemm_resid_ln_bf16_impl(int f16, const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
                                       int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(c && xb && ln_part, SAT_E_INVALID, "gemm_resid_ln: null output");
     GemmArgs g{};
-    g.A = (const bf16_t*)a; g.W = (const bf16_t*)w; g.bias = bias; g.M = m; g.N = n; g.K = k;
-    g.C = c; g.ldc = n; g.accumulate = 1; g.variant = variant; g.xb = (bf16_t*)xb; g.ln_part_out = ln_part;
+    g.f16 = f16;
+    g.A = (const op_t*)a; g.W = (const op_t*)w; g.bias = bias; g.M = m; g.N = n; g.K = k;
+    g.C = c; g.ldc = n; g.accumulate = 1; g.variant = variant; g.xb = (op_t*)xb; g.ln_part_out = ln_part;
     return sat_launch_gemm(EPI_RESID, g, (hipStream_t)stream);
 }
+extern "C" int sat_gemm_resid_ln_bf16(const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
+                                      int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
+    return gemm_resid_ln_bf16_impl(0, a, w, bias, c, xb, ln_part, m, n, k, variant, stream);
+}
+extern "C" int sat_gemm_resid_ln_f16(const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
+                                      int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
+    return gemm_resid_ln_bf16_impl(1, a, w, bias, c, xb, ln_part, m, n, k, variant, stream);
+}
 
-extern "C" int sat_gemm_swiglu_ln_bf16(const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
+static int gemm_swiglu_ln_bf16_impl(int f16, const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
                                        const float* bias_f32, void* wpack, float* c12, void* h, int32_t m, int32_t n, int32_t k,
                                        int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(xb && ln_part && w_f32 && gamma && beta && wpack && c12 && h, SAT_E_INVALID, "gemm_swiglu_ln: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (!(variant & 0x4000))       // bit 14: wpack / c12 already hold the packed operands of a previous call (benchmarks)
-        SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, bias_f32, (bf16_t*)wpack, c12, c12 + n, n, k, 1, s));
+        SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, bias_f32, (op_t*)wpack, c12, c12 + n, n, k, 1, s, f16));
     GemmArgs g{};
-    g.A = (const bf16_t*)xb; g.W = (const bf16_t*)wpack; g.M = m; g.N = n; g.K = k; g.H = (bf16_t*)h; g.variant = variant & ~0x4000;
+    g.f16 = f16;
+    g.A = (const op_t*)xb; g.W = (const op_t*)wpack; g.M = m; g.N = n; g.K = k; g.H = (op_t*)h; g.variant = variant & ~0x4000;
     g.ln_part = ln_part; g.ln_c1 = c12; g.ln_c2 = c12 + n; g.ln_eps = 1e-5f;
     return sat_launch_gemm(EPI_SWIGLU, g, s);
 }
+extern "C" int sat_gemm_swiglu_ln_bf16(const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
+                                       const float* bias_f32, void* wpack, float* c12, void* h, int32_t m, int32_t n, int32_t k,
+                                       int32_t variant, sat_stream_t stream) {
+    return gemm_swiglu_ln_bf16_impl(0, xb, ln_part, w_f32, gamma, beta, bias_f32, wpack, c12, h, m, n, k, variant, stream);
+}
+extern "C" int sat_gemm_swiglu_ln_f16(const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
+                                       const float* bias_f32, void* wpack, float* c12, void* h, int32_t m, int32_t n, int32_t k,
+                                       int32_t variant, sat_stream_t stream) {
+    return gemm_swiglu_ln_bf16_impl(1, xb, ln_part, w_f32, gamma, beta, bias_f32, wpack, c12, h, m, n, k, variant, stream);
+}
 
-extern "C" int sat_qkv_rope_ln_bf16(const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
+static int qkv_rope_ln_bf16_impl(int f16, const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
                                     void* wpack, float* c12, const float* inv_freq, void* q, void* k, void* vt, float* rope_scratch,
                                     int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(xb && ln_part && w_f32 && gamma && beta && wpack && c12 && inv_freq && q && k && vt && rope_scratch, SAT_E_INVALID,
@@ -857,15 +950,26 @@ extern "C" int sat_qkv_rope_ln_bf16(const void* xb, const float* ln_part, const 
     float* cs = rope_scratch;
     float* sn = rope_scratch + (size_t)s_len * 16;
     SAT_TRY(sat_launch_rope_table(inv_freq, cs, sn, s_len, s));
-    SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, nullptr, (bf16_t*)wpack, c12, c12 + 3 * d, 3 * d, d, 0, s));
+    SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, nullptr, (op_t*)wpack, c12, c12 + 3 * d, 3 * d, d, 0, s, f16));
     GemmArgs g{};
-    g.A = (const bf16_t*)xb; g.W = (const bf16_t*)wpack; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant;
-    g.heads.out[0] = (bf16_t*)q; g.heads.out[1] = (bf16_t*)k; g.heads.out[2] = (bf16_t*)vt;
+    g.f16 = f16;
+    g.A = (const op_t*)xb; g.W = (const op_t*)wpack; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant;
+    g.heads.out[0] = (op_t*)q; g.heads.out[1] = (op_t*)k; g.heads.out[2] = (op_t*)vt;
     g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
     g.heads.parts = 3; g.heads.heads = H; g.heads.S = s_len; g.heads.Spad = s_pad;
     g.heads.rope_cos = cs; g.heads.rope_sin = sn;
     g.ln_part = ln_part; g.ln_c1 = c12; g.ln_c2 = c12 + 3 * d; g.ln_eps = 1e-5f;
     return sat_launch_gemm(EPI_HEADS, g, s);
+}
+extern "C" int sat_qkv_rope_ln_bf16(const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
+                                    void* wpack, float* c12, const float* inv_freq, void* q, void* k, void* vt, float* rope_scratch,
+                                    int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant, sat_stream_t stream) {
+    return qkv_rope_ln_bf16_impl(0, xb, ln_part, w_f32, gamma, beta, wpack, c12, inv_freq, q, k, vt, rope_scratch, b, s_len, s_pad, d, variant, stream);
+}
+extern "C" int sat_qkv_rope_ln_f16(const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,
+                                    void* wpack, float* c12, const float* inv_freq, void* q, void* k, void* vt, float* rope_scratch,
+                                    int32_t b, int32_t s_len, int32_t s_pad, int32_t d, int32_t variant, sat_stream_t stream) {
+    return qkv_rope_ln_bf16_impl(1, xb, ln_part, w_f32, gamma, beta, wpack, c12, inv_freq, q, k, vt, rope_scratch, b, s_len, s_pad, d, variant, stream);
 }
 
 extern "C" int sat_quant_rows_fp8(const float* x, void* out8, float* row_scale, int32_t rows, int32_t k, sat_stream_t stream) {
@@ -881,7 +985,7 @@ extern "C" int sat_gemm_fp8_f32(const void* a8, const float* a_scale, const void
                                 float* c, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream) {
     SAT_CHECK_ARG(a8 && w8 && a_scale && w_scale && c, SAT_E_INVALID, "gemm_fp8: null pointer");
     GemmArgs g{};
-    g.A = (const bf16_t*)a8; g.W = (const bf16_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & ~256;
+    g.A = (const op_t*)a8; g.W = (const op_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & ~256;
     g.C = c; g.ldc = n; g.accumulate = accumulate; g.a_scale = a_scale; g.w_scale = w_scale;
     g.fp8 = (variant & 256) ? 1 : 2;      // bit 8 of variant: the plain 32x32x16 fp8 MFMA instead of the 2x-rate scaled 32x32x64
     return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);
@@ -896,7 +1000,7 @@ extern "C" int sat_gemm_mxfp8_f32(const void* a8, const void* a_scales, const vo
     SAT_CHECK_ARG(a8 && w8 && a_scales && w_scale && c, SAT_E_INVALID, "gemm_mxfp8: null pointer");
     SAT_CHECK_ARG(((uintptr_t)a_scales & 3) == 0, SAT_E_INVALID, "gemm_mxfp8: the scale array must be 4-byte aligned");
     GemmArgs g{};
-    g.A = (const bf16_t*)a8; g.W = (const bf16_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & 0xff;
+    g.A = (const op_t*)a8; g.W = (const op_t*)w8; g.bias = bias; g.M = m; g.N = n; g.K = k; g.variant = variant & 0xff;
     g.C = c; g.ldc = n; g.accumulate = accumulate; g.a_bscale = (const unsigned*)a_scales; g.w_scale = w_scale; g.fp8 = 3;
     return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);
 }

@@ -70,7 +70,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 }
             }
     } else if constexpr (EPI == EPI_SWIGLU) {
-        bf16_t* __restrict__ H = g.H;
+        op_t* __restrict__ H = g.H;
         const int ldh = N >> 1;
         const float bv = g.bias ? g.bias[nw + l31] : 0.f;
         const float bg = g.bias ? g.bias[nw + 32 + l31] : 0.f;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                         if (l31 == 0) g.Hs[(size_t)m * (ldh >> 5) + (hc >> 5)] = (unsigned char)(e + 127);
                     }
                 } else if (m < M) {
-                    H[(size_t)m * ldh + hc] = f32_to_bf16(hv);
+                    H[(size_t)m * ldh + hc] = f32_to_op(hv);
                 }
             }
     } else {   // EPI_HEADS
@@ -110,7 +110,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         const int part = nw / hp;
         const int head = (nw - part * hp) >> 6;
         const int kind = he.kind[part];
-        bf16_t* __restrict__ dst = he.out[part];
+        op_t* __restrict__ dst = he.out[part];
         const int S = he.S, Spad = he.Spad;
         // K rows / V^T columns of sequence b are shifted by o_b = (b*S) & 3 (kind bit 2) so that the 4 consecutive
         // tokens a lane holds (rows 4q..4q+3 of the GEMM) land on an 8-byte aligned V^T span: one dwordx2 store
@@ -163,15 +163,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                         const int ob = shift ? ((bb[0] * S) & 3) : 0;
                         const size_t hbase = ((size_t)(bb[0] * he.heads + head) * 64) * Spad;
                         const size_t base = hbase + vt_pos(ss[0] + ob);         // aligned group of 4 keys: stays a group of 4
-                        bf16x4 p0, p1;
+                        opx4 p0, p1;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            p0[e] = f32_to_bf16(v0[e]);
-                            p1[e] = f32_to_bf16(v1[e]);
+                            p0[e] = f32_to_op(v0[e]);
+                            p1[e] = f32_to_op(v1[e]);
                         }
                         if (shift) {     // aligned: (ss[0] + ob) % 4 == mb % 4 == 0
-                            *reinterpret_cast<bf16x4*>(dst + base + (size_t)l31 * Spad) = p0;
-                            *reinterpret_cast<bf16x4*>(dst + base + (size_t)(32 + l31) * Spad) = p1;
+                            *reinterpret_cast<opx4*>(dst + base + (size_t)l31 * Spad) = p0;
+                            *reinterpret_cast<opx4*>(dst + base + (size_t)(32 + l31) * Spad) = p1;
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -186,8 +186,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                             if (mb + e < M) {
                                 const int ob = shift ? ((bb[e] * S) & 3) : 0;
                                 const size_t base = ((size_t)(bb[e] * he.heads + head) * 64) * Spad + vt_pos(ss[e] + ob);
-                                dst[base + (size_t)l31 * Spad] = f32_to_bf16(v0[e]);
-                                dst[base + (size_t)(32 + l31) * Spad] = f32_to_bf16(v1[e]);
+                                dst[base + (size_t)l31 * Spad] = f32_to_op(v0[e]);
+                                dst[base + (size_t)(32 + l31) * Spad] = f32_to_op(v1[e]);
                             }
                     }
                 } else {
@@ -197,8 +197,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                         if (mb + e < M) {
                             const int ob = shift ? ((bb[e] * S) & 3) : 0;
                             const size_t base = ((size_t)(bb[e] * he.heads + head) * Spad + ss[e] + ob) * 64;
-                            dst[base + l31] = f32_to_bf16(v0[e] * qs);
-                            dst[base + 32 + l31] = f32_to_bf16(v1[e] * qs);
+                            dst[base + l31] = f32_to_op(v0[e] * qs);
+                            dst[base + 32 + l31] = f32_to_op(v1[e] * qs);
                         }
                 }
             }
@@ -321,15 +321,15 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                 unsigned pk[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    pk[2 * q] = pack_bf16x2(hv[4 * q], hv[4 * q + 1]);
-                    pk[2 * q + 1] = pack_bf16x2(hv[4 * q + 2], hv[4 * q + 3]);
+                    pk[2 * q] = pack_op2(hv[4 * q], hv[4 * q + 1]);
+                    pk[2 * q + 1] = pack_op2(hv[4 * q + 2], hv[4 * q + 3]);
                 }
                 half_swap(pk[0], pk[2]);
                 half_swap(pk[1], pk[3]);
                 half_swap(pk[4], pk[6]);
                 half_swap(pk[5], pk[7]);
                 if (m < M) {
-                    bf16_t* hrow = g.H + (size_t)m * ldh + hc0 + 8 * half;
+                    op_t* hrow = g.H + (size_t)m * ldh + hc0 + 8 * half;
                     *reinterpret_cast<u32x4*>(hrow) = u32x4{pk[0], pk[1], pk[2], pk[3]};
                     *reinterpret_cast<u32x4*>(hrow + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
                 }
@@ -342,7 +342,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
         const int part = nw / hp;
         const int head = (nw - part * hp) >> 6;
         const int kind = he.kind[part];
-        bf16_t* __restrict__ dst = he.out[part];
+        op_t* __restrict__ dst = he.out[part];
         const int S = he.S, Spad = he.Spad;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -383,14 +383,14 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] *= he.qscale;
             }
-            bf16_t* row = dst + ((size_t)(b * he.heads + head) * Spad + s + ob) * 64 + 8 * half;
+            op_t* row = dst + ((size_t)(b * he.heads + head) * Spad + s + ob) * 64 + 8 * half;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 unsigned pk[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    pk[2 * q] = pack_bf16x2(acc[i][j][4 * q], acc[i][j][4 * q + 1]);
-                    pk[2 * q + 1] = pack_bf16x2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    pk[2 * q] = pack_op2(acc[i][j][4 * q], acc[i][j][4 * q + 1]);
+                    pk[2 * q + 1] = pack_op2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 }
                 half_swap(pk[0], pk[2]);
                 half_swap(pk[1], pk[3]);
@@ -455,19 +455,19 @@ __device__ __forceinline__ void gemm_epilogue_f32_staged(const GemmArgs& g, f32x
                 if (g.xb) {
                     // LayerNorm fold, producer side (wave-uniform test): bf16 image of the updated row piece + the statistics of the
                     // ROUNDED values over this wave's 64-column block (the 16 lanes of a DPP row hold one row of the pass)
-                    bf16x4 xr;
+                    opx4 xr;
                     float sum = 0.f, sq = 0.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        xr[e] = f32_to_bf16(v[e]);
-                        const float f = bf16_to_f32(xr[e]);
+                        xr[e] = f32_to_op(v[e]);
+                        const float f = op_to_f32(xr[e]);
                         sum += f;
                         sq += f * f;
                     }
                     sum = row16_sum(sum);
                     sq = row16_sum(sq);
                     if (m < M) {
-                        *reinterpret_cast<bf16x4*>(g.xb + (size_t)m * g.N + nw + c4) = xr;
+                        *reinterpret_cast<opx4*>(g.xb + (size_t)m * g.N + nw + c4) = xr;
                         if ((lane & 15) == 0)
                             *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (g.N >> 6) + (nw >> 6)) * 2) = make_float2(sum, sq);
                     }
@@ -479,6 +479,7 @@ __device__ __forceinline__ void gemm_epilogue_f32_staged(const GemmArgs& g, f32x
 
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
+    sat_f16_saturate();
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
     constexpr int TN = BN / WN;
@@ -515,12 +516,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
-    const bf16_t* __restrict__ A = g.A;
-    const bf16_t* __restrict__ W = g.W;
+    const op_t* __restrict__ A = g.A;
+    const op_t* __restrict__ W = g.W;
 
     // per-thread staging coordinates
     int a_row[A_CH], a_chk[A_CH];
-    const bf16_t* a_ptr[A_CH];
+    const op_t* a_ptr[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         int id = i * NT + tid;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
         a_ptr[i] = A + (size_t)gm * K + a_chk[i] * 8;
     }
     int b_row[B_CH], b_chk[B_CH];
-    const bf16_t* b_ptr[B_CH];
+    const op_t* b_ptr[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
         int id = i * NT + tid;
@@ -569,18 +570,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
         const char* sb = sa + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[MI], bfr[NI];
+            opx8 af[MI], bfr[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+                af[i] = *reinterpret_cast<const opx8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+                bfr[j] = *reinterpret_cast<const opx8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16(af[i], bfr[j], acc[i][j]);
         }
     };
 
@@ -610,6 +611,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs g) {
+    sat_f16_saturate();
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
     constexpr int TN = BN / WN;
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs g) {
     const int n0 = tn * BN;
 
     // per-lane source pointers (swizzle folded in); LDS destinations are wave-uniform
-    const bf16_t* a_ptr[A_CH];
+    const op_t* a_ptr[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         int q = i * NT + tid;
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs g) {
         gm = gm < M ? gm : M - 1;
         a_ptr[i] = g.A + (size_t)gm * K + c * 8;
     }
-    const bf16_t* b_ptr[B_CH];
+    const op_t* b_ptr[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
         int q = i * NT + tid;
@@ -690,18 +692,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmArgs g) {
         const char* sb = sa + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[MI], bfr[NI];
+            opx8 af[MI], bfr[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+                af[i] = *reinterpret_cast<const opx8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+                bfr[j] = *reinterpret_cast<const opx8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16(af[i], bfr[j], acc[i][j]);
         }
     };
 
@@ -740,6 +742,7 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
 // v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16 rate, but every LDS / L2 / HBM byte carries twice the k.
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
+    sat_f16_saturate();
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
     constexpr int TN = BN / WN;
@@ -802,8 +805,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     [[maybe_unused]] auto xa_stage = [&](int b) {
         const HeadsEpi& he = g.heads;
         const int kvh = (n0 >> 6) / (he.heads / he.xa_kvh);
-        const bf16_t* kbase = he.xa_k + (size_t)(b * he.xa_kvh + kvh) * he.xa_sk_pad * 64;
-        const bf16_t* vbase = he.xa_vt + (size_t)(b * he.xa_kvh + kvh) * 64 * he.xa_sk_pad;
+        const op_t* kbase = he.xa_k + (size_t)(b * he.xa_kvh + kvh) * he.xa_sk_pad * 64;
+        const op_t* vbase = he.xa_vt + (size_t)(b * he.xa_kvh + kvh) * 64 * he.xa_sk_pad;
         const int n_t = (((b * he.xa_sk) & 3) + he.xa_sk + 63) >> 6;
         for (int t = 0; t < n_t; ++t)
 #pragma unroll
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // LDS behind the ring: (mean, 1/std) of the BM rows, then the BN (c1, c2) pairs of this tile's output channels
     [[maybe_unused]] float2* lnst = reinterpret_cast<float2*>(smem + NS * STAGE_BYTES);
     [[maybe_unused]] float* lnc = reinterpret_cast<float*>(smem + NS * STAGE_BYTES + BM * 8);      // c1[BN] then c2[BN]
-    const bf16_t* ld_ptr[LPT];
+    const op_t* ld_ptr[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int L = i * NW + wave;               // wave-uniform
@@ -1032,14 +1035,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             }
             return;
         }
-        bf16x8 af[2][MI], bfr[2][NI];
+        opx8 af[2][MI], bfr[2][NI];
         auto frag = [&](int ks, int buf) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[buf][i] = *reinterpret_cast<const bf16x8*>(sa + lds_off_bk<BK>(wm * TM + i * 32 + l31, ks * 2 + half));
+                af[buf][i] = *reinterpret_cast<const opx8*>(sa + lds_off_bk<BK>(wm * TM + i * 32 + l31, ks * 2 + half));
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                bfr[buf][j] = *reinterpret_cast<const bf16x8*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
+                bfr[buf][j] = *reinterpret_cast<const opx8*>(sb + lds_off_bk<BK>(wn * TN + j * 32 + l31, ks * 2 + half));
         };
         frag(0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);        // the first fragments: DS reads only
@@ -1050,8 +1053,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = TRc ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0)
-                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TRc ? mfma_32x32x16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j])
+                                    : mfma_32x32x16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
             // pin the interleave: one ds_read of the NEXT step's fragments behind each MFMA of this step
             if (ks + 1 < KS) {
                 constexpr int NR = MI + NI, NM = MI * NI;
@@ -1177,11 +1180,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) qp[j][e] = 0u;
             if (wave_rows_valid) gemm_epilogue_t<EPI, MI, NI, LN_CONS>(g, acc, m0 + wm * TM, n0, half, l31, lnst + wm * TM, lnc, lnc + BN, qp);
-            bf16x8 qf[4];
+            opx8 qf[4];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                qf[2 * j] = __builtin_bit_cast(bf16x8, u32x4{qp[j][0], qp[j][1], qp[j][2], qp[j][3]});
-                qf[2 * j + 1] = __builtin_bit_cast(bf16x8, u32x4{qp[j][4], qp[j][5], qp[j][6], qp[j][7]});
+                qf[2 * j] = __builtin_bit_cast(opx8, u32x4{qp[j][0], qp[j][1], qp[j][2], qp[j][3]});
+                qf[2 * j + 1] = __builtin_bit_cast(opx8, u32x4{qp[j][4], qp[j][5], qp[j][6], qp[j][7]});
             }
             const int S = he.S;
             const int m = m0 + wm * TM + l31;
@@ -1208,14 +1211,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
                     attn::tile<2>(st, qf, sk, sk + 8192, edge, t * 64, ob, k_end, t == 0, 1.0f, l31, half);
                 }
                 const float inv = 1.0f / attn::half_sum(st.l_run);
-                bf16_t* op = he.xa_out + (size_t)m * ((size_t)he.heads * 64) + n0 + 8 * half;      // out row = b * S + s = m
+                op_t* op = he.xa_out + (size_t)m * ((size_t)he.heads * 64) + n0 + 8 * half;      // out row = b * S + s = m
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     unsigned pk[8];
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
-                        pk[2 * rq] = pack_bf16x2(st.oacc[db][rq * 4] * inv, st.oacc[db][rq * 4 + 1] * inv);
-                        pk[2 * rq + 1] = pack_bf16x2(st.oacc[db][rq * 4 + 2] * inv, st.oacc[db][rq * 4 + 3] * inv);
+                        pk[2 * rq] = pack_op2(st.oacc[db][rq * 4] * inv, st.oacc[db][rq * 4 + 1] * inv);
+                        pk[2 * rq + 1] = pack_op2(st.oacc[db][rq * 4 + 2] * inv, st.oacc[db][rq * 4 + 3] * inv);
                     }
                     half_swap(pk[0], pk[2]);            // 8 consecutive channels per lane: 16-byte stores
                     half_swap(pk[1], pk[3]);
@@ -1368,8 +1371,6 @@ inline bool deep_ring_off() {
 #endif
 }
 
-int g_wide_tile = 80;
-
 template <int EPI>
 int launch_epi(const GemmArgs& a, hipStream_t stream) {
     int v = a.variant & 0xff;
@@ -1403,7 +1404,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             }
         } else if (a.fp8 == 2) {      // block-scaled MFMA with unit scales: 2x the MFMA rate
             const int fv = a.variant & 0xff;
-            if ((fv == 80 || (fv == 0 && v == 22 && g_wide_tile == 80)) && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
+            if ((fv == 80 || (fv == 0 && v == 22 && sat_g_wide_tile == 80)) && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
             switch (v) {
                 case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 2>(a, stream);
                 case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 2>(a, stream);
@@ -1430,7 +1431,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             // (profiles/r03_ph8_streamk.txt): SwiGLU 1.26, heads 1.07, fp32 output with a long reduction 1.02 -- and with the K-split of the
             // remainder round (sat_gemm_ph8_splits) the last round costs ~0.35 of a round instead of 1.
             double s256 = score(256, 256, 1.0);
-            if (g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) {
+            if (sat_g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) {
                 const double rate = EPI == EPI_SWIGLU ? 1.26 : EPI == EPI_HEADS ? 1.07 : 1.02;
                 const long t = (long)cdiv(a.M, 256) * (a.N / 256);
                 const double rounds = sat_gemm_ph8_splits(EPI, a) ? (double)(t / 256) + 0.35 : (double)((t + 255) / 256);
@@ -1451,7 +1452,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
     }
     // the 256x256 tile is the 8-wave / 8-phase kernel of gemm_ph8.hip wherever it applies (bf16 operands, K % 128 == 0);
     // sat_gemm_set_wide_tile(22) brings the 16-wave 2-stage tile back for A/B measurements
-    if (v == 22 && !(a.variant & 0xff) && g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
+    if (v == 22 && !(a.variant & 0xff) && sat_g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
     switch (v) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
         case 5: return launch_cfg<128, 128, 2, 2, EPI, true>(a, stream);
@@ -1487,14 +1488,28 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+#ifndef SAT_OPERAND_F16
+int sat_g_wide_tile = 80;
 extern "C" int sat_gemm_set_wide_tile(int32_t tile) {
     SAT_CHECK_ARG(tile == 22 || tile == 80, SAT_E_INVALID, "sat_gemm_set_wide_tile: 22 (16 waves, 2-stage ring) or 80 (8 waves, 8-phase)");
-    g_wide_tile = tile;
+    sat_g_wide_tile = tile;
     return 0;
 }
+#else
+// entry of the fp16 build for the bf16 build's dispatcher (GemmArgs differs only in the pointer element type)
+int sat_launch_gemm_f16(int epi, const void* gemm_args, hipStream_t stream) {
+    return f16::sat_launch_gemm(epi, *static_cast<const f16::GemmArgs*>(gemm_args), stream);
+}
+#endif
 
-int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
+int SAT_OPNS::sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
+#ifndef SAT_OPERAND_F16
+    if (a.f16) return sat_launch_gemm_f16(epi, &a, stream);
+#else
+    SAT_CHECK_ARG(a.f16, SAT_E_INVALID, "gemm: bf16 operands handed to the fp16 build");
+#endif
     SAT_CHECK_ARG(a.A && a.W, SAT_E_INVALID, "gemm: null operand");
+    SAT_CHECK_ARG(!a.f16 || !a.fp8, SAT_E_UNSUPPORTED, "gemm: e4m3 operands ride in the bf16 build (fp8 mode keeps bf16 for everything else)");
     SAT_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, SAT_E_INVALID, "gemm: bad shape %d %d %d", a.M, a.N, a.K);
     SAT_CHECK_ARG(a.K % (a.fp8 ? 128 : 64) == 0, SAT_E_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", a.K, a.fp8 ? 128 : 64);
     SAT_CHECK_ARG(a.N % 128 == 0, SAT_E_UNSUPPORTED, "gemm: N=%d must be a multiple of 128", a.N);

@@ -161,15 +161,15 @@ __device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[
         x += old[nb];
         if (m < M) *reinterpret_cast<f32x4_t*>(crow + nb * 16) = x;
         if (prod) {
-            bf16x4 xr;
+            opx4 xr;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                xr[e] = f32_to_bf16(x[e]);
-                const float f = bf16_to_f32(xr[e]);
+                xr[e] = f32_to_op(x[e]);
+                const float f = op_to_f32(xr[e]);
                 sum += f;
                 sq += f * f;
             }
-            if (m < M) *reinterpret_cast<bf16x4*>(g.xb + (size_t)m * N + ncol0 + 4 * q4 + nb * 16) = xr;
+            if (m < M) *reinterpret_cast<opx4*>(g.xb + (size_t)m * N + ncol0 + 4 * q4 + nb * 16) = xr;
         }
     }
     if (prod) {       // add the four lanes (q4 = 0..3) that share the token row
@@ -201,6 +201,7 @@ __device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[
 // not matter.  The fp32 accumulators are multiplied by a_scale[token] * w_scale[channel] in front of the epilogue.
 template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0>
 __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
+    sat_f16_saturate();
     constexpr int NW = 2 * WN, NT = NW * 64;
     constexpr int QR = MFQ * 16;                 // rows of one quadrant of a wave
     constexpr int WR = 2 * QR;                   // rows of a wave
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     }
 
     f32x4_t acc[MB][4];
-    bf16x8 fa[MFQ][2], fwl[2][2], fwh[2][2];
+    opx8 fa[MFQ][2], fwl[2][2], fwh[2][2];
     typedef int i32x8_t __attribute__((ext_vector_type(8)));
     [[maybe_unused]] i32x8_t fa8[MFQ], fw8l[2], fw8h[2];          // FP8: one 32-byte fragment per 16-row block and K-tile
     // logical chunks 2 q4 and 2 q4 + 1 of the lane's row (the XOR swizzle may swap their physical order: put them back)
@@ -328,14 +329,14 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 #pragma unroll
         for (int f = 0; f < MFQ; ++f)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[f][ks] = *reinterpret_cast<const bf16x8*>(base + offA[ks] + f * 2048);
+            for (int ks = 0; ks < 2; ++ks) fa[f][ks] = *reinterpret_cast<const opx8*>(base + offA[ks] + f * 2048);
     };
-    auto read_w = [&](int buf, int hi, bf16x8 (&fw)[2][2]) {
+    auto read_w = [&](int buf, int hi, opx8 (&fw)[2][2]) {
         const char* base = smem + buf * BUF_BYTES + koff(hi ? 2 : 0);
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fw[f][ks] = *reinterpret_cast<const bf16x8*>(base + offW[ks] + f * 2048);
+            for (int ks = 0; ks < 2; ++ks) fw[f][ks] = *reinterpret_cast<const opx8*>(base + offW[ks] + f * 2048);
     };
 
     // SWAP: W fragment as the MFMA A operand -> a 16 x 16 block holds C^T (lane = token l15, registers = channels 4 q4 + r).
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     // Quadrant mi of a wave is skipped when its 64 rows lie beyond M (M-tail tiles: the wave keeps staging and joining barriers).
     auto main_loop = [&](auto swap_c, const int kt0, const int nk, const bool q_valid0, const bool q_valid1) {
         constexpr bool SWAP = decltype(swap_c)::value;
-        auto mfma_quadrant = [&](int mi, int ni, bf16x8 (&fw)[2][2]) {
+        auto mfma_quadrant = [&](int mi, int ni, opx8 (&fw)[2][2]) {
             if constexpr (DBG == 3) return;
             if (!(mi ? q_valid1 : q_valid0)) return;
             __builtin_amdgcn_s_setprio(1);
@@ -353,8 +354,8 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 for (int f = 0; f < MFQ; ++f)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[mi * MFQ + f][ni * 2 + n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[n][ks], fa[f][ks], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0)
-                                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f][ks], fw[n][ks], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0);
+                        acc[mi * MFQ + f][ni * 2 + n] = SWAP ? mfma_16x16x32(fw[n][ks], fa[f][ks], acc[mi * MFQ + f][ni * 2 + n])
+                                                             : mfma_16x16x32(fa[f][ks], fw[n][ks], acc[mi * MFQ + f][ni * 2 + n]);
             __builtin_amdgcn_s_setprio(0);
         };
         // One K-tile = four phases.  BUF is the LDS buffer of tile t; tile t + 2 restages the same buffer.
@@ -456,15 +457,15 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int ni = ni_first ^ h;
-                bf16x8 (&fw)[2][2] = ni ? fwh : fwl;
+                opx8 (&fw)[2][2] = ni ? fwh : fwl;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int f = 0; f < MFQ; ++f)
 #pragma unroll
                         for (int n = 0; n < 2; ++n)
-                            acc[mi * MFQ + f][ni * 2 + n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[n][ks], fa[f][ks], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0)
-                                                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f][ks], fw[n][ks], acc[mi * MFQ + f][ni * 2 + n], 0, 0, 0);
+                            acc[mi * MFQ + f][ni * 2 + n] = SWAP ? mfma_16x16x32(fw[n][ks], fa[f][ks], acc[mi * MFQ + f][ni * 2 + n])
+                                                                 : mfma_16x16x32(fa[f][ks], fw[n][ks], acc[mi * MFQ + f][ni * 2 + n]);
             }
             __builtin_amdgcn_s_setprio(0);
         };
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 c2v[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + q4 * 8 + nf * 4);
                 c2g[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + 32 + q4 * 8 + nf * 4);
             }
-            bf16_t* __restrict__ hbase = g.H + (ncol0 >> 1) + q4 * 8;
+            op_t* __restrict__ hbase = g.H + (ncol0 >> 1) + q4 * 8;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int m = mrow0 + mb * 16;
@@ -672,8 +673,8 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         hv[e] = v * silu_fast(gt);
                         if constexpr (FP8 != 0) hv8[4 * nf + e] = hv[e];
                     }
-                    pk[2 * nf] = pack_bf16x2(hv[0], hv[1]);
-                    pk[2 * nf + 1] = pack_bf16x2(hv[2], hv[3]);
+                    pk[2 * nf] = pack_op2(hv[0], hv[1]);
+                    pk[2 * nf + 1] = pack_op2(hv[2], hv[3]);
                 }
                 if constexpr (FP8 != 0) {
                     if (g.H8) {
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             const int part = ncol0 / hp;
             const int head = (ncol0 - part * hp) >> 6;
             const int kind = he.kind[part];
-            bf16_t* __restrict__ dst = he.out[part];
+            op_t* __restrict__ dst = he.out[part];
             const int S = he.S, Spad = he.Spad;
             if (s.tr) {
                 // q / k, row-major [B, H, Spad, 64].  PERM 2: block ni = 0 holds d = 16 nf + 4 q4 + r (the rotation partner d + 16 is
@@ -750,11 +751,11 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         for (int nb = 0; nb < 4; ++nb) x[nb] *= he.qscale;
                     }
                     if (m < M) {
-                        bf16_t* row = dst + ((size_t)(b * he.heads + head) * Spad + sq_ + ob) * 64;
-                        *reinterpret_cast<u32x2*>(row + 4 * q4) = u32x2{pack_bf16x2(x[0][0], x[0][1]), pack_bf16x2(x[0][2], x[0][3])};
-                        *reinterpret_cast<u32x2*>(row + 16 + 4 * q4) = u32x2{pack_bf16x2(x[1][0], x[1][1]), pack_bf16x2(x[1][2], x[1][3])};
-                        *reinterpret_cast<u32x4*>(row + 32 + 8 * q4) = u32x4{pack_bf16x2(x[2][0], x[2][1]), pack_bf16x2(x[2][2], x[2][3]),
-                                                                             pack_bf16x2(x[3][0], x[3][1]), pack_bf16x2(x[3][2], x[3][3])};
+                        op_t* row = dst + ((size_t)(b * he.heads + head) * Spad + sq_ + ob) * 64;
+                        *reinterpret_cast<u32x2*>(row + 4 * q4) = u32x2{pack_op2(x[0][0], x[0][1]), pack_op2(x[0][2], x[0][3])};
+                        *reinterpret_cast<u32x2*>(row + 16 + 4 * q4) = u32x2{pack_op2(x[1][0], x[1][1]), pack_op2(x[1][2], x[1][3])};
+                        *reinterpret_cast<u32x4*>(row + 32 + 8 * q4) = u32x4{pack_op2(x[2][0], x[2][1]), pack_op2(x[2][2], x[2][3]),
+                                                                             pack_op2(x[3][0], x[3][1]), pack_op2(x[3][2], x[3][3])};
                     }
                 }
             } else {
@@ -795,13 +796,13 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         }
                         const size_t drow = (size_t)(nb * 16 + l15) * Spad;
                         if (whole4 && shift) {         // aligned: (ss[0] + ob) % 4 == mbase % 4 == 0
-                            *reinterpret_cast<u32x2*>(dst + hb0 + vt_pos(ss[0] + ob0) + drow) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                            *reinterpret_cast<u32x2*>(dst + hb0 + vt_pos(ss[0] + ob0) + drow) = u32x2{pack_op2(v[0], v[1]), pack_op2(v[2], v[3])};
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
                                 if (mbase + e < M) {
                                     const int ob = shift ? ((bb[e] * S) & 3) : 0;
-                                    dst[((size_t)(bb[e] * he.heads + head) * 64) * Spad + vt_pos(ss[e] + ob) + drow] = f32_to_bf16(v[e]);
+                                    dst[((size_t)(bb[e] * he.heads + head) * 64) * Spad + vt_pos(ss[e] + ob) + drow] = f32_to_op(v[e]);
                                 }
                         }
                     }
@@ -939,6 +940,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 // eight waves -- every contributor's accumulator image in ascending workgroup order, bit-deterministic -- and runs the fp32 /
 // residual / LayerNorm-producer epilogue on the sums.  Same lane <-> element map as the GEMM, so the slab reads are 1-KiB coalesced.
 __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sched sc) {
+    sat_f16_saturate();
     const int j = blockIdx.x >> 3, mb = blockIdx.x & 7;
     const int parts = sc.sk_parts[j];
     if (parts <= 1) return;                          // a whole tile: finished by the GEMM launch itself
@@ -1192,7 +1194,7 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
 }  // namespace
 
 // whether the launcher's automatic choice of the 256 x 256 tile should land here (a forced variant 80 always does)
-bool sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
+bool SAT_OPNS::sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
     if (a.N % 256 || a.K % 128 || (uint64_t)a.M * (uint64_t)a.K * 2u >= (1ull << 31)) return false;
     if (a.fp8 || a.H8) {      // e4m3: the LayerNorm-fed GEMMs (to_qkv, cross to_q, FF-in) with per-token scales
         if (a.fp8 != 2 || a.K % 256 || a.ln_part || !(epi == EPI_SWIGLU || epi == EPI_HEADS) || (a.H8 && epi != EPI_SWIGLU)) return false;
@@ -1205,7 +1207,7 @@ bool sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
     return true;
 }
 
-#ifdef SAT_GEMM_EXPERIMENTS
+#if defined(SAT_GEMM_EXPERIMENTS) && !defined(SAT_OPERAND_F16)
 extern "C" int sat_gemm_ph8_timestamps(unsigned long long* out_host) {
     SAT_CHECK_ARG(g_ts_buf, SAT_E_INVALID, "no timestamps recorded");
     SAT_HIP(hipDeviceSynchronize());
@@ -1214,11 +1216,11 @@ extern "C" int sat_gemm_ph8_timestamps(unsigned long long* out_host) {
 }
 #endif
 
-bool sat_gemm_ph8_splits(int epi, const GemmArgs& a) {
+bool SAT_OPNS::sat_gemm_ph8_splits(int epi, const GemmArgs& a) {
     return ph8_auto_split(a, epi == EPI_F32 || epi == EPI_RESID, 256);
 }
 
-int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
+int SAT_OPNS::sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
     const int dbg = (a.variant & 0xfff) / 100;
 #ifdef SAT_GEMM_EXPERIMENTS
     // The 128 x 128 geometry (4 waves, two workgroups per CU), experiments build only: measured SLOWER than the 16-wave-family tiles at

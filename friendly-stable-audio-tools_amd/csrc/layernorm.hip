@@ -2,17 +2,22 @@
 // Replaces F.layer_norm at models/transformer.py:205-206 (pre_norm / cross_attend_norm /
 // ff_norm, :671/678/685 resp. :692/695/700).  HBM-bound: reads the fp32 residual stream
 // once (float4 per lane), two-pass statistics in registers, writes the bf16 GEMM operand.
+#include <type_traits>
+
 #include "sat_common.h"
 
 namespace {
 
 // D = 64 * 4 * NV  (NV float4 per lane)
 // FP8: the row is quantised to e4m3 with its own scale (amax / 448) -- the A operand of the fp8 GEMMs; y then points to bytes
-template <int NV, bool FP8 = false>
+// OT: the 16-bit output type, bf16 or IEEE fp16 (saturating conversion) -- the operand type of the GEMM kernels that read it
+template <int NV, bool FP8 = false, typename OT = bf16_t>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        const float* __restrict__ beta, OT* __restrict__ y,
                                                         int m, int d, const float* __restrict__ sc, const float* __restrict__ sh,
                                                         int rps, int ld, float* __restrict__ row_scale = nullptr) {
+    typedef OT otx4 __attribute__((ext_vector_type(4)));
+    sat_saturate_for<OT>();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -34,7 +39,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
     const float4* gr = reinterpret_cast<const float4*>(gamma);
     const float4* br = reinterpret_cast<const float4*>(beta);
-    [[maybe_unused]] bf16x4* yr = reinterpret_cast<bf16x4*>(y + (size_t)row * d);
+    [[maybe_unused]] otx4* yr = reinterpret_cast<otx4*>(y + (size_t)row * d);
     // adaLN modulation (wave-uniform branch): per-sequence (1 + scale) and shift vectors
     const float4* scr = sc ? reinterpret_cast<const float4*>(sc + (size_t)(row / rps) * ld) : nullptr;
     const float4* shr = sc ? reinterpret_cast<const float4*>(sh + (size_t)(row / rps) * ld) : nullptr;
@@ -57,11 +62,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if constexpr (FP8) {
             v[i] = r;             // keep the normalised row in registers for the amax pass
         } else {
-            bf16x4 o;
-            o[0] = f32_to_bf16(r.x);
-            o[1] = f32_to_bf16(r.y);
-            o[2] = f32_to_bf16(r.z);
-            o[3] = f32_to_bf16(r.w);
+            otx4 o;
+            o[0] = (OT)r.x;
+            o[1] = (OT)r.y;
+            o[2] = (OT)r.z;
+            o[3] = (OT)r.w;
             yr[i * 64 + lane] = o;
         }
     }
@@ -85,10 +90,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // generic fallback: any d % 4 == 0 (strided loop, row re-read from L2)
+template <typename OT>
 __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                const float* __restrict__ beta, OT* __restrict__ y,
                                                                 int m, int d, const float* __restrict__ sc,
                                                                 const float* __restrict__ sh, int rps, int ld) {
+    sat_saturate_for<OT>();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -107,30 +114,36 @@ __global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __r
     for (int i = lane; i < d; i += 64) {
         float r = (xr[i] - mean) * rstd * gamma[i] + (beta ? beta[i] : 0.f);
         if (scr) r = r * scr[i] + shr[i];
-        y[(size_t)row * d + i] = f32_to_bf16(r);
+        y[(size_t)row * d + i] = (OT)r;
     }
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+template <typename OT>
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, OT* __restrict__ y, int64_t n) {
+    typedef OT otx4 __attribute__((ext_vector_type(4)));
+    sat_saturate_for<OT>();
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     for (; i + 3 < n; i += stride) {
         float4 v = *reinterpret_cast<const float4*>(x + i);
-        bf16x4 o;
-        o[0] = f32_to_bf16(v.x);
-        o[1] = f32_to_bf16(v.y);
-        o[2] = f32_to_bf16(v.z);
-        o[3] = f32_to_bf16(v.w);
-        *reinterpret_cast<bf16x4*>(y + i) = o;
+        otx4 o;
+        o[0] = (OT)v.x;
+        o[1] = (OT)v.y;
+        o[2] = (OT)v.z;
+        o[3] = (OT)v.w;
+        *reinterpret_cast<otx4*>(y + i) = o;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int64_t j = n & ~(int64_t)3; j < n; ++j) y[j] = f32_to_bf16(x[j]);
+        for (int64_t j = n & ~(int64_t)3; j < n; ++j) y[j] = (OT)x[j];
 }
 
 // out[n'][k] = bf16(w[src(n')][k]); swiglu_interleave: groups of 64 output rows = 32 value
 // rows g*32.. followed by the 32 matching gate rows n/2 + g*32..  (see gemm_bf16.hip)
-__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int n, int k,
+template <typename OT>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ w, OT* __restrict__ out, int n, int k,
                                                         int interleave) {
+    typedef OT otx4 __attribute__((ext_vector_type(4)));
+    sat_saturate_for<OT>();
     const int row = blockIdx.x;
     int src = row;
     if (interleave) {
@@ -138,25 +151,28 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
         src = (c < 32) ? (g * 32 + c) : (n / 2 + g * 32 + (c - 32));
     }
     const float* wr = w + (size_t)src * k;
-    bf16_t* o = out + (size_t)row * k;
+    OT* o = out + (size_t)row * k;
     for (int i = threadIdx.x * 4; i < k; i += 256 * 4) {
         float4 v = *reinterpret_cast<const float4*>(wr + i);
-        bf16x4 p;
-        p[0] = f32_to_bf16(v.x);
-        p[1] = f32_to_bf16(v.y);
-        p[2] = f32_to_bf16(v.z);
-        p[3] = f32_to_bf16(v.w);
-        *reinterpret_cast<bf16x4*>(o + i) = p;
+        otx4 p;
+        p[0] = (OT)v.x;
+        p[1] = (OT)v.y;
+        p[2] = (OT)v.z;
+        p[3] = (OT)v.w;
+        *reinterpret_cast<otx4*>(o + i) = p;
     }
 }
 
 // Weights of a GEMM that absorbs the LayerNorm in front of it (GemmArgs::ln_*): out[n'][k] = bf16(gamma[k] * w[src(n')][k]),
 // c1[n'] = sum_k float(out[n'][k]) (the sum of what the MFMA will actually multiply), c2[n'] = sum_k beta[k] * w[src][k] + bias.
 // One workgroup per output row, same row permutation as pack_rows_kernel.
+template <typename OT>
 __global__ __launch_bounds__(256) void pack_rows_ln_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ bias,
-                                                           bf16_t* __restrict__ out, float* __restrict__ c1, float* __restrict__ c2, int n, int k,
+                                                           OT* __restrict__ out, float* __restrict__ c1, float* __restrict__ c2, int n, int k,
                                                            int interleave) {
+    typedef OT otx4 __attribute__((ext_vector_type(4)));
+    sat_saturate_for<OT>();
     __shared__ float red[2][4];
     const int row = blockIdx.x;
     int src = row;
@@ -165,19 +181,19 @@ __global__ __launch_bounds__(256) void pack_rows_ln_kernel(const float* __restri
         src = (c < 32) ? (g * 32 + c) : (n / 2 + g * 32 + (c - 32));
     }
     const float* wr = w + (size_t)src * k;
-    bf16_t* o = out + (size_t)row * k;
+    OT* o = out + (size_t)row * k;
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x * 4; i < k; i += 256 * 4) {
         const float4 v = *reinterpret_cast<const float4*>(wr + i);
         const float4 gm = *reinterpret_cast<const float4*>(gamma + i);
         const float4 bt = *reinterpret_cast<const float4*>(beta + i);
-        bf16x4 p;
-        p[0] = f32_to_bf16(v.x * gm.x);
-        p[1] = f32_to_bf16(v.y * gm.y);
-        p[2] = f32_to_bf16(v.z * gm.z);
-        p[3] = f32_to_bf16(v.w * gm.w);
-        *reinterpret_cast<bf16x4*>(o + i) = p;
-        s1 += (bf16_to_f32(p[0]) + bf16_to_f32(p[1])) + (bf16_to_f32(p[2]) + bf16_to_f32(p[3]));
+        otx4 p;
+        p[0] = (OT)(v.x * gm.x);
+        p[1] = (OT)(v.y * gm.y);
+        p[2] = (OT)(v.z * gm.z);
+        p[3] = (OT)(v.w * gm.w);
+        *reinterpret_cast<otx4*>(o + i) = p;
+        s1 += ((float)p[0] + (float)p[1]) + ((float)p[2] + (float)p[3]);
         s2 += (v.x * bt.x + v.y * bt.y) + (v.z * bt.z + v.w * bt.w);
     }
     s1 = wave_sum(s1);
@@ -273,24 +289,25 @@ __global__ void rope_table_kernel(const float* __restrict__ inv_freq, float* __r
 }  // namespace
 
 int sat_launch_layernorm_mod(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, const float* sc,
-                             const float* sh, int rps, int ld, hipStream_t s) {
+                             const float* sh, int rps, int ld, hipStream_t s, int f16) {
     SAT_CHECK_ARG(x && gamma && y && m > 0 && d > 0 && d % 4 == 0, SAT_E_INVALID, "layernorm: bad args m=%d d=%d", m, d);
     SAT_CHECK_ARG((sc == nullptr) == (sh == nullptr) && (!sc || (rps > 0 && ld % 4 == 0)), SAT_E_INVALID,
                   "layernorm: modulation needs both scale and shift, rows_per_seq > 0 and ld %% 4 == 0");
     dim3 grid(cdiv(m, 4)), block(256);
-    if (d % 256 == 0 && d / 256 <= 8) {
-        switch (d / 256) {
-            case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
-            case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
-            case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
-            case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
-            case 6: hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
-            case 8: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
-            default: hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld); break;
+    auto go = [&](auto* yt) {
+        using OT = std::remove_pointer_t<decltype(yt)>;
+        switch ((d % 256 == 0 && d / 256 <= 8) ? d / 256 : 0) {
+            case 1: hipLaunchKernelGGL((layernorm_kernel<1, false, OT>), grid, block, 0, s, x, gamma, beta, yt, m, d, sc, sh, rps, ld, (float*)nullptr); break;
+            case 2: hipLaunchKernelGGL((layernorm_kernel<2, false, OT>), grid, block, 0, s, x, gamma, beta, yt, m, d, sc, sh, rps, ld, (float*)nullptr); break;
+            case 3: hipLaunchKernelGGL((layernorm_kernel<3, false, OT>), grid, block, 0, s, x, gamma, beta, yt, m, d, sc, sh, rps, ld, (float*)nullptr); break;
+            case 4: hipLaunchKernelGGL((layernorm_kernel<4, false, OT>), grid, block, 0, s, x, gamma, beta, yt, m, d, sc, sh, rps, ld, (float*)nullptr); break;
+            case 6: hipLaunchKernelGGL((layernorm_kernel<6, false, OT>), grid, block, 0, s, x, gamma, beta, yt, m, d, sc, sh, rps, ld, (float*)nullptr); break;
+            case 8: hipLaunchKernelGGL((layernorm_kernel<8, false, OT>), grid, block, 0, s, x, gamma, beta, yt, m, d, sc, sh, rps, ld, (float*)nullptr); break;
+            default: hipLaunchKernelGGL(layernorm_generic_kernel<OT>, grid, block, 0, s, x, gamma, beta, yt, m, d, sc, sh, rps, ld); break;
         }
-    } else {
-        hipLaunchKernelGGL(layernorm_generic_kernel, grid, block, 0, s, x, gamma, beta, y, m, d, sc, sh, rps, ld);
-    }
+    };
+    if (f16) go(reinterpret_cast<_Float16*>(y));
+    else go(y);
     SAT_LAUNCH_CHECK();
     return 0;
 }
@@ -316,34 +333,37 @@ int sat_launch_layernorm_fp8(const float* x, const float* gamma, const float* be
     return 0;
 }
 
-int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s) {
-    return sat_launch_layernorm_mod(x, gamma, beta, y, m, d, nullptr, nullptr, 1, 0, s);
+int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s, int f16) {
+    return sat_launch_layernorm_mod(x, gamma, beta, y, m, d, nullptr, nullptr, 1, 0, s, f16);
 }
 
-int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s) {
+int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s, int f16) {
     SAT_CHECK_ARG(x && y && n > 0, SAT_E_INVALID, "cast: bad args");
     SAT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0), SAT_E_INVALID, "cast: unaligned pointers");
     int blocks = (int)((n / 4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, s, x, y, n);
+    if (f16) hipLaunchKernelGGL(cast_bf16_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, x, reinterpret_cast<_Float16*>(y), n);
+    else hipLaunchKernelGGL(cast_bf16_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, y, n);
     SAT_LAUNCH_CHECK();
     return 0;
 }
 
-int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swiglu_interleave, hipStream_t s) {
+int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swiglu_interleave, hipStream_t s, int f16) {
     SAT_CHECK_ARG(w && out && n > 0 && k > 0 && k % 4 == 0, SAT_E_INVALID, "pack_rows: bad args");
     SAT_CHECK_ARG(!swiglu_interleave || n % 128 == 0, SAT_E_UNSUPPORTED, "pack_rows: swiglu needs n %% 128 == 0");
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(n), dim3(256), 0, s, w, out, n, k, swiglu_interleave);
+    if (f16) hipLaunchKernelGGL(pack_rows_kernel<_Float16>, dim3(n), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(out), n, k, swiglu_interleave);
+    else hipLaunchKernelGGL(pack_rows_kernel<bf16_t>, dim3(n), dim3(256), 0, s, w, out, n, k, swiglu_interleave);
     SAT_LAUNCH_CHECK();
     return 0;
 }
 
 int sat_launch_pack_rows_ln(const float* w, const float* gamma, const float* beta, const float* bias, bf16_t* out, float* c1, float* c2,
-                            int n, int k, int swiglu_interleave, hipStream_t s) {
+                            int n, int k, int swiglu_interleave, hipStream_t s, int f16) {
     SAT_CHECK_ARG(w && gamma && beta && out && c1 && c2 && n > 0 && k > 0 && k % 4 == 0, SAT_E_INVALID, "pack_rows_ln: bad args");
     SAT_CHECK_ARG(!swiglu_interleave || n % 128 == 0, SAT_E_UNSUPPORTED, "pack_rows_ln: swiglu needs n %% 128 == 0");
-    hipLaunchKernelGGL(pack_rows_ln_kernel, dim3(n), dim3(256), 0, s, w, gamma, beta, bias, out, c1, c2, n, k, swiglu_interleave);
+    if (f16) hipLaunchKernelGGL(pack_rows_ln_kernel<_Float16>, dim3(n), dim3(256), 0, s, w, gamma, beta, bias, reinterpret_cast<_Float16*>(out), c1, c2, n, k, swiglu_interleave);
+    else hipLaunchKernelGGL(pack_rows_ln_kernel<bf16_t>, dim3(n), dim3(256), 0, s, w, gamma, beta, bias, out, c1, c2, n, k, swiglu_interleave);
     SAT_LAUNCH_CHECK();
     return 0;
 }

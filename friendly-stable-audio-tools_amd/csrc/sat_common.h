@@ -11,6 +11,30 @@ typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------
+// The 16-bit OPERAND type of the matrix kernels.  gemm_bf16.hip, gemm_ph8.hip, attention.hip (+ attn_core.h) and oobleck.hip are
+// compiled TWICE (csrc/Makefile): once with op_t = bf16 and once with -DSAT_OPERAND_F16, op_t = IEEE fp16 -- gfx950 runs
+// v_mfma_f32_*_f16 at exactly the rate of the bf16 instructions (MI355X_MICROARCH.md), fp16 carries three more significand bits
+// (8x less operand rounding), and fp16 is what the reference itself computes in on a GPU (inference/sampling.py:210 autocast,
+// models/transformer.py:496-504 flash-attn fp16, models/pretransforms.py:39-59 model_half).  Everything that names the element type
+// in those files goes through op_t / opx8 / f32_to_op / mfma_*; the host-facing launchers of the two builds live in namespace
+// bf16 / f16 (SAT_OPNS), the bf16 build owns the un-namespaced dispatchers and every extern "C" symbol.  Files compiled once
+// (dit_plan.hip, layernorm.hip, ...) see op_t = bf16 and treat operand buffers as opaque 16-bit storage.
+// fp16 range policy: conversions SATURATE at +-65504 (MODE.FP16_OVFL, set by sat_f16_saturate() at the top of every kernel of the
+// fp16 build) instead of producing infinities; inf / NaN inputs still propagate.
+#ifdef SAT_OPERAND_F16
+typedef _Float16 op_t;
+#define SAT_OPNS f16
+#define SAT_OP_IS_F16 1
+#else
+typedef __bf16 op_t;
+#define SAT_OPNS bf16
+#define SAT_OP_IS_F16 0
+#endif
+typedef op_t opx8 __attribute__((ext_vector_type(8)));
+typedef op_t opx4 __attribute__((ext_vector_type(4)));
+typedef op_t opx2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -62,6 +86,38 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }   // RNE
+__device__ __forceinline__ float op_to_f32(op_t v) { return (float)v; }
+__device__ __forceinline__ op_t f32_to_op(float v) { return (op_t)v; }          // RNE (fp16: saturating under sat_f16_saturate)
+
+// fp16 build: overflowing float -> half conversions clamp to +-65504 (MODE.FP16_OVFL, bit 23 of the MODE register) instead of
+// returning infinity.  One scalar instruction at kernel entry; a no-op in the bf16 build.
+__device__ __forceinline__ void sat_f16_saturate_on() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+__device__ __forceinline__ void sat_f16_saturate() {
+#ifdef SAT_OPERAND_F16
+    sat_f16_saturate_on();
+#endif
+}
+// kernels templated on their 16-bit output type (layernorm.hip, dit_glue.hip: compiled once)
+template <typename OT>
+__device__ __forceinline__ void sat_saturate_for() {
+    if constexpr (__is_same(OT, _Float16)) sat_f16_saturate_on();
+}
+
+// the two dense 16-bit MFMAs of gfx950 on the operand type of this build (same rate for bf16 and fp16)
+__device__ __forceinline__ f32x16 mfma_32x32x16(opx8 a, opx8 b, f32x16 c) {
+#ifdef SAT_OPERAND_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 mfma_16x16x32(opx8 a, opx8 b, f32x4 c) {
+#ifdef SAT_OPERAND_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
@@ -142,6 +198,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     v[1] = f32_to_bf16(b);
     return __builtin_bit_cast(unsigned, v);
 }
+__device__ __forceinline__ unsigned pack_op2(float a, float b) {
+    opx2 v;
+    v[0] = f32_to_op(a);
+    v[1] = f32_to_op(b);
+    return __builtin_bit_cast(unsigned, v);
+}
 // the same exchange on the fp32 values of a whole block: afterwards v[0..7] are channels c0 .. c0+7 and v[8..15] channels
 // c0+16 .. c0+23 of the lane's row, c0 = 8 * half (16-byte residual reads, 16-byte bf16 stores after packing)
 __device__ __forceinline__ void gather_channel_runs(const f32x16& a, float (&v)[16]) {
@@ -195,8 +257,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ---------------------------------------------------------------------------------------
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_HEADS = 3 };
 
+namespace SAT_OPNS {
+
 struct HeadsEpi {
-    bf16_t* out[3];      // per part destination
+    op_t* out[3];      // per part destination
     int kind[3];         // bit0: transposed ([B,Hh,64,Spad]) else [B,Hh,Spad,64]; bit1: apply RoPE;
                          // bit2: key-side tensor (K / V^T): rows/columns of sequence b shifted by (b*S)&3
                          // bit3: query tensor written PRE-SCALED by `qscale` (row-major destinations only): the attention
@@ -206,9 +270,9 @@ struct HeadsEpi {
     // store Q at all -- each wave keeps its 32 queries x 64 channels as MFMA fragments and runs softmax(q k^T) v against the
     // (batch, kv-head)'s keys / values, which the workgroup staged in LDS behind the GEMM ring at kernel start
     // (models/transformer.py:496-536 behind :430-437).  xa_k == nullptr: off.
-    const bf16_t* xa_k;      // [B, kvh, sk_pad, 64], key-side layout of sat_attention_bf16
-    const bf16_t* xa_vt;     // [B, kvh, 64, sk_pad]
-    bf16_t* xa_out;          // [M, heads * 64]
+    const op_t* xa_k;      // [B, kvh, sk_pad, 64], key-side layout of sat_attention_bf16
+    const op_t* xa_vt;     // [B, kvh, 64, sk_pad]
+    op_t* xa_out;          // [M, heads * 64]
     int xa_kvh, xa_sk, xa_sk_pad;
     int parts;           // N == parts * heads * 64
     int heads;           // heads per part
@@ -219,8 +283,9 @@ struct HeadsEpi {
 };
 
 struct GemmArgs {
-    const bf16_t* A;     // [M,K]
-    const bf16_t* W;     // [N,K]
+    int f16;             // operand format of A / W / H / xb / heads.*: 0 = bf16, 1 = IEEE fp16 (routes to the fp16 build of the kernels)
+    const op_t* A;     // [M,K]
+    const op_t* W;     // [N,K]
     const float* bias;   // [N] or nullptr
     int M, N, K;
     int variant;
@@ -242,7 +307,7 @@ struct GemmArgs {
     const float* gate;   // adaLN: (acc + bias) * gate[(row / gate_rows) * gate_ld + col] before the residual add; or nullptr
     int gate_rows, gate_ld;
     // EPI_SWIGLU
-    bf16_t* H;           // [M, N/2]
+    op_t* H;           // [M, N/2]
     // EPI_HEADS
     HeadsEpi heads;
     // ---- LayerNorm folded into the GEMMs either side of the residual stream (bf16 operands, pipelined tiles only).
@@ -250,7 +315,7 @@ struct GemmArgs {
     // (EPI_RESID, the "producer") also writes the bf16 image of the new rows and, per row and 64-column block, the sum and the
     // sum of squares of those rounded values; the GEMM that CONSUMES the normalised rows (EPI_SWIGLU / EPI_HEADS) takes the bf16
     // image as its A operand, gamma-scaled weights, and finishes the normalisation on its fp32 accumulators.
-    bf16_t* xb;                // producer: [M, N] bf16(C after the update), or nullptr
+    op_t* xb;                // producer: [M, N] bf16(C after the update), or nullptr
     float* ln_part_out;        // producer: [M][N / 64][2]
     const float* ln_part;      // consumer: [M][K / 64][2] partial (sum, sum of squares) of A's rows, or nullptr (no fold)
     const float* ln_c1;        // consumer: [N] sum_k bf16(gamma_k W_nk), epilogue channel order
@@ -258,28 +323,40 @@ struct GemmArgs {
     float ln_eps;
 };
 
+// bf16 build: checks a.f16 and forwards fp16 work to sat_launch_gemm_f16 (the fp16 build of the same file)
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream);
 bool sat_gemm_ph8_supports(int epi, const GemmArgs& a);
 bool sat_gemm_ph8_splits(int epi, const GemmArgs& a);       // the automatic schedule would split the remainder round along K
 int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream);     // gemm_ph8.hip: the 8-wave / 8-phase 256x256 tile
-int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, hipStream_t s);
+// out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
+// q_scale: what the kernel still has to multiply in -- SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e) for a plain Q, 1.0f for a Q the
+// producer already wrote pre-scaled (HeadsEpi kind bit 3): only then the single-KV-group kernel carries its softmax reference
+// through the matrix pipe (a plain Q would have to be rounded to bf16 a second time).
+// f16 != 0: q / k / vt / out hold IEEE fp16 (bf16 build: forwards to sat_launch_attention_f16)
+#define SAT_ATTN_QSCALE (0.125f * 1.4426950408889634f)
+int sat_launch_attention(const op_t* q, const op_t* k, const op_t* vt, op_t* out, int b, int h, int kvh,
+                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales = nullptr,
+                         float q_scale = SAT_ATTN_QSCALE, int f16 = 0);
+}  // namespace SAT_OPNS
+using namespace SAT_OPNS;
+// entry points of the fp16 build for the dispatchers of the bf16 build (GemmArgs is layout-identical in both builds: the pointer
+// element type is the only difference)
+int sat_launch_gemm_f16(int epi, const void* gemm_args, hipStream_t stream);
+int sat_launch_attention_f16(const void* q, const void* k, const void* vt, void* out, int b, int h, int kvh, int sq, int sk, int sq_pad,
+                             int sk_pad, hipStream_t s, unsigned char* out_scales, float q_scale);
+extern int sat_g_wide_tile;          // sat_gemm_set_wide_tile (gemm_bf16.hip, bf16 build)
+
+// f16 (last argument of the launchers below): the 16-bit output is IEEE fp16 (saturating) instead of bf16
+int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, op_t* y, int m, int d, hipStream_t s, int f16 = 0);
 // adaLN: y = LN(x) * scale1p[b] + shift[b] with b = row / rows_per_seq and per-sequence vectors ld apart (transformer.py:671-672)
-int sat_launch_layernorm_mod(const float* x, const float* gamma, const float* beta, bf16_t* y, int m, int d, const float* scale1p,
-                             const float* shift, int rows_per_seq, int ld, hipStream_t s);
+int sat_launch_layernorm_mod(const float* x, const float* gamma, const float* beta, op_t* y, int m, int d, const float* scale1p,
+                             const float* shift, int rows_per_seq, int ld, hipStream_t s, int f16 = 0);
 // LayerNorm (+ optional adaLN modulation) quantised per row to fp8 e4m3: y8 = rne(r / s), s = amax(r) / 448 -> row_scale[m]
 int sat_launch_layernorm_fp8(const float* x, const float* gamma, const float* beta, void* y8, float* row_scale, int m, int d,
                              const float* scale1p, const float* shift, int rows_per_seq, int ld, hipStream_t s);
 // rows of an fp32 matrix -> fp8 e4m3 with one scale per row (weights: per output channel; optional SwiGLU interleave)
 int sat_launch_quant_rows_fp8(const float* w, void* out8, float* row_scale, int n, int k, int swiglu_interleave, hipStream_t s);
 int sat_launch_quant_mx_rows(const float* x, void* out8, void* scales_e8m0, int rows, int k, hipStream_t s);
-// out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
-// q_scale: what the kernel still has to multiply in -- SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e) for a plain Q, 1.0f for a Q the
-// producer already wrote pre-scaled (HeadsEpi kind bit 3): only then the single-KV-group kernel carries its softmax reference
-// through the matrix pipe (a plain Q would have to be rounded to bf16 a second time).
-#define SAT_ATTN_QSCALE (0.125f * 1.4426950408889634f)
-int sat_launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* out, int b, int h, int kvh,
-                         int sq, int sk, int sq_pad, int sk_pad, hipStream_t s, unsigned char* out_scales = nullptr,
-                         float q_scale = SAT_ATTN_QSCALE);
 // fp32 verification path (f32_ref.hip)
 int sat_launch_gemm_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int ldc, int accumulate,
                         const float* gate, int gate_rows, int gate_ld, hipStream_t s);
@@ -290,11 +367,11 @@ int sat_launch_split_heads_f32(const float* src, float* d0, float* d1, float* d2
 int sat_launch_swiglu_f32(const float* hg, float* h, int64_t M, int inner, hipStream_t s);
 int sat_launch_attention_f32(const float* q, const float* k, const float* v, float* out, int b, int h, int kvh, int sq, int sk,
                              hipStream_t s);
-int sat_launch_cast_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t s);
-int sat_launch_pack_rows_bf16(const float* w, bf16_t* out, int n, int k, int swiglu_interleave, hipStream_t s);
+int sat_launch_cast_bf16(const float* x, op_t* y, int64_t n, hipStream_t s, int f16 = 0);
+int sat_launch_pack_rows_bf16(const float* w, op_t* out, int n, int k, int swiglu_interleave, hipStream_t s, int f16 = 0);
 int sat_launch_pack_bias(const float* b, float* out, int n, int swiglu_interleave, hipStream_t s);
 // weights of a GEMM that absorbs the LayerNorm in front of it: out = bf16(gamma (.) w) (rows permuted like pack_rows),
 // c1[n] = sum_k float(out[n][k]), c2[n] = sum_k beta[k] w[n][k] (+ bias[n])
-int sat_launch_pack_rows_ln(const float* w, const float* gamma, const float* beta, const float* bias, bf16_t* out, float* c1, float* c2,
-                            int n, int k, int swiglu_interleave, hipStream_t s);
+int sat_launch_pack_rows_ln(const float* w, const float* gamma, const float* beta, const float* bias, op_t* out, float* c1, float* c2,
+                            int n, int k, int swiglu_interleave, hipStream_t s, int f16 = 0);
 int sat_launch_rope_table(const float* inv_freq, float* cos_t, float* sin_t, int s_len, hipStream_t s);

@@ -21,7 +21,7 @@ class SatError(RuntimeError):
 class SatDitCfg(Structure):
     _fields_ = [("io_channels", c_int32), ("embed_dim", c_int32), ("depth", c_int32), ("num_heads", c_int32),
                 ("cond_token_dim", c_int32), ("cond_embed_dim", c_int32), ("global_cond_dim", c_int32),
-                ("max_seq_len", c_int32), ("adaln", c_int32), ("fp8_gemm", c_int32), ("ln_fold", c_int32)]
+                ("max_seq_len", c_int32), ("adaln", c_int32), ("gemm_dtype", c_int32), ("ln_fold", c_int32)]
 
 
 class SatT5Cfg(Structure):
@@ -106,6 +106,10 @@ _SIGNATURES = {
     "sat_overlap_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "sat_number_embed": (c_int32, [c_void_p, c_int32, c_float, c_float, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
 }
+
+# the same unit-level entry points on IEEE fp16 operands (gemm_dtype = 3): identical signatures
+for _n in ("sat_layernorm_bf16", "sat_cast_bf16", "sat_gemm_bf16_f32", "sat_gemm_swiglu_bf16", "sat_attention_bf16", "sat_cross_attention_fused_bf16", "sat_attention_prescaled_bf16", "sat_qkv_rope_bf16", "sat_gemm_resid_ln_bf16", "sat_gemm_swiglu_ln_bf16", "sat_qkv_rope_ln_bf16"):
+    _SIGNATURES[_n.replace("bf16", "f16")] = _SIGNATURES[_n]
 
 _lib = None
 

@@ -19,6 +19,9 @@ from .blocks import FourierFeatures
 from .transformer import ContinuousTransformer
 
 
+GEMM_DTYPES = {"bf16": 0, "fp8": 1, "fp32x": 2, "fp16": 3}      # sat_dit_cfg.gemm_dtype (include/sat_hip.h)
+
+
 class DiffusionTransformer(nn.Module):
     def __init__(self, io_channels: int = 32, patch_size: int = 1, embed_dim: int = 768, cond_token_dim: int = 0,
                  project_cond_tokens: bool = True, global_cond_dim: int = 0, project_global_cond: bool = True,
@@ -80,11 +83,14 @@ class DiffusionTransformer(nn.Module):
         return self
 
     def set_gemm_dtype(self, dtype: str):
-        """Build extension: "bf16" (default), "fp8" (BASELINE config 5: OCP e4m3 / MXFP8 operands for the block GEMMs) or "fp32x" --
-        the fp32 verification mode (exact fp32 MFMA, fp32 q / k / v / P; ~20x slower): the same plan and data flow with no operand
-        rounding, which meets the 1e-3 of north_star against the reference's own outputs.  Rebuilds the plan on next use."""
-        if dtype not in ("bf16", "fp8", "fp32x"):
-            raise ValueError("gemm_dtype must be 'bf16', 'fp8' or 'fp32x'")
+        """Build extension: operand format of the block GEMMs and attention kernels (accumulation is fp32 in all of them).
+        "bf16" (default); "fp16" -- IEEE fp16 operands on the fp16 build of the same kernels: the same MFMA rate on gfx950, three more
+        significand bits, and the arithmetic the reference itself uses on a GPU (``torch.cuda.amp.autocast`` in
+        ``inference/sampling.py:210``, fp16 flash attention in ``models/transformer.py:496-504``); conversions saturate at +-65504;
+        "fp8" (BASELINE config 5: OCP e4m3 / MXFP8 operands for the block GEMMs); "fp32x" -- the fp32 verification mode (exact fp32
+        MFMA, fp32 q / k / v / P; ~20x slower): the same plan and data flow with no operand rounding.  Rebuilds the plan on next use."""
+        if dtype not in GEMM_DTYPES:
+            raise ValueError(f"gemm_dtype must be one of {sorted(GEMM_DTYPES)}")
         if dtype != self.gemm_dtype:
             self.gemm_dtype = dtype
             self._plan_version = None
@@ -111,7 +117,7 @@ class DiffusionTransformer(nn.Module):
             self._plan = None
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
                              self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
-                             1 if self.global_cond_type == "adaLN" else 0, {"bf16": 0, "fp8": 1, "fp32x": 2}[self.gemm_dtype],
+                             1 if self.global_cond_type == "adaLN" else 0, GEMM_DTYPES[self.gemm_dtype],
                              1 if self.layernorm_fusion else 0)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))

@@ -54,6 +54,11 @@ const char* sat_last_error(void);
  * ---------------------------------------------------------------------------------- */
 typedef struct sat_dit_plan sat_dit_plan;
 
+#define SAT_GEMM_BF16 0
+#define SAT_GEMM_FP8 1
+#define SAT_GEMM_FP32X 2
+#define SAT_GEMM_FP16 3
+
 typedef struct sat_dit_cfg {
     int32_t io_channels;       /* config "io_channels" (64) */
     int32_t embed_dim;         /* "embed_dim" (1536); multiple of 128 */
@@ -67,17 +72,22 @@ typedef struct sat_dit_cfg {
                                   1: "adaLN" (models/dit.py:205-206, models/transformer.py:665-689): no prepend token, the
                                   global embedding drives per-layer scale/shift/gate of the self-attention and FF branches;
                                   needs "transformer.layers.N.to_scale_shift_gate.1.weight" [6*embed_dim, embed_dim] */
-    int32_t fp8_gemm;          /* 0: bf16 GEMM operands everywhere (default, the headline path);
-                                  1: BASELINE config 5 -- the GEMMs fed by a LayerNorm (self-attention to_qkv, cross-attention
+    int32_t gemm_dtype;        /* operand format of the block GEMMs and the attention kernels (fp32 accumulation throughout):
+                                  0 (SAT_GEMM_BF16): bf16 operands everywhere (the default, the headline path);
+                                  3 (SAT_GEMM_FP16): IEEE fp16 operands everywhere -- the same kernels built on v_mfma_f32_*_f16, which
+                                  gfx950 issues at the bf16 rate; three more significand bits (8x less operand rounding), and what the
+                                  reference computes in on a GPU (inference/sampling.py:210 autocast, transformer.py:496-504).  Range
+                                  policy: every fp32 -> fp16 conversion SATURATES at +-65504 (MODE.FP16_OVFL); values below 6e-8 flush;
+                                  1 (SAT_GEMM_FP8): BASELINE config 5 -- the GEMMs fed by a LayerNorm (self-attention to_qkv, cross-attention
                                   to_q, FF-in; transformer.py:314, 311, 222) take OCP e4m3 operands with one scale per token
                                   (activations) and per output channel (weights), fp32 accumulation; FF-out (transformer.py:270)
                                   takes the SwiGLU output as MXFP8 (e4m3 + one E8M0 scale per 32 hidden channels, written by the
                                   FF-in epilogue, consumed as hardware block scales) and e4m3 weights; the attention kernels write
                                   MXFP8 too (one scale per half head) for the to_out projections (transformer.py:319); rest as 0;
-                                  2: fp32 VERIFICATION mode -- every contraction of the blocks on the exact fp32 MFMA
+                                  2 (SAT_GEMM_FP32X): fp32 VERIFICATION mode -- every contraction of the blocks on the exact fp32 MFMA
                                   (v_mfma_f32_32x32x2_f32), fp32 LayerNorm output, fp32 q / k / v / P, fp32 weights: same plan, data flow
                                   and index arithmetic, no operand rounding (~20x slower; meets 1e-3 vs the reference's outputs) */
-    int32_t ln_fold;           /* 1 (fp8_gemm == 0, adaln == 0, embed_dim >= 256; ignored otherwise): no standalone LayerNorm launches
+    int32_t ln_fold;           /* 1 (gemm_dtype 0 or 3, adaln == 0, embed_dim >= 256; ignored otherwise): no standalone LayerNorm launches
                                   after the first one.  LN(x) W^T = rstd (x (gamma.W)^T - mean rowsum(gamma.W)) + beta W^T: the GEMM
                                   that updates the residual stream (to_out, FF-out; transformer.py:692-700) also writes bf16(x) and
                                   per-row partial sums, the GEMM behind the LayerNorm (to_qkv, to_q, FF-in) multiplies bf16(x) with
@@ -161,7 +171,7 @@ int sat_dpmpp3m_update(float* x_dev, const float* d_dev, const float* d1_dev, co
 int sat_lincomb(float* out_dev, const float* t0, float c0, const float* t1, float c1, const float* t2, float c2,
                 const float* t3, float c3, const float* t4, float c4, int64_t n, sat_stream_t stream);
 
-/* fp8 building blocks of fp8_gemm = 1, exported for the kernel-level parity tests:
+/* fp8 building blocks of gemm_dtype = 1, exported for the kernel-level parity tests:
  *   sat_quant_rows_fp8: x [rows, k] fp32 -> out8 [rows, k] OCP e4m3 bytes, row_scale[rows] = amax(row) / 448 (1 if the row is 0)
  *   sat_layernorm_fp8 : LayerNorm (eps 1e-5, transformer.py:205-206) fused with that row quantisation
  *   sat_gemm_fp8_f32  : c [m, n] (+)= (a8 . w8^T) * a_scale[m] * w_scale[n] (+ bias), k % 128 == 0, n % 128 == 0 */
@@ -314,6 +324,40 @@ int sat_qkv_rope_ln_bf16(const void* xb_dev, const float* ln_part_dev, const flo
                          const float* beta_dev, void* wpack_dev, float* c12_dev, const float* inv_freq_dev, void* q_dev, void* k_dev,
                          void* vt_dev, float* rope_scratch_dev, int32_t b, int32_t s, int32_t s_pad, int32_t d, int32_t variant,
                          sat_stream_t stream);
+/* ------------------------------------------------------------------------------------
+ * The same unit-level entry points on IEEE fp16 operands (gemm_dtype = 3): identical signatures and layouts, every
+ * "bf16" tensor holds fp16 instead, the kernels are the fp16 build of the same sources (v_mfma_f32_32x32x16_f16 /
+ * v_mfma_f32_16x16x32_f16; conversions saturate at +-65504).
+ * ---------------------------------------------------------------------------------- */
+int sat_layernorm_f16(const float* x_dev, const float* gamma_dev, const float* beta_dev, void* y_f16_dev,
+                      int32_t m, int32_t d, sat_stream_t stream);
+int sat_cast_f16(const float* x_dev, void* y_f16_dev, int64_t n, sat_stream_t stream);
+int sat_gemm_f16_f32(const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, float* c_dev,
+                     int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream);
+int sat_gemm_swiglu_f16(const void* a_f16_dev, const float* w_f32_dev, const float* bias_f32_dev,
+                        void* wpack_dev, float* bpack_dev, void* h_f16_dev,
+                        int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream);
+int sat_attention_f16(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
+                      int32_t b, int32_t h, int32_t kvh, int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad,
+                      sat_stream_t stream);
+int sat_attention_prescaled_f16(const void* q_dev, const void* k_dev, const void* vt_dev, void* out_dev,
+                                int32_t b, int32_t h, int32_t kvh, int32_t sq, int32_t sk, int32_t sq_pad, int32_t sk_pad,
+                                sat_stream_t stream);
+int sat_cross_attention_fused_f16(const void* a_f16_dev, const void* wq_f16_dev, const void* k_dev, const void* vt_dev, void* out_dev,
+                                  int32_t b, int32_t s, int32_t d, int32_t kvh, int32_t sk, int32_t sk_pad, sat_stream_t stream);
+int sat_qkv_rope_f16(const void* a_f16_dev, const void* w_f16_dev, const float* inv_freq_dev,
+                     void* q_dev, void* k_dev, void* vt_dev, float* rope_scratch_dev,
+                     int32_t b, int32_t s, int32_t s_pad, int32_t d, int32_t variant, sat_stream_t stream);
+int sat_gemm_resid_ln_f16(const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, float* c_dev, void* xb_dev,
+                          float* ln_part_dev, int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream);
+int sat_gemm_swiglu_ln_f16(const void* xb_dev, const float* ln_part_dev, const float* w_f32_dev, const float* gamma_dev,
+                           const float* beta_dev, const float* bias_f32_dev, void* wpack_dev, float* c12_dev, void* h_dev, int32_t m,
+                           int32_t n, int32_t k, int32_t variant, sat_stream_t stream);
+int sat_qkv_rope_ln_f16(const void* xb_dev, const float* ln_part_dev, const float* w_f32_dev, const float* gamma_dev,
+                        const float* beta_dev, void* wpack_dev, float* c12_dev, const float* inv_freq_dev, void* q_dev, void* k_dev,
+                        void* vt_dev, float* rope_scratch_dev, int32_t b, int32_t s, int32_t s_pad, int32_t d, int32_t variant,
+                        sat_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * T5 encoder stack: the text front-end of the conditioner.  Replaces the transformers.T5EncoderModel call in
  * T5Conditioner.forward (models/conditioners.py:317-339): last_hidden_state for tokenised prompts.  The algorithm is

@@ -24,6 +24,12 @@ def bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def fp16_round(x):
+    """IEEE fp16 rounding of the fp16 build (gemm_dtype = 3): round to nearest even, SATURATING at +-65504 (the kernels run with
+    MODE.FP16_OVFL set), subnormals kept."""
+    return x.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
+
+
 def _r(rnd, x):
     return x if rnd is None else rnd(x)
 
@@ -53,7 +59,7 @@ def mxfp8_blocks(x, block=32):
 
 
 class Fp8Rounding:
-    """Matched-rounding hook of BASELINE config 5 (sat_dit_cfg.fp8_gemm): bf16 everywhere, except that the LayerNorm outputs
+    """Matched-rounding hook of BASELINE config 5 (sat_dit_cfg.gemm_dtype = 1): bf16 everywhere, except that the LayerNorm outputs
     and the weights of the three GEMMs they feed (to_qkv, cross to_q, FF-in) are e4m3 with per-row scales, and FF-out takes the
     SwiGLU output as MXFP8 (block-32 power-of-two scales) and per-channel e4m3 weights; the attention outputs feed the to_out
     projections as MXFP8 too.  I.e. every GEMM of the blocks except the per-generation to_kv of the context."""
@@ -97,6 +103,12 @@ class LnFoldRounding:
         wp = self.round(h.gamma * w)
         c2 = F.linear(h.beta, w) if bias is None else F.linear(h.beta, w) + bias
         return rstd * (F.linear(xb, wp) - mean * wp.sum(dim=-1)) + c2
+
+
+class LnFoldRoundingF16(LnFoldRounding):
+    """The same plan on IEEE fp16 operands (``sat_dit_cfg.gemm_dtype = 3``)."""
+
+    round = staticmethod(fp16_round)
 
 
 def _norm_for_gemm(rnd, x, gamma, beta, fold=True):

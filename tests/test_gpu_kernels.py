@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import assert_close, bf16_round, rel_l2
+from util import FORMATS, assert_close, bf16_round, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -23,27 +23,31 @@ def _rand(shape, seed, scale=1.0):
     return torch.randn(shape, generator=g) * scale
 
 
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("m,d", [(2050, 1536), (37, 256), (5, 768)])
-def test_layernorm(dev, m, d):
+def test_layernorm(dev, m, d, fmt):
     _hip, lib = _lib()
     x = _rand((m, d), 1, 2.0) + 0.3
     g = 0.5 + 0.1 * _rand((d,), 2)
     b = 0.05 * _rand((d,), 3)
     want = F.layer_norm(x, (d,), g, b, eps=1e-5)
     xd, gd, bd = x.to(dev), g.to(dev), b.to(dev)
-    y = torch.empty((m, d), dtype=torch.bfloat16, device=dev)
-    _hip.check(lib.sat_layernorm_bf16(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(y), m, d, _hip.stream()))
-    assert_close("layernorm", y, want, 4e-3)
-    assert_close("layernorm-vs-rounded", y, bf16_round(want), 1e-3)
+    y = torch.empty((m, d), dtype=fmt.dtype, device=dev)
+    _hip.check(fmt.fn(lib, "sat_layernorm_bf16")(_hip.ptr(xd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(y), m, d, _hip.stream()))
+    assert_close("layernorm", y, want, fmt.tol(4e-3))
+    assert_close("layernorm-vs-rounded", y, fmt.round(want), fmt.tol(1e-3))
 
 
-def test_cast_bf16(dev):
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
+def test_cast_bf16(dev, fmt):
     _hip, lib = _lib()
     x = _rand((1000003,), 4)
+    if fmt.f16:       # range policy of the fp16 build: saturate at +-65504, keep subnormals, flush below 2^-25
+        x[:8] = torch.tensor([7e4, -7e4, 65504.0, 65520.0, 1e30, 3e-6, 2e-8, -1e-9])
     xd = x.to(dev)
-    y = torch.empty(x.shape, dtype=torch.bfloat16, device=dev)
-    _hip.check(lib.sat_cast_bf16(_hip.ptr(xd), _hip.ptr(y), x.numel(), _hip.stream()))
-    assert torch.equal(y.cpu(), x.to(torch.bfloat16))
+    y = torch.empty(x.shape, dtype=fmt.dtype, device=dev)
+    _hip.check(fmt.fn(lib, "sat_cast_bf16")(_hip.ptr(xd), _hip.ptr(y), x.numel(), _hip.stream()))
+    assert torch.equal(y.cpu(), x.clamp(-65504.0, 65504.0).to(fmt.dtype) if fmt.f16 else x.to(fmt.dtype))
 
 
 # the shipped tile configurations (gemm_bf16.hip: launch_epi); 0 = the launcher's own choice
@@ -66,41 +70,43 @@ def _skip_tile(variant, n, k):
         pytest.skip("the deep-prefetch variants need K >= stages * BK")
 
 
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("variant", GEMM_F32_VARIANTS)
 @pytest.mark.parametrize("m,n,k", [(2050, 1536, 1536), (130, 256, 128), (1, 512, 64), (257, 768, 6144)])
-def test_gemm_f32(dev, variant, m, n, k):
+def test_gemm_f32(dev, variant, m, n, k, fmt):
     _skip_tile(variant, n, k)
     _hip, lib = _lib()
-    a = _rand((m, k), 5).to(torch.bfloat16)
+    a = _rand((m, k), 5).to(fmt.dtype)
     # asymmetric weights so that a transposed / mis-indexed tile cannot pass
-    w = (_rand((n, k), 6) * 0.05 + torch.linspace(-0.02, 0.03, n)[:, None]).to(torch.bfloat16)
+    w = (_rand((n, k), 6) * 0.05 + torch.linspace(-0.02, 0.03, n)[:, None]).to(fmt.dtype)
     bias = _rand((n,), 7)
     c0 = _rand((m, n), 8)
     want = a.float() @ w.float().T + bias + c0
     ad, wd, bd, cd = a.to(dev), w.to(dev), bias.to(dev), c0.to(dev)
-    _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1, variant, _hip.stream()))
-    assert_close(f"gemm v{variant} {m}x{n}x{k}", cd, want, 1e-3)
+    _hip.check(fmt.fn(lib, "sat_gemm_bf16_f32")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1, variant, _hip.stream()))
+    assert_close(f"gemm v{variant} {m}x{n}x{k}", cd, want, 1e-3 if not fmt.f16 else 1e-5)      # same operands: fp32 summation order only
 
 
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("m", [300, 770])
 @pytest.mark.parametrize("variant", [0] + GEMM_VARIANTS)
-def test_gemm_swiglu(dev, variant, m):
+def test_gemm_swiglu(dev, variant, m, fmt):
     _hip, lib = _lib()
     k, inner = 256, 768
     _skip_tile(variant, 2 * inner, k)
-    a = _rand((m, k), 9).to(torch.bfloat16)
+    a = _rand((m, k), 9).to(fmt.dtype)
     w = _rand((2 * inner, k), 10) * 0.08
     bias = _rand((2 * inner,), 11) * 0.1
-    h = F.linear(a.float(), bf16_round(w), bias)
+    h = F.linear(a.float(), fmt.round(w), bias)
     val, gate = h.chunk(2, dim=-1)
     want = val * F.silu(gate)
     ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
-    wp = torch.empty((2 * inner, k), dtype=torch.bfloat16, device=dev)
+    wp = torch.empty((2 * inner, k), dtype=fmt.dtype, device=dev)
     bp = torch.empty((2 * inner,), dtype=torch.float32, device=dev)
-    out = torch.empty((m, inner), dtype=torch.bfloat16, device=dev)
-    _hip.check(lib.sat_gemm_swiglu_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m,
-                                        2 * inner, k, variant, _hip.stream()))
-    assert_close("swiglu", out, want, 4e-3)
+    out = torch.empty((m, inner), dtype=fmt.dtype, device=dev)
+    _hip.check(fmt.fn(lib, "sat_gemm_swiglu_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m,
+                                                   2 * inner, k, variant, _hip.stream()))
+    assert_close("swiglu", out, want, fmt.tol(4e-3))
 
 
 def _vt_perm(n):
@@ -120,155 +126,246 @@ def _pad_heads(x, s_pad, key_side=False):
     return out
 
 
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("prescaled", [False, True])
 @pytest.mark.parametrize("b,h,kvh,sq,sk", [(2, 4, 4, 1025, 1025), (1, 4, 2, 300, 130), (2, 2, 2, 64, 64), (1, 2, 1, 129, 7), (8, 64, 8, 300, 700)])
-def test_attention(dev, b, h, kvh, sq, sk, prescaled):
+def test_attention(dev, b, h, kvh, sq, sk, prescaled, fmt):
     """prescaled: the layout the DiT plan runs -- Q carries log2(e)/8 (written so by the QKV epilogue); every shape with <= 512 keys or
     >= 1024 workgroups of 256 queries then takes the single-KV-group kernel whose softmax reference rides in the matrix pipe."""
     from oracle import dit as odit
     _hip, lib = _lib()
     if b * h > 16 and not prescaled:
         pytest.skip("the 1024-workgroup grid is there for the pre-scaled single-group kernel on a long key range (11 tiles)")
-    q = (_rand((b, h, sq, 64), 12) * 1.5).to(torch.bfloat16)
-    k = (_rand((b, kvh, sk, 64), 13) * 1.5).to(torch.bfloat16)
-    v = _rand((b, kvh, sk, 64), 14).to(torch.bfloat16)
+    q = (_rand((b, h, sq, 64), 12) * 1.5).to(fmt.dtype)
+    k = (_rand((b, kvh, sk, 64), 13) * 1.5).to(fmt.dtype)
+    v = _rand((b, kvh, sk, 64), 14).to(fmt.dtype)
     # spike one key against one query so that the running max jumps late in the sequence (rescale branch)
     k[0, 0, sk - 1] = q[0, 0, min(5, sq - 1)] * 3
-    fn = lib.sat_attention_bf16
+    fn = fmt.fn(lib, "sat_attention_bf16")
     if prescaled:
         c = 0.125 * 1.4426950408889634
-        q = (q.float() * c).to(torch.bfloat16)          # what the producer stores ...
-        fn = lib.sat_attention_prescaled_bf16
+        q = (q.float() * c).to(fmt.dtype)               # what the producer stores ...
+        fn = fmt.fn(lib, "sat_attention_prescaled_bf16")
         q_eff = q.float() / c                           # ... and the query it stands for
     else:
         q_eff = q.float()
-    want = odit._merge(odit.attention_core(q_eff, k.float(), v.float(), rnd=bf16_round))
+    want = odit._merge(odit.attention_core(q_eff, k.float(), v.float(), rnd=fmt.round))
     sq_pad = (sq + 127) // 128 * 128
     sk_pad = (sk + 3 + 63) // 64 * 64
     qd = _pad_heads(q, sq_pad).to(dev)
     kd = _pad_heads(k, sk_pad, key_side=True).to(dev)
     vtd = _pad_heads(v, sk_pad, key_side=True).transpose(2, 3)[..., _vt_perm(sk_pad)].contiguous().to(dev)
-    out = torch.empty((b * sq, h * 64), dtype=torch.bfloat16, device=dev)
+    out = torch.empty((b * sq, h * 64), dtype=fmt.dtype, device=dev)
     _hip.check(fn(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, h, kvh, sq, sk, sq_pad, sk_pad, _hip.stream()))
-    assert_close(f"attention {b}x{h}x{sq}x{sk}", out.view(b, sq, h * 64), want, 5e-3)
+    assert_close(f"attention {b}x{h}x{sq}x{sk}", out.view(b, sq, h * 64), want, fmt.tol(5e-3))
     exact = odit._merge(odit.attention_core(q_eff, k.float(), v.float()))
-    assert rel_l2(out.view(b, sq, h * 64), exact) < 1e-2
+    assert rel_l2(out.view(b, sq, h * 64), exact) < fmt.tol(1e-2)
 
 
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_all_scores_strongly_negative(dev, prescaled, fmt):
+    """a query whose scores are ALL far below zero (log2-domain scores < -126).  The standing softmax reference of the
+    single-group pre-scaled kernel starts at 0; the sequence's first block has to SET it to the true maximum instead of clamping it
+    at >= 0, or every p flushes to 0 and the row divides by a zero sum.  Queries 0..31 anti-aligned with every key (logits ~ -150),
+    the rest ordinary; the second sequence tile holds the row's maximum (the reference has to move up, once)."""
+    from oracle import dit as odit
+    _hip, lib = _lib()
+    b, h, kvh, sq, sk = 1, 2, 2, 96, 200
+    base = F.normalize(_rand((64,), 300), dim=0)
+    k = (base[None, None, None, :] * 12.0 + 0.03 * _rand((b, kvh, sk, 64), 301)).to(fmt.dtype)
+    q = (_rand((b, h, sq, 64), 302) * 1.5)
+    q[:, :, :32] = -base * 100.0 + 0.03 * _rand((b, h, 32, 64), 303)           # q . k / 8 ~ -150: log2-domain ~ -216
+    q = q.to(fmt.dtype)
+    k[0, :, 150] = k[0, :, 150] * 0.62                                          # the negative rows' maximum (~ -93) sits in the third KV tile
+    v = _rand((b, kvh, sk, 64), 304).to(fmt.dtype)
+    fn = fmt.fn(lib, "sat_attention_bf16")
+    q_eff = q.float()
+    if prescaled:
+        c = 0.125 * 1.4426950408889634
+        q = (q.float() * c).to(fmt.dtype)
+        fn = fmt.fn(lib, "sat_attention_prescaled_bf16")
+        q_eff = q.float() / c
+    scores = torch.einsum("bhid,bhjd->bhij", q_eff, k.float()) / 8
+    assert scores[:, :, :32].max().item() < -88, "the first 32 queries must have every logit below -87 (2^-126 in the log2 domain)"
+    want = odit._merge(odit.attention_core(q_eff, k.float(), v.float(), rnd=fmt.round))
+    sq_pad, sk_pad = 128, 256
+    qd = _pad_heads(q, sq_pad).to(dev)
+    kd = _pad_heads(k, sk_pad, key_side=True).to(dev)
+    vtd = _pad_heads(v, sk_pad, key_side=True).transpose(2, 3)[..., _vt_perm(sk_pad)].contiguous().to(dev)
+    out = torch.empty((b * sq, h * 64), dtype=fmt.dtype, device=dev)
+    _hip.check(fn(_hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, h, kvh, sq, sk, sq_pad, sk_pad, _hip.stream()))
+    assert_close("attention, all-negative rows", out.view(b, sq, h * 64)[:, :32], want[:, :32], 2e-2 if not fmt.f16 else 5e-3)
+    assert_close("attention, ordinary rows", out.view(b, sq, h * 64)[:, 32:], want[:, 32:], fmt.tol(5e-3))
+
+
+def test_fp16_range_policy(dev):
+    """gemm_dtype = 3 range policy (include/sat_hip.h): residual-stream rows up to +-3e4 go through the LayerNorm-fold producer and
+    consumer at full fp16 relative precision; rows beyond +-65504 SATURATE in the fp16 image (finite output, statistics of the
+    saturated row) instead of turning the row into inf / NaN."""
+    fmt = FORMATS[1]
+    _hip, lib = _lib()
+    m, d, inner = 300, 768, 768
+    cd, xb, part = _ln_fold_producer(dev, m, d, 256, 0, seed=400, fmt=fmt, x_scale=1.0e4)       # |x| up to ~4e4
+    assert cd.abs().max().item() > 3.0e4
+    w = _rand((2 * inner, d), 401) * 0.08
+    gamma = 0.8 + 0.2 * _rand((d,), 402)
+    beta = 0.1 * _rand((d,), 403)
+    bias = 0.1 * _rand((2 * inner,), 404)
+    wd, gd, bd, bbd = w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev)
+    wp = torch.empty((2 * inner, d), dtype=fmt.dtype, device=dev)
+    c12 = torch.empty((4 * inner,), dtype=torch.float32, device=dev)
+    out = torch.full((m, inner), float("nan"), dtype=fmt.dtype, device=dev)
+    _hip.check(lib.sat_gemm_swiglu_ln_f16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(bbd), _hip.ptr(wp),
+                                          _hip.ptr(c12), _hip.ptr(out), m, 2 * inner, d, 0, _hip.stream()))
+    val, gate = F.linear(F.layer_norm(cd.cpu(), (d,), gamma, beta, eps=1e-5), w, bias).chunk(2, dim=-1)
+    assert_close("fp16 fold on rows of magnitude 3e4 vs fp32 LayerNorm + Linear", out, val * F.silu(gate), 2.5e-3)
+    # beyond the range: saturation, not infinity
+    x = _rand((64, d), 405) * 3.0e4
+    x[:, 7] = 2.0e5
+    x[:, 9] = -1.0e6
+    y = torch.empty((64, d), dtype=torch.float16, device=dev)
+    xd = x.to(dev)
+    _hip.check(lib.sat_cast_f16(_hip.ptr(xd), _hip.ptr(y), x.numel(), _hip.stream()))
+    assert torch.isfinite(y).all() and y[:, 7].eq(65504).all() and y[:, 9].eq(-65504).all()
+    a = torch.full((64, 256), 200.0, dtype=torch.float16)
+    wq = torch.full((d, 256), 2.0, dtype=torch.float16)
+    c0 = torch.zeros((64, d))
+    xb2 = torch.empty((64, d), dtype=torch.float16, device=dev)
+    part2 = torch.empty((64, d // 64, 2), dtype=torch.float32, device=dev)
+    ad, wqd, c0d = a.to(dev), wq.to(dev), c0.to(dev)
+    _hip.check(lib.sat_gemm_resid_ln_f16(_hip.ptr(ad), _hip.ptr(wqd), None, _hip.ptr(c0d), _hip.ptr(xb2), _hip.ptr(part2), 64, d, 256, 0, _hip.stream()))
+    assert c0d.eq(102400.0).all(), "fp32 output: exact"
+    assert xb2.eq(65504).all(), "the fp16 image of an over-range row saturates"
+    assert torch.allclose(part2[..., 0].cpu(), torch.full((64, d // 64), 64 * 65504.0)), "row statistics are those of the saturated image"
+    # below the normal range: fp16 subnormal operands (|x| < 2^-14) are multiplied as they are, not flushed, by the fp16 MFMAs
+    for variant in (15, 80):
+        a = torch.full((256, 256), 2.0 ** -20, dtype=torch.float16)
+        a[:, ::2] = 3 * 2.0 ** -24
+        wq = torch.full((256, 256), 4.0, dtype=torch.float16)
+        cz = torch.zeros((256, 256))
+        ad, wqd, czd = a.to(dev), wq.to(dev), cz.to(dev)
+        _hip.check(lib.sat_gemm_f16_f32(_hip.ptr(ad), _hip.ptr(wqd), None, _hip.ptr(czd), 256, 256, 256, 0, variant, _hip.stream()))
+        assert torch.equal(czd.cpu(), a.float() @ wq.float().T), f"tile {variant}: subnormal fp16 operands were flushed by the MFMA"
+
+
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("b,s,d,kvh,sk", [(1, 1025, 256, 2, 130), (3, 300, 256, 4, 7), (2, 129, 256, 1, 189), (1, 50, 1536, 12, 130)])
-def test_cross_attention_fused(dev, b, s, d, kvh, sk):
+def test_cross_attention_fused(dev, b, s, d, kvh, sk, fmt):
     """to_q projection + cross-attention core in one launch (the 128 x 64 GEMM tile keeps Q in registers and attends to the context keys
     staged in LDS; transformer.py:430-437 + 496-536) against the oracle on the query the epilogue stands for (pre-scaled by log2(e)/8,
     one bf16 rounding).  s = 300 / 129: tiles and waves whose rows straddle two sequences (second pass on the next sequence's keys)."""
     from oracle import dit as odit
     _hip, lib = _lib()
     h = d // 64
-    a = _rand((b * s, d), 31).to(torch.bfloat16)
-    wq = (_rand((d, d), 32) * (1.5 / d ** 0.5)).to(torch.bfloat16)
-    k = (_rand((b, kvh, sk, 64), 33) * 1.5).to(torch.bfloat16)
-    v = _rand((b, kvh, sk, 64), 34).to(torch.bfloat16)
+    a = _rand((b * s, d), 31).to(fmt.dtype)
+    wq = (_rand((d, d), 32) * (1.5 / d ** 0.5)).to(fmt.dtype)
+    k = (_rand((b, kvh, sk, 64), 33) * 1.5).to(fmt.dtype)
+    v = _rand((b, kvh, sk, 64), 34).to(fmt.dtype)
     c = 0.125 * 1.4426950408889634
     q = (a.float() @ wq.float().T).view(b, s, h, 64).permute(0, 2, 1, 3)
-    q_eff = (q * c).to(torch.bfloat16).float() / c
-    want = odit._merge(odit.attention_core(q_eff, k.float(), v.float(), rnd=bf16_round))
+    q_eff = (q * c).to(fmt.dtype).float() / c
+    want = odit._merge(odit.attention_core(q_eff, k.float(), v.float(), rnd=fmt.round))
     sk_pad = (sk + 3 + 63) // 64 * 64
     kd = _pad_heads(k, sk_pad, key_side=True).to(dev)
     vtd = _pad_heads(v, sk_pad, key_side=True).transpose(2, 3)[..., _vt_perm(sk_pad)].contiguous().to(dev)
-    out = torch.zeros((b * s, d), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((b * s, d), dtype=fmt.dtype, device=dev)
     ad, wd = a.to(dev), wq.to(dev)          # (named: a temporary would be freed before the launch reads it)
-    _hip.check(lib.sat_cross_attention_fused_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, s, d,
-                                                  kvh, sk, sk_pad, _hip.stream()))
-    assert_close(f"fused cross-attention {b}x{s}x{d} kv{kvh} sk{sk}", out.view(b, s, d), want, 5e-3)
+    _hip.check(fmt.fn(lib, "sat_cross_attention_fused_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(out), b, s, d,
+                                                             kvh, sk, sk_pad, _hip.stream()))
+    assert_close(f"fused cross-attention {b}x{s}x{d} kv{kvh} sk{sk}", out.view(b, s, d), want, fmt.tol(5e-3))
 
 
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
 @pytest.mark.parametrize("variant", [0] + GEMM_VARIANTS)
-def test_qkv_rope(dev, variant, s, s_pad):
+def test_qkv_rope(dev, variant, s, s_pad, fmt):
     from oracle import dit as odit
     _hip, lib = _lib()
     b, d = 2, 256
     _skip_tile(variant, 3 * d, d)
     h = d // 64
-    a = _rand((b * s, d), 15).to(torch.bfloat16)
-    w = (_rand((3 * d, d), 16) * 0.1).to(torch.bfloat16)
+    a = _rand((b * s, d), 15).to(fmt.dtype)
+    w = (_rand((3 * d, d), 16) * 0.1).to(fmt.dtype)
     inv_freq = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
     qkv = (a.float() @ w.float().T).view(b, s, 3 * d)
     q, k, v = (odit._heads(t, h) for t in qkv.chunk(3, dim=-1))
     freqs = odit.rotary_freqs(inv_freq, s)
     q, k = odit.apply_rotary(q, freqs), odit.apply_rotary(k, freqs)
     ad, wd, fd = a.to(dev), w.to(dev), inv_freq.to(dev)
-    qd = torch.full((b, h, s_pad, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    qd = torch.full((b, h, s_pad, 64), float("nan"), dtype=fmt.dtype, device=dev)
     kd = torch.full_like(qd, float("nan"))
-    vtd = torch.full((b, h, 64, s_pad), float("nan"), dtype=torch.bfloat16, device=dev)
+    vtd = torch.full((b, h, 64, s_pad), float("nan"), dtype=fmt.dtype, device=dev)
     scratch = torch.empty((2 * s * 16,), dtype=torch.float32, device=dev)
-    _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd),
-                                     _hip.ptr(scratch), b, s, s_pad, d, variant, _hip.stream()))
-    assert_close("rope q", qd[:, :, :s], q, 4e-3)
+    _hip.check(fmt.fn(lib, "sat_qkv_rope_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd),
+                                                _hip.ptr(scratch), b, s, s_pad, d, variant, _hip.stream()))
+    assert_close("rope q", qd[:, :, :s], q, fmt.tol(4e-3))
     vtd = vtd[..., _vt_perm(s_pad).to(vtd.device)]      # undo the key permutation of the V^T layout
     for i in range(b):     # key-side tensors of sequence i start at row/column (i*s) & 3
         ob = (i * s) & 3
-        assert_close("rope k", kd[i, :, ob:ob + s], k[i], 4e-3)
-        assert_close("v^T", vtd[i, :, :, ob:ob + s], v[i].transpose(1, 2), 4e-3)
+        assert_close("rope k", kd[i, :, ob:ob + s], k[i], fmt.tol(4e-3))
+        assert_close("v^T", vtd[i, :, :, ob:ob + s], v[i].transpose(1, 2), fmt.tol(4e-3))
         assert (kd[i, :, :ob] == 0).all() and (kd[i, :, ob + s:] == 0).all(), "K pads must be zero"
         assert (vtd[i, :, :, :ob] == 0).all() and (vtd[i, :, :, ob + s:] == 0).all(), "V^T pads must be zero"
     assert (qd[:, :, s:] == 0).all(), "Q pads must be zero"
 
 
-def _ln_fold_producer(dev, m, d, k, variant, seed=40):
-    """x0 + a w^T + bias through the producer entry; returns (c fp32, xb bf16, ln_part) on the device after checking them."""
+def _ln_fold_producer(dev, m, d, k, variant, seed=40, fmt=FORMATS[0], x_scale=2.0):
+    """x0 + a w^T + bias through the producer entry; returns (c fp32, xb bf16 / fp16, ln_part) on the device after checking them."""
     _hip, lib = _lib()
-    a = _rand((m, k), seed).to(torch.bfloat16)
-    w = (_rand((d, k), seed + 1) * 0.05 + torch.linspace(-0.02, 0.03, d)[:, None]).to(torch.bfloat16)
+    a = _rand((m, k), seed).to(fmt.dtype)
+    w = (_rand((d, k), seed + 1) * 0.05 + torch.linspace(-0.02, 0.03, d)[:, None]).to(fmt.dtype)
     bias = _rand((d,), seed + 2)
-    x0 = _rand((m, d), seed + 3, 2.0) + 0.3           # rows with a mean: the fold has to subtract it
+    x0 = _rand((m, d), seed + 3, x_scale) + 0.3       # rows with a mean: the fold has to subtract it
     want = a.float() @ w.float().T + bias + x0
     ad, wd, bd, cd = a.to(dev), w.to(dev), bias.to(dev), x0.to(dev)
-    xb = torch.full((m, d), float("nan"), dtype=torch.bfloat16, device=dev)
+    xb = torch.full((m, d), float("nan"), dtype=fmt.dtype, device=dev)
     part = torch.full((m, d // 64, 2), float("nan"), dtype=torch.float32, device=dev)
-    _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), _hip.ptr(xb), _hip.ptr(part), m, d, k,
-                                          variant, _hip.stream()))
+    _hip.check(fmt.fn(lib, "sat_gemm_resid_ln_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), _hip.ptr(xb), _hip.ptr(part), m, d, k,
+                                                     variant, _hip.stream()))
     assert_close(f"ln-fold producer v{variant}", cd, want, 1e-3)
-    assert torch.equal(xb, cd.to(torch.bfloat16)), "xb must be the bf16 rounding of the fp32 rows just written"
+    assert torch.equal(xb, cd.clamp(-65504.0, 65504.0).to(fmt.dtype)), "xb must be the 16-bit rounding (fp16: saturating) of the fp32 rows just written"
     blocks = xb.float().view(m, d // 64, 64).double()
     assert_close("ln-fold partial sums", part[..., 0], blocks.sum(-1), 1e-5)
     assert_close("ln-fold partial squares", part[..., 1], (blocks * blocks).sum(-1), 1e-5)
     return cd, xb, part
 
 
-def _ln_fold_reference(xb, w, gamma, beta, bias):
+def _ln_fold_reference(xb, w, gamma, beta, bias, fmt=FORMATS[0]):
     """What the consumer computes, in fp64 on the same rounded operands: rstd (xb (gamma.w)^T - mean c1) + c2."""
     x = xb.double().cpu()
     mean = x.mean(-1, keepdim=True)
     var = (x * x).mean(-1, keepdim=True) - mean * mean
     rstd = 1.0 / torch.sqrt(var + 1e-5)
-    wp = bf16_round(gamma * w).double()
+    wp = fmt.round(gamma * w).double()
     c2 = (w.double() * beta.double()).sum(-1) + (bias.double() if bias is not None else 0.0)
     return (rstd * (x @ wp.T - mean * wp.sum(-1)) + c2).float()
 
 
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("m", [300, 770])
 @pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (0, 0), (80, 80), (15, 80), (80, 30), (80 | 0x10000, 80 | 0x10000)])
-def test_ln_fold_swiglu(dev, prod, cons, m):
+def test_ln_fold_swiglu(dev, prod, cons, m, fmt):
     """LayerNorm folded into FF-in (sat_dit_cfg.ln_fold): producer epilogue -> bf16 rows + partial sums -> SwiGLU GEMM that finishes
     the normalisation.  Gates: 4e-3 against the same arithmetic in fp64 (one bf16 rounding of the output), 1e-2 against the plain fp32
     LayerNorm -> Linear -> SwiGLU of the reference (transformer.py:700, 222, 232-235; adds the bf16 rounding of the operands)."""
     _hip, lib = _lib()
     d, inner = 768, 768
-    cd, xb, part = _ln_fold_producer(dev, m, d, 256, prod)
+    cd, xb, part = _ln_fold_producer(dev, m, d, 256, prod, fmt=fmt)
     w = _rand((2 * inner, d), 50) * 0.08
     gamma = 0.8 + 0.2 * _rand((d,), 51)
     beta = 0.1 * _rand((d,), 52)
     bias = 0.1 * _rand((2 * inner,), 53)
     wd, gd, bd, bbd = w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev)
-    wp = torch.empty((2 * inner, d), dtype=torch.bfloat16, device=dev)
+    wp = torch.empty((2 * inner, d), dtype=fmt.dtype, device=dev)
     c12 = torch.empty((4 * inner,), dtype=torch.float32, device=dev)
-    out = torch.full((m, inner), float("nan"), dtype=torch.bfloat16, device=dev)
-    _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(bbd), _hip.ptr(wp),
-                                           _hip.ptr(c12), _hip.ptr(out), m, 2 * inner, d, cons, _hip.stream()))
-    val, gate = _ln_fold_reference(xb, w, gamma, beta, bias).chunk(2, dim=-1)
-    assert_close("ln-fold swiglu vs same arithmetic", out, val * F.silu(gate), 4e-3)
+    out = torch.full((m, inner), float("nan"), dtype=fmt.dtype, device=dev)
+    _hip.check(fmt.fn(lib, "sat_gemm_swiglu_ln_bf16")(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(bbd),
+                                                      _hip.ptr(wp), _hip.ptr(c12), _hip.ptr(out), m, 2 * inner, d, cons, _hip.stream()))
+    val, gate = _ln_fold_reference(xb, w, gamma, beta, bias, fmt).chunk(2, dim=-1)
+    assert_close("ln-fold swiglu vs same arithmetic", out, val * F.silu(gate), fmt.tol(4e-3))
     val, gate = F.linear(F.layer_norm(cd.cpu(), (d,), gamma, beta, eps=1e-5), w, bias).chunk(2, dim=-1)
-    assert_close("ln-fold swiglu vs fp32 LayerNorm + Linear", out, val * F.silu(gate), 1e-2)
+    assert_close("ln-fold swiglu vs fp32 LayerNorm + Linear", out, val * F.silu(gate), fmt.tol(1e-2))
 
 
 @pytest.mark.parametrize("row_mean,outlier", [(0.0, 0.0), (8.0, 0.0), (30.0, 0.0), (0.0, 60.0)])
@@ -316,16 +413,17 @@ def test_ln_fold_rows_with_common_mode(dev, row_mean, outlier):
     assert e_f <= 1e-2 * max(1.0, ratio) * 2, f"fold: {e_f:.3e} exceeds 2 x 1e-2 x the predicted ratio {ratio:.1f}"
 
 
+@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
 @pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (0, 0), (80, 80), (16, 80), (80, 15), (80 | 0x10000, 80 | 0x10000)])
-def test_ln_fold_qkv_rope(dev, prod, cons, s, s_pad):
+def test_ln_fold_qkv_rope(dev, prod, cons, s, s_pad, fmt):
     """LayerNorm folded into to_qkv + RoPE + head split (transformer.py:692, 314, 430-452): q / k through the transposed epilogue,
     V^T through the un-swapped one -- both have to apply the per-row statistics."""
     from oracle import dit as odit
     _hip, lib = _lib()
     b, d = 2, 768
     h = d // 64
-    cd, xb, part = _ln_fold_producer(dev, b * s, d, 256, prod, seed=60)
+    cd, xb, part = _ln_fold_producer(dev, b * s, d, 256, prod, seed=60, fmt=fmt)
     w = _rand((3 * d, d), 70) * 0.06
     gamma = 0.8 + 0.2 * _rand((d,), 71)
     beta = 0.1 * _rand((d,), 72)
@@ -336,20 +434,20 @@ def test_ln_fold_qkv_rope(dev, prod, cons, s, s_pad):
         q, k, v = (odit._heads(t, h) for t in qkv.view(b, s, 3 * d).chunk(3, dim=-1))
         return odit.apply_rotary(q, freqs), odit.apply_rotary(k, freqs), v
 
-    same = split(_ln_fold_reference(xb, w, gamma, beta, None))
+    same = split(_ln_fold_reference(xb, w, gamma, beta, None, fmt))
     plain = split(F.linear(F.layer_norm(cd.cpu(), (d,), gamma, beta, eps=1e-5), w))
     wd, gd, bd, fd = w.to(dev), gamma.to(dev), beta.to(dev), inv_freq.to(dev)
-    wp = torch.empty((3 * d, d), dtype=torch.bfloat16, device=dev)
+    wp = torch.empty((3 * d, d), dtype=fmt.dtype, device=dev)
     c12 = torch.empty((6 * d,), dtype=torch.float32, device=dev)
-    qd = torch.full((b, h, s_pad, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    qd = torch.full((b, h, s_pad, 64), float("nan"), dtype=fmt.dtype, device=dev)
     kd = torch.full_like(qd, float("nan"))
-    vtd = torch.full((b, h, 64, s_pad), float("nan"), dtype=torch.bfloat16, device=dev)
+    vtd = torch.full((b, h, 64, s_pad), float("nan"), dtype=fmt.dtype, device=dev)
     scratch = torch.empty((2 * s * 16,), dtype=torch.float32, device=dev)
-    _hip.check(lib.sat_qkv_rope_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(wp), _hip.ptr(c12),
-                                        _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(scratch), b, s, s_pad, d, cons,
-                                        _hip.stream()))
+    _hip.check(fmt.fn(lib, "sat_qkv_rope_ln_bf16")(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(wp),
+                                                   _hip.ptr(c12), _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd), _hip.ptr(scratch),
+                                                   b, s, s_pad, d, cons, _hip.stream()))
     vtd = vtd[..., _vt_perm(s_pad).to(vtd.device)]
-    for (q, k, v), tol in ((same, 4e-3), (plain, 1e-2)):
+    for (q, k, v), tol in ((same, fmt.tol(4e-3)), (plain, fmt.tol(1e-2))):
         assert_close("ln-fold q", qd[:, :, :s], q, tol)
         for i in range(b):
             ob = (i * s) & 3

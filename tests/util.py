@@ -21,3 +21,32 @@ def assert_close(name, got, want, tol):
     assert torch.isfinite(got.float()).all(), f"{name}: non-finite values in the HIP result"
     assert err <= tol, f"{name}: rel-L2 {err:.3e} > tol {tol:.1e} (max abs {max_abs(got, want):.3e})"
     return err
+
+
+def fp16_round(x):
+    return x.clamp(-65504.0, 65504.0).to(torch.float16).to(torch.float32)
+
+
+class OperandFormat:
+    """The two 16-bit operand formats of the matrix kernels (sat_dit_cfg.gemm_dtype 0 / 3): torch dtype, the rounding the kernels
+    apply at their store points, the C-ABI name mapping (sat_*_bf16* -> sat_*_f16*), and the share of a bf16 tolerance that the
+    format's unit roundoff leaves (bf16 2^-9, fp16 2^-12: gates for fp16 are the bf16 gates / 4, a 2x margin on the 8x)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.f16 = name == "f16"
+        self.dtype = torch.float16 if self.f16 else torch.bfloat16
+        self.round = fp16_round if self.f16 else bf16_round
+        self.tol_scale = 0.25 if self.f16 else 1.0
+
+    def fn(self, lib, name):
+        return getattr(lib, name.replace("bf16", "f16") if self.f16 else name)
+
+    def tol(self, bf16_tol):
+        return bf16_tol * self.tol_scale
+
+    def __repr__(self):
+        return self.name
+
+
+FORMATS = [OperandFormat("bf16"), OperandFormat("f16")]
