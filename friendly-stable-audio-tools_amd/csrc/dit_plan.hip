@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <set>
@@ -47,6 +48,24 @@ int sat_ensure_dynamic_lds(const void* kernel, int bytes) {
     }
     if (n_seen < 64) seen[n_seen++] = Seen{kernel, dev};
     return 0;
+}
+// compute units of the current device: one attribute query per device and process (no allocation, no synchronisation); 0 on failure
+int sat_device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        sat_set_error("hipGetDevice failed");
+        return 0;
+    }
+    int c = (dev >= 0 && dev < 64) ? cache[dev].load(std::memory_order_relaxed) : 0;
+    if (!c) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) {
+            sat_set_error("hipDeviceGetAttribute(MultiprocessorCount) failed");
+            return 0;
+        }
+        if (dev >= 0 && dev < 64) cache[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
 }
 extern "C" int sat_version(void) { return 4; }
 
@@ -279,6 +298,8 @@ struct Workspace {
     float *gsum, *ssg;      // adaLN: silu(global + timestep embed) [bf, D]; per-layer modulation [bf, depth, 6, D]
     float* ln_part = nullptr;    // ln_fold: [M][D / 64][2] partial (sum, sum of squares) of the bf16 image of X kept in A
     float* f32_wide = nullptr;   // fp32 verification mode: [M, max(3D, 2 inner)] GEMM output before the head split / SwiGLU
+    float* slab = nullptr;       // K-split scratch of the 8-phase FF-out GEMM (GemmArgs::slab), present where that schedule splits
+    size_t slab_bytes = 0;
     size_t qkv_bytes;
     size_t total;
 };
@@ -332,6 +353,10 @@ Workspace carve(const sat_dit_plan* p, int bf, int T, char* base) {
     w.gsum = c.adaln ? (float*)take((size_t)bf * D * 4) : nullptr;
     w.ssg = c.adaln ? (float*)take((size_t)bf * c.depth * 6 * D * 4) : nullptr;
     w.ln_part = p->ln_fold ? (float*)take(M * (size_t)(D / 64) * 2 * 4) : nullptr;
+    // FF-out (K = inner) is the one fp32-output GEMM with a reduction long enough for the 8-phase kernel's K-split of the remainder
+    // round (SA-2.0 shape): its slabs live here, per workspace = per caller and stream
+    w.slab_bytes = (c.gemm_dtype == 0 || c.gemm_dtype == 3) ? sat_gemm_ph8_slab_bytes(EPI_RESID, (int)M, D, p->inner) : 0;
+    w.slab = w.slab_bytes ? (float*)take(w.slab_bytes) : nullptr;
     w.total = off;
     return w;
 }
@@ -497,6 +522,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.Hs; g.w_scale = L.s_ff2; }
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
+        g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         if (l + 1 < c.depth) fold_out(g);       // nobody normalises the output of the last block
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
     }
@@ -768,21 +794,38 @@ extern "C" int sat_cast_f16(const float* x, void* y, int64_t n, sat_stream_t str
 }
 
 static int gemm_bf16_f32_impl(int f16, const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
-                                 int32_t accumulate, int32_t variant, sat_stream_t stream) {
+                              int32_t accumulate, int32_t variant, void* ws, size_t ws_bytes, sat_stream_t stream) {
     SAT_CHECK_ARG(c, SAT_E_INVALID, "gemm: null output");
     GemmArgs g{};
     g.f16 = f16;
     g.A = (const op_t*)a; g.W = (const op_t*)w; g.bias = bias; g.M = m; g.N = n; g.K = k;
     g.C = c; g.ldc = n; g.accumulate = accumulate; g.variant = variant;
+    g.slab = (float*)ws; g.slab_bytes = ws ? ws_bytes : 0;
     return sat_launch_gemm(EPI_F32, g, (hipStream_t)stream);
 }
 extern "C" int sat_gemm_bf16_f32(const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
                                  int32_t accumulate, int32_t variant, sat_stream_t stream) {
-    return gemm_bf16_f32_impl(0, a, w, bias, c, m, n, k, accumulate, variant, stream);
+    return gemm_bf16_f32_impl(0, a, w, bias, c, m, n, k, accumulate, variant, nullptr, 0, stream);
 }
 extern "C" int sat_gemm_f16_f32(const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
-                                 int32_t accumulate, int32_t variant, sat_stream_t stream) {
-    return gemm_bf16_f32_impl(1, a, w, bias, c, m, n, k, accumulate, variant, stream);
+                                int32_t accumulate, int32_t variant, sat_stream_t stream) {
+    return gemm_bf16_f32_impl(1, a, w, bias, c, m, n, k, accumulate, variant, nullptr, 0, stream);
+}
+extern "C" int sat_gemm_bf16_f32_ws(const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
+                                    int32_t accumulate, int32_t variant, void* ws, size_t ws_bytes, sat_stream_t stream) {
+    return gemm_bf16_f32_impl(0, a, w, bias, c, m, n, k, accumulate, variant, ws, ws_bytes, stream);
+}
+extern "C" int sat_gemm_f16_f32_ws(const void* a, const void* w, const float* bias, float* c, int32_t m, int32_t n, int32_t k,
+                                   int32_t accumulate, int32_t variant, void* ws, size_t ws_bytes, sat_stream_t stream) {
+    return gemm_bf16_f32_impl(1, a, w, bias, c, m, n, k, accumulate, variant, ws, ws_bytes, stream);
+}
+extern "C" int sat_gemm_f32_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t variant, size_t* out_bytes) {
+    SAT_CHECK_ARG(out_bytes && m > 0 && n > 0 && k > 0, SAT_E_INVALID, "gemm_f32_workspace_bytes: bad argument");
+    const int cus = sat_device_cus();
+    SAT_CHECK_ARG(cus > 0, SAT_E_INVALID, "gemm_f32_workspace_bytes: no device");
+    // forced K-split (variant bit 16, tests / measurements): one slab per workgroup; otherwise what the automatic schedule would use
+    *out_bytes = (variant & 0x10000) ? (size_t)cus * 65536 * sizeof(float) : sat_gemm_ph8_slab_bytes(EPI_F32, m, n, k);
+    return 0;
 }
 
 static int gemm_swiglu_bf16_impl(int f16, const void* a, const float* w_f32, const float* bias_f32, void* wpack, float* bpack,
@@ -894,21 +937,30 @@ extern "C" int sat_qkv_rope_f16(const void* a, const void* w, const float* inv_f
 
 // ---- LayerNorm folded into the neighbouring GEMMs (sat_dit_cfg.ln_fold), one entry per role
 static int gemm_resid_ln_bf16_impl(int f16, const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
-                                      int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
+                                   int32_t n, int32_t k, int32_t variant, void* ws, size_t ws_bytes, sat_stream_t stream) {
     SAT_CHECK_ARG(c && xb && ln_part, SAT_E_INVALID, "gemm_resid_ln: null output");
     GemmArgs g{};
     g.f16 = f16;
     g.A = (const op_t*)a; g.W = (const op_t*)w; g.bias = bias; g.M = m; g.N = n; g.K = k;
     g.C = c; g.ldc = n; g.accumulate = 1; g.variant = variant; g.xb = (op_t*)xb; g.ln_part_out = ln_part;
+    g.slab = (float*)ws; g.slab_bytes = ws ? ws_bytes : 0;
     return sat_launch_gemm(EPI_RESID, g, (hipStream_t)stream);
 }
 extern "C" int sat_gemm_resid_ln_bf16(const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
                                       int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
-    return gemm_resid_ln_bf16_impl(0, a, w, bias, c, xb, ln_part, m, n, k, variant, stream);
+    return gemm_resid_ln_bf16_impl(0, a, w, bias, c, xb, ln_part, m, n, k, variant, nullptr, 0, stream);
 }
 extern "C" int sat_gemm_resid_ln_f16(const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
-                                      int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
-    return gemm_resid_ln_bf16_impl(1, a, w, bias, c, xb, ln_part, m, n, k, variant, stream);
+                                     int32_t n, int32_t k, int32_t variant, sat_stream_t stream) {
+    return gemm_resid_ln_bf16_impl(1, a, w, bias, c, xb, ln_part, m, n, k, variant, nullptr, 0, stream);
+}
+extern "C" int sat_gemm_resid_ln_bf16_ws(const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
+                                         int32_t n, int32_t k, int32_t variant, void* ws, size_t ws_bytes, sat_stream_t stream) {
+    return gemm_resid_ln_bf16_impl(0, a, w, bias, c, xb, ln_part, m, n, k, variant, ws, ws_bytes, stream);
+}
+extern "C" int sat_gemm_resid_ln_f16_ws(const void* a, const void* w, const float* bias, float* c, void* xb, float* ln_part, int32_t m,
+                                        int32_t n, int32_t k, int32_t variant, void* ws, size_t ws_bytes, sat_stream_t stream) {
+    return gemm_resid_ln_bf16_impl(1, a, w, bias, c, xb, ln_part, m, n, k, variant, ws, ws_bytes, stream);
 }
 
 static int gemm_swiglu_ln_bf16_impl(int f16, const void* xb, const float* ln_part, const float* w_f32, const float* gamma, const float* beta,

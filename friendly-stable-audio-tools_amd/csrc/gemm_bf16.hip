@@ -16,6 +16,8 @@
 #include <type_traits>
 
 #include "attn_core.h"
+#include <algorithm>
+
 #include "sat_common.h"
 
 namespace {
@@ -1380,11 +1382,12 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);
         }
     }
-    // fill of the last round of 256 CUs x measured in-kernel rate of the tile, relative to the 256x256 tile
+    // fill of the last round of the device's CUs (256 on MI355X) x measured in-kernel rate of the tile, relative to the 256x256 tile
+    const long cus = std::max(1, sat_device_cus());
     auto score = [&](int bm, int bn, double rate) {
         if (a.N % bn) return 0.0;
         long t = (long)cdiv(a.M, bm) * (a.N / bn);
-        return rate * (double)t / (double)(((t + 255) / 256) * 256);
+        return rate * (double)t / (double)(((t + cus - 1) / cus) * cus);
     };
     if (a.fp8) {
         if (v == 0) {
@@ -1434,8 +1437,8 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             if (sat_g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) {
                 const double rate = EPI == EPI_SWIGLU ? 1.26 : EPI == EPI_HEADS ? 1.07 : 1.02;
                 const long t = (long)cdiv(a.M, 256) * (a.N / 256);
-                const double rounds = sat_gemm_ph8_splits(EPI, a) ? (double)(t / 256) + 0.35 : (double)((t + 255) / 256);
-                s256 = rate * (double)t / (rounds * 256.0);
+                const double rounds = sat_gemm_ph8_splits(EPI, a) ? (double)(t / cus) + 0.35 : (double)((t + cus - 1) / cus);
+                s256 = rate * (double)t / (rounds * (double)cus);
             }
             const double s192 = score(256, 192, 0.95), s128 = score(128, 128, 0.7), s64 = score(128, 64, 0.6);
             const double best = s256 > s192 ? (s256 > s128 ? s256 : s128) : (s192 > s128 ? s192 : s128);

@@ -27,29 +27,31 @@
 //   (profiles/r03_ph8_two_phases.txt).  It is kept as `main_loop` for A/B, variant bit 18, experiments build.)
 //   Measured in the loop: 1.36 us per K-tile on 256 CUs = 1575 TFLOP/s (profiles/r03_ph8_ksweep_fixed_overhead.txt).
 //
-// Schedule (PERSISTENT workgroups, one per CU; Ph8Sched, built on the host).  With one 136-KiB workgroup per CU nothing overlaps a
-// tile's prologue and epilogue, and a launch of T tiles costs ceil(T / 256) rounds: measured 8-10 us of a 42-52 us tile
+// Schedule (PERSISTENT workgroups, one per CU; Ph8Sched).  With one 136-KiB workgroup per CU nothing overlaps a tile's prologue and
+// epilogue, and a launch of T tiles costs ceil(T / 256) rounds: measured 8-10 us of a 42-52 us tile
 // (profiles/r03_ph8_workgroup_timeline.txt) and, at one prompt, 2 rounds for 1.5 rounds of work.  So:
 //   * workgroup i walks `dp_rounds` whole tiles (logical tile s G + i in round s: the same neighbourhood per round as hardware
-//     dispatch order, XCD-aware), then its share of the REMAINDER round, which is split along K ("stream-K" for the last round only):
-//     the remaining tiles' K-pair units (128 k) are dealt to the G workgroups in contiguous, cost-balanced ranges (row tiles with
-//     <= 64 valid rows -- the 2 leftover rows of M = 2 x 1025 -- count 0.4);
-//   * a K-range that is not a whole tile ends in a fix-up: every contributor writes its raw accumulators to its own slab
-//     (lane-for-lane the register image, 1-KiB coalesced pieces), agent-scope release + ticket; the LAST arriver acquires, adds the
-//     slabs in ascending workgroup order (bit-deterministic whoever is last; two contributors: own registers + the other slab,
-//     fp32 addition commutes) and runs the normal epilogue.  Nobody waits for anybody;
+//     dispatch order, XCD-aware), then its share of the REMAINDER round: whole tiles (contiguous shares), or -- fp32 output with a long
+//     reduction behind a whole round, sat_gemm_ph8_splits -- ONE K-range of a remainder tile: every remainder tile is cut along K into
+//     equal parts, one workgroup per part, parts in proportion to cost (row tiles with <= 64 valid rows -- the 2 leftover rows of
+//     M = 2 x 1025 -- count half);
+//   * a partial K-range stores its raw accumulators to the workgroup's slab (lane-for-lane the register image, 1-KiB coalesced
+//     pieces); a second launch (ph8_reduce_f32_kernel) adds a tile's slabs in ascending workgroup order -- bit-deterministic -- and
+//     runs the fp32 / residual / LayerNorm-producer epilogue on the sums.  The slabs live in the CALLER's workspace (GemmArgs::slab):
+//     nothing here allocates, synchronises or keeps state between launches, so plans on different streams are independent and a
+//     forward can be captured into a hipGraph.  (Round 3 also built the in-kernel last-arriver fix-up with arrival tickets, and
+//     contiguous stream-K shares: both measured slower than this -- profiles/r03_ph8_streamk_timeline.txt,
+//     r03_ph8_ffout_streamk_negative.txt -- and are gone from the source.)
+//   * the whole schedule is a handful of integers computed on the host per launch in closed form and passed by value: no device
+//     tables, no cache, no lock;
 //   * the LDS-DMA prologue of the next K-range (7 half-tiles) is issued BEFORE the epilogue of the current one -- the ring is
 //     free after the last barrier of the main loop and the DMA needs no registers -- so its latency hides behind the epilogue.
 //
 // Epilogues run on TRANSPOSED accumulators (W fragment = MFMA A operand): lane l owns token row (l & 15) of a 16 x 16 block and
 // four consecutive output channels; which channels a wave's W rows are is a free permutation applied where the DMA picks its
 // source rows (chan_of), chosen per epilogue so that stores are 16 bytes and SwiGLU / RoPE partners are lane-local.
-#include <atomic>
-#include <map>
-#include <mutex>
-#include <tuple>
+#include <algorithm>
 #include <type_traits>
-#include <vector>
 
 #include "sat_common.h"
 
@@ -80,7 +82,7 @@ __device__ __forceinline__ int chan_of(int ni, int nf, int i) {
     else return ni == 0 ? nf * 16 + i : 32 + q * 8 + nf * 4 + r;
 }
 
-struct Ph8Sched {
+struct Ph8Sched {          // host-computed per launch (ph8_schedule), passed by value
     int G;                  // workgroups (== gridDim.x)
     int tiles_n;
     int tiles_m_full;       // row tiles of the "full" logical tile space
@@ -89,21 +91,55 @@ struct Ph8Sched {
     int dp_rounds;          // whole tiles per workgroup
     int nkp;                // K-pair units (128 k) per tile
     int sk_tiles;           // tiles of the remainder space (the full tiles left over by the whole rounds, and the light tiles)
-    const int* sk_tile;     // [sk_tiles] position in the work order
-    const int* sk_begin;    // [G + 1] first unit of workgroup i in that space
-    const int* sk_first;    // [sk_tiles] first contributing workgroup
-    const int* sk_parts;    // [sk_tiles] number of contributing workgroups
-    unsigned* sk_count;     // [sk_tiles] arrival tickets, zero between launches
-    float* sk_slab;         // [G][2][65536] raw accumulator images
-    int any_split;          // some remainder tile has more than one contributor
-    int dump;               // 1: a partial K-range only stores its accumulators; ph8_reduce_f32_kernel adds them up and finishes the tile
+    int rem0;               // work-order position of the first remainder tile (remainder tile j = position rem0 + j)
+    int split;              // 0: remainder tiles stay whole; 1: every remainder tile is cut along K, one workgroup per part
+    int sk_q, sk_r;         // split 0: workgroup i takes sk_q (+ 1 if i < sk_r) consecutive remainder tiles
+    int cls_n[3], cls_p[3]; // split 1: three consecutive classes of remainder tiles, cls_n[c] tiles of cls_p[c] parts each
+    float* sk_slab;         // split 1: [G][65536] raw accumulator images (caller's workspace)
 };
+
+// units [b, e) of the remainder space (unit = 128 k of one tile, tile j = units [j nkp, (j + 1) nkp)) that workgroup i works on
+__host__ __device__ __forceinline__ void ph8_wg_units(const Ph8Sched& sc, int i, int& b, int& e) {
+    if (!sc.split) {
+        const int lo = i < sc.sk_r ? i : sc.sk_r, hi = i + 1 < sc.sk_r ? i + 1 : sc.sk_r;
+        b = (i * sc.sk_q + lo) * sc.nkp;
+        e = ((i + 1) * sc.sk_q + hi) * sc.nkp;
+        return;
+    }
+    int w0 = 0, j0 = 0;
+    b = e = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int n = sc.cls_n[c], p = sc.cls_p[c];
+        if (i >= w0 && i < w0 + n * p) {
+            const int j = j0 + (i - w0) / p, k = (i - w0) % p;
+            b = j * sc.nkp + sc.nkp * k / p;
+            e = j * sc.nkp + sc.nkp * (k + 1) / p;
+        }
+        w0 += n * p;
+        j0 += n;
+    }
+}
+// split 1: the workgroups first .. first + parts - 1 that hold remainder tile j's K-ranges
+__host__ __device__ __forceinline__ void ph8_tile_parts(const Ph8Sched& sc, int j, int& first, int& parts) {
+    int w0 = 0, j0 = 0;
+    first = 0;
+    parts = 1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int n = sc.cls_n[c], p = sc.cls_p[c];
+        if (j >= j0 && j < j0 + n) {
+            first = w0 + (j - j0) * p;
+            parts = p;
+        }
+        w0 += n * p;
+        j0 += n;
+    }
+}
 
 struct Seg {                // one K-range of one tile
     int m0, n0;
     int kt0, nk;            // first K-tile, K-tiles (even)
-    int skj;                // stream-K tile index (ticket / contributor tables)
-    int slot;               // slab of this workgroup that takes the partial: 0 = its first stream-K range, 1 = a later one
     bool whole;             // the K-range covers the tile: plain epilogue
     bool tr;                // accumulator orientation (transposed unless a V^T destination)
 };
@@ -225,23 +261,22 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     // ---- the walk over this workgroup's K-ranges
     auto tile_of = [&](int id, int& tm, int& tn) { ph8_tile_of(sc, id, tm, tn); };
     int dp_s = 0;
-    const int sk_b = sc.sk_tiles ? sc.sk_begin[wgi] : 0;
-    const int sk_e = sc.sk_tiles ? sc.sk_begin[wgi + 1] : 0;
+    int sk_b = 0, sk_e = 0;
+    if (sc.sk_tiles) ph8_wg_units(sc, wgi, sk_b, sk_e);
     int sk_u = sk_b;
     auto next_seg = [&](Seg& s) -> bool {
         int tm, tn;
         if (dp_s < sc.dp_rounds) {
             tile_of(dp_s * sc.G + wgi, tm, tn);
             ++dp_s;
-            s.kt0 = 0; s.nk = 2 * sc.nkp; s.whole = true; s.skj = 0; s.slot = 0;
+            s.kt0 = 0; s.nk = 2 * sc.nkp; s.whole = true;
         } else {
             if (sk_u >= sk_e) return false;
             const int j = sk_u / sc.nkp;
             const int ub = sk_u - j * sc.nkp;
             const int ue = min(sc.nkp, ub + (sk_e - sk_u));
-            tile_of(sc.sk_tile[j], tm, tn);
-            s.kt0 = 2 * ub; s.nk = 2 * (ue - ub); s.whole = (ub == 0 && ue == sc.nkp); s.skj = j;
-            s.slot = (sk_u == sk_b) ? 0 : 1;
+            tile_of(sc.rem0 + j, tm, tn);
+            s.kt0 = 2 * ub; s.nk = 2 * (ue - ub); s.whole = (ub == 0 && ue == sc.nkp);
             sk_u += ue - ub;
         }
         s.m0 = tm * BM; s.n0 = tn * BN;
@@ -811,66 +846,6 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         }
     };
 
-    // ---- stream-K fix-up of a partial K-range.  Returns true when this workgroup is the last arriver: `acc` then holds the whole sum.
-    // Inter-workgroup visibility without cache-wide fences (an agent-scope release / acquire writes back and invalidates a whole
-    // XCD's L2 under every other workgroup's feet: measured 2x slower kernels): slabs are written with sc1 (write-through) stores
-    // and read with sc1 loads, the ticket is a relaxed agent-scope atomic issued after every wave's stores have been acknowledged.
-    unsigned* misc = reinterpret_cast<unsigned*>(smem + RING_BYTES + 2 * LN_BYTES);
-    auto fixup = [&](const Seg& s) -> bool {
-        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-        int lane_l = lane;
-        asm volatile("" : "+v"(lane_l));
-        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)sc.sk_slab, 0, sc.G * 2 * (BM * BN * 4), 0x00020000);
-        auto slab_off = [&](int w, int slot) { return (w * 2 + slot) * (BM * BN * 4) + wave * (MB * 4096) + lane_l * 16; };       // bytes
-        const int parts = sc.sk_parts[s.skj];
-        const int first = sc.sk_first[s.skj];
-        const int mine = slab_off(wgi, s.slot);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[mb][nb]), rsS, mine + (mb * 4 + nb) * 1024, 0, 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid_ == 0) misc[0] = __hip_atomic_fetch_add(sc.sk_count + s.skj, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const unsigned ticket = misc[0];
-        if ((int)ticket != parts - 1) return false;
-        if (tid_ == 0) __hip_atomic_store(sc.sk_count + s.skj, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // every ticket of this launch is drawn
-        const int tile_u0 = s.skj * sc.nkp;
-        // (two batches of 16 pieces with a scheduling fence between them: the whole image at once would need 128 registers on top of
-        // the 128 accumulators, and the allocator would answer by spilling accumulators -- inside the main loop as well)
-        auto add_slab = [&](int off) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                u32x4_t t[MB * 2];
-#pragma unroll
-                for (int i = 0; i < MB * 2; ++i) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rsS, off + (h * MB * 2 + i) * 1024, 0, 16);
-#pragma unroll
-                for (int i = 0; i < MB * 2; ++i) acc[h * (MB / 2) + (i >> 2)][i & 3] += __builtin_bit_cast(f32x4_t, t[i]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        // Two contributors: own registers + the other slab (fp32 addition commutes: the same bits whoever is last).  More: all slabs in
-        // ascending workgroup order, own included, on zeroed registers.  ONE code path for both (the registers are scaled by 1 or 0):
-        // two paths that redefine the 128 accumulators differently cost 100+ spilled registers, inside the main loop as well.
-        const bool two = parts == 2;
-        const float keep = two ? 1.0f : 0.0f;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] *= keep;
-        int seen = 0;
-        for (int w = first; seen < parts; ++w) {
-            const int wb = sc.sk_begin[w];
-            if (sc.sk_begin[w + 1] <= wb) continue;          // a workgroup whose share of the (cost-weighted) unit space is empty
-            ++seen;
-            if (two && w == wgi) continue;
-            add_slab(slab_off(w, wb >= tile_u0 ? 0 : 1));
-        }
-        return true;
-    };
-
     // ---- the persistent loop
     Seg cur, nxt;
     if (!next_seg(cur)) return;
@@ -908,17 +883,13 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         const bool more = next_seg(nxt);
         if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
         bool fin = true;
-        if (!cur.whole) {
-            if (sc.dump) {          // two-launch split (fp32 output): plain stores, the kernel boundary publishes them
-                float* mine = sc.sk_slab + ((size_t)wgi * 2 + cur.slot) * (BM * BN) + (size_t)(wave * MB * 4) * 256 + lane * 4;
+        if (!cur.whole) {           // a part of a K-split tile (fp32 output): plain stores of the raw accumulators, the kernel boundary publishes
+            float* mine = sc.sk_slab + (size_t)wgi * (BM * BN) + (size_t)(wave * MB * 4) * 256 + lane * 4;       // them to ph8_reduce_f32_kernel
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4_t*>(mine + (mb * 4 + nb) * 256) = acc[mb][nb];
-                fin = false;
-            } else {
-                fin = fixup(cur);
-            }
+                for (int nb = 0; nb < 4; ++nb) *reinterpret_cast<f32x4_t*>(mine + (mb * 4 + nb) * 256) = acc[mb][nb];
+            fin = false;
         }
         if constexpr (DBG == 9) t2 = __builtin_amdgcn_s_memrealtime();
         if (fin && rows_valid) epilogue(cur, lb);
@@ -942,23 +913,19 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sched sc) {
     sat_f16_saturate();
     const int j = blockIdx.x >> 3, mb = blockIdx.x & 7;
-    const int parts = sc.sk_parts[j];
+    int first, parts;
+    ph8_tile_parts(sc, j, first, parts);
     if (parts <= 1) return;                          // a whole tile: finished by the GEMM launch itself
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, q4 = lane >> 4;
     int tm, tn;
-    ph8_tile_of(sc, sc.sk_tile[j], tm, tn);
+    ph8_tile_of(sc, sc.rem0 + j, tm, tn);
     const int m = (tm << 8) + wr * 128 + mb * 16 + l15;
     const int ncol0 = (tn << 8) + wc * 64;
     if ((tm << 8) + wr * 128 >= g.M) return;
     f32x4_t v[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const int tile_u0 = j * sc.nkp;
-    int seen = 0;
-    for (int w = sc.sk_first[j]; seen < parts; ++w) {
-        const int wb = sc.sk_begin[w];
-        if (sc.sk_begin[w + 1] <= wb) continue;
-        ++seen;
-        const float* src = sc.sk_slab + ((size_t)w * 2 + (wb >= tile_u0 ? 0 : 1)) * 65536 + (size_t)(wave * 32 + mb * 4) * 256 + lane * 4;
+    for (int w = first; w < first + parts; ++w) {
+        const float* src = sc.sk_slab + (size_t)w * 65536 + (size_t)(wave * 32 + mb * 4) * 256 + lane * 4;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) v[nb] += *reinterpret_cast<const f32x4_t*>(src + nb * 256);
     }
@@ -972,50 +939,32 @@ __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sche
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// host side: the persistent schedule of a shape (cached per device and shape)
+// host side: the persistent schedule of a shape -- a few integers in closed form, rebuilt per launch (no state, no allocation)
 // ---------------------------------------------------------------------------------------------------------------------------------
-// the slab of a device may be re-allocated when a later shape needs a bigger one (ph8_schedule): the lock-free hit table of
-// launch_ph8 compares the pointer it cached with one relaxed read
-std::atomic<float*> g_slab_now[16];
-float* slab_of_device(int dev) { return dev < 16 ? g_slab_now[dev].load(std::memory_order_relaxed) : nullptr; }
-
-struct DevState {
-    int cus = 0;
-    float* slab = nullptr;
-    size_t slab_wgs = 0;
-    std::map<std::tuple<int, int, int, int, int>, Ph8Sched> shapes;          // (M, N, K, split, tile rows)
-};
-std::mutex g_sched_mu;
-std::map<int, DevState> g_dev;
+int ph8_cus(int& out) {
+    out = sat_device_cus();
+    return out > 0 ? 0 : SAT_E_INVALID;
+}
 
 // Measured policy (profiles/r03_ph8_streamk.txt): split only fp32-output GEMMs with a long reduction (K >= 4096: FF-out) behind at
 // least one whole round, and only when every remainder tile gets >= 2 parts (otherwise the whole tiles set the makespan and the slab
-// traffic -- 2 x 256 KiB per part at HBM speed, everybody at the same time -- is pure loss): SA-2.0 FF-out -25 %.  8 prompts (134
-// remainder tiles on 256 CUs) and every K = 1536 GEMM stay whole; below one whole round the 128 x 128 tiles of gemm_bf16.hip are
-// faster (FF-out at 1 prompt: 60 us against 67).
+// traffic -- 256 KiB per part written and read back at HBM speed, everybody at the same time -- is pure loss): SA-2.0 FF-out -25 %.
+// 8 prompts (134 remainder tiles on 256 CUs) and every K = 1536 GEMM stay whole; below one whole round the 128 x 128 tiles of
+// gemm_bf16.hip are faster (FF-out at 1 prompt: 60 us against 67).
 bool ph8_auto_split(const GemmArgs& a, bool epi_f32, int cus) {
     const long t_all = (long)cdiv(a.M, 256) * (a.N / 256);
     const long rem = t_all % cus;
     return epi_f32 && a.K >= 4096 && t_all > cus && rem > 0 && 2 * rem <= cus;
 }
 
-// split: 0 = the remainder round's tiles stay whole (one per workgroup, light tiles last), 1 = the remainder round is split along K,
-// -1 = the measured policy below
+// split: 0 = the remainder round's tiles stay whole (contiguous shares, light tiles last), 1 = every remainder tile is cut along K
+// (needs GemmArgs::slab), -1 = the measured policy above
 int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int wgs_per_cu, Ph8Sched& out) {
-    int dev = 0;
-    SAT_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_sched_mu);
-    DevState& d = g_dev[dev];
-    if (!d.cus) SAT_HIP(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (split < 0) split = (bm == 256 && ph8_auto_split(a, epi_f32, d.cus)) ? 1 : 0;
-    if (bm != 256) split = 0;          // the K-split machinery (slabs, reduce kernel) is built for the 256 x 256 tile
-    auto key = std::make_tuple(a.M, a.N, a.K, split, bm);
-    auto it = d.shapes.find(key);
-    if (it != d.shapes.end()) {
-        out = it->second;
-        out.sk_slab = d.slab;
-        return 0;
-    }
+    int cus = 0;
+    SAT_TRY(ph8_cus(cus));
+    const bool have_slab = a.slab != nullptr;
+    if (split < 0) split = (bm == 256 && epi_f32 && have_slab && ph8_auto_split(a, epi_f32, cus)) ? 1 : 0;
+    if (bm != 256 || !epi_f32) split = 0;          // the K-split machinery (slabs, reduce kernel) is built for the 256 x 256 fp32-output tile
     Ph8Sched s{};
     const int tiles_m = cdiv(a.M, bm), tail = a.M % bm;
     s.tiles_n = a.N / bn;
@@ -1023,100 +972,42 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
     s.tiles_m_full = tiles_m - s.light;
     s.nkp = a.K / 128;
     const long t_full = (long)s.tiles_m_full * s.tiles_n, t_light = s.light ? s.tiles_n : 0;
-    const long units_all = (t_full + t_light) * s.nkp;
-    s.G = (int)std::min<long>((long)d.cus * wgs_per_cu, split ? units_all : t_full + t_light);
     const long t_all = t_full + t_light;
+    s.G = (int)std::min<long>((long)cus * wgs_per_cu, split ? t_all * s.nkp : t_all);
     s.dp_rounds = (int)((split ? t_all : t_full) / s.G);
     // K-split with at least one whole round: the light tiles go FIRST (they idle their workgroup for half of round 0 -- a handful of
     // them) so that the remainder round holds full tiles only and splits evenly
     s.light_first = (split && s.dp_rounds >= 1 && t_light) ? 1 : 0;
-    const int rem0 = (int)((long)s.dp_rounds * s.G);          // first work-order position of the remainder
-    s.sk_tiles = (int)(t_all - rem0);
-    if (s.sk_tiles) {
-        // The remainder space, tile by tile, and who works on it.
-        //   split == 0: whole tiles, contiguous shares (the first sk_tiles % G workgroups take one more); light tiles are last.
-        //   split == 1: every tile is cut along K into equal parts, one workgroup per part (so a workgroup has ONE K-range and at
-        //     most one fix-up); parts in proportion to cost (a light tile counts half).
-        std::vector<int> tile, begin(s.G + 1, 0), first, parts;
-        std::vector<int> share;          // units of each workgroup, in order
-        auto is_light = [&](int pos) { return s.light_first ? pos < t_light : pos >= t_full; };
-        for (int j = 0; j < s.sk_tiles; ++j) tile.push_back(rem0 + j);
-        if (!split) {
-            const long q = s.sk_tiles / s.G, r = s.sk_tiles % s.G;
-            for (int i = 0; i < s.G; ++i) share.push_back((int)((q + (i < r ? 1 : 0)) * s.nkp));
-        } else if (split == 2) {
-            // stream-K proper: the remainder's K-units in one line, cut into G equal contiguous shares (a share spans at most two
-            // tiles when it is shorter than a tile: two partial K-ranges, two slab slots).  Light tiles count half.
-            long cost2 = 0;
-            for (int j = 0; j < s.sk_tiles; ++j) cost2 += is_light(tile[j]) ? 1 : 2;
-            // walk the line in cost space: boundary i sits at cost i * cost2 * nkp / G (in half-units), mapped back to units
-            std::vector<long> cum(s.sk_tiles + 1, 0);          // cumulative cost (half-units x nkp) at tile starts
-            for (int j = 0; j < s.sk_tiles; ++j) cum[j + 1] = cum[j] + (is_light(tile[j]) ? 1 : 2) * (long)s.nkp;
-            long prev = 0;
-            int j = 0;
-            for (int i = 1; i <= s.G; ++i) {
-                const long target = cum[s.sk_tiles] * i / s.G;
-                while (j < s.sk_tiles && cum[j + 1] <= target) ++j;
-                long u = j < s.sk_tiles ? (long)j * s.nkp + (target - cum[j]) / (is_light(tile[j]) ? 1 : 2) : (long)s.sk_tiles * s.nkp;
-                if (i == s.G) u = (long)s.sk_tiles * s.nkp;
-                share.push_back((int)(u - prev));
-                prev = u;
-            }
-        } else {
-            long cost2 = 0;              // in halves of a full tile
-            for (int j = 0; j < s.sk_tiles; ++j) cost2 += is_light(tile[j]) ? 1 : 2;
-            std::vector<int> pj(s.sk_tiles);
-            long used = 0;
-            for (int j = 0; j < s.sk_tiles; ++j) {
-                const long c2 = is_light(tile[j]) ? 1 : 2;
-                pj[j] = (int)std::max<long>(1, std::min<long>(std::min(s.nkp, 8), (long)s.G * c2 / cost2));
-                used += pj[j];
-            }
-            for (int j = 0; j < s.sk_tiles && used < s.G; ++j)          // leftover workgroups: one more part for the first full tiles
-                if (!is_light(tile[j]) && pj[j] < std::min(s.nkp, 8)) { ++pj[j]; ++used; }
-            for (int j = 0; j < s.sk_tiles; ++j)
-                for (int k = 0; k < pj[j]; ++k) share.push_back((int)((long)s.nkp * (k + 1) / pj[j] - (long)s.nkp * k / pj[j]));
-        }
-        SAT_CHECK_ARG((int)share.size() <= s.G, SAT_E_INVALID, "gemm(8-phase): schedule needs %d workgroups, has %d", (int)share.size(), s.G);
-        for (int i = 0; i < s.G; ++i) begin[i + 1] = begin[i] + (i < (int)share.size() ? share[i] : 0);
-        SAT_CHECK_ARG(begin[s.G] == s.sk_tiles * s.nkp, SAT_E_INVALID, "gemm(8-phase): schedule covers %d of %d units", begin[s.G], s.sk_tiles * s.nkp);
-        first.assign(s.sk_tiles, 0);
-        parts.assign(s.sk_tiles, 0);
-        for (int i = 0; i < s.G; ++i) {
-            if (begin[i + 1] <= begin[i]) continue;
-            for (int j = begin[i] / s.nkp; j <= (begin[i + 1] - 1) / s.nkp; ++j) {
-                if (!parts[j]) first[j] = i;
-                parts[j]++;
-            }
-        }
-        bool any_split = false;
-        for (int j = 0; j < s.sk_tiles; ++j) any_split = any_split || parts[j] > 1;
-        int *dt, *db, *df, *dp;
-        unsigned* dc;
-        SAT_HIP(hipMalloc(&dt, s.sk_tiles * sizeof(int)));
-        SAT_HIP(hipMalloc(&db, (s.G + 1) * sizeof(int)));
-        SAT_HIP(hipMalloc(&df, s.sk_tiles * sizeof(int)));
-        SAT_HIP(hipMalloc(&dp, s.sk_tiles * sizeof(int)));
-        SAT_HIP(hipMalloc(&dc, s.sk_tiles * sizeof(unsigned)));
-        SAT_HIP(hipMemcpy(dt, tile.data(), s.sk_tiles * sizeof(int), hipMemcpyHostToDevice));
-        SAT_HIP(hipMemcpy(db, begin.data(), (s.G + 1) * sizeof(int), hipMemcpyHostToDevice));
-        SAT_HIP(hipMemcpy(df, first.data(), s.sk_tiles * sizeof(int), hipMemcpyHostToDevice));
-        SAT_HIP(hipMemcpy(dp, parts.data(), s.sk_tiles * sizeof(int), hipMemcpyHostToDevice));
-        SAT_HIP(hipMemset(dc, 0, s.sk_tiles * sizeof(unsigned)));
-        s.sk_tile = dt; s.sk_begin = db; s.sk_first = df; s.sk_parts = dp; s.sk_count = dc;
-        s.any_split = any_split ? 1 : 0;
-        if (any_split && d.slab_wgs < (size_t)s.G) {
-            // one slab pair per workgroup, shared by every shape on this device: launches on ONE stream only (the plans' use)
-            SAT_HIP(hipDeviceSynchronize());
-            if (d.slab) SAT_HIP(hipFree(d.slab));
-            SAT_HIP(hipMalloc(&d.slab, (size_t)s.G * 2 * 65536 * sizeof(float)));
-            d.slab_wgs = s.G;
-            if (dev < 16) g_slab_now[dev].store(d.slab, std::memory_order_relaxed);
-        }
+    s.rem0 = (int)((long)s.dp_rounds * s.G);
+    s.sk_tiles = (int)(t_all - s.rem0);
+    s.split = (split && s.sk_tiles) ? 1 : 0;
+    if (s.sk_tiles && !s.split) {
+        s.sk_q = s.sk_tiles / s.G;
+        s.sk_r = s.sk_tiles % s.G;
+    } else if (s.sk_tiles) {
+        // remainder tiles in work order: full ones (cost 2), then -- unless they went first -- the light ones (cost 1).  Parts per tile in
+        // proportion to cost, at most min(nkp, 8); leftover workgroups give the first full tiles one more part: three classes.
+        const int n_light = s.light_first ? 0 : (int)std::min<long>(t_light, s.sk_tiles);
+        const int n_full = s.sk_tiles - n_light;
+        const long cost2 = 2L * n_full + n_light;
+        const int cap = std::min(s.nkp, 8);
+        const int pf = (int)std::max<long>(1, std::min<long>(cap, (long)s.G * 2 / cost2));
+        const int pl = (int)std::max<long>(1, std::min<long>(cap, (long)s.G * 1 / cost2));
+        long used = (long)n_full * pf + (long)n_light * pl;
+        int extra = 0;
+        if (pf < cap && used < s.G) extra = (int)std::min<long>(n_full, s.G - used);
+        used += extra;
+        SAT_CHECK_ARG(used <= s.G, SAT_E_INVALID, "gemm(8-phase): the K-split needs %ld workgroups, has %d", used, s.G);
+        s.cls_n[0] = extra; s.cls_p[0] = pf + 1;
+        s.cls_n[1] = n_full - extra; s.cls_p[1] = pf;
+        s.cls_n[2] = n_light; s.cls_p[2] = pl;
+        const size_t need = (size_t)s.G * 65536 * sizeof(float);
+        SAT_CHECK_ARG(a.slab && a.slab_bytes >= need, SAT_E_WORKSPACE, "gemm(8-phase): the K-split of the remainder round needs %zu bytes of slab workspace, got %zu",
+                      need, a.slab ? a.slab_bytes : (size_t)0);
+        SAT_CHECK_ARG(((uintptr_t)a.slab & 15) == 0, SAT_E_INVALID, "gemm(8-phase): the slab workspace must be 16-byte aligned");
+        s.sk_slab = a.slab;
     }
-    d.shapes[key] = s;
     out = s;
-    out.sk_slab = d.slab;
     return 0;
 }
 
@@ -1138,7 +1029,7 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
         SAT_CHECK_ARG(!a.fp8 && !a.H8, SAT_E_UNSUPPORTED, "gemm(8-phase): built for bf16 operands");
     }
     constexpr int BM = 64 * MFQ, BN = 64 * WN, NT = 2 * WN * 64;
-    constexpr int LDS = 2 * 2 * (BM / 2 + BN / 2) * 128 + 2 * (BM + BN) * 8 + 64;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column) + ticket
+    constexpr int LDS = 2 * 2 * (BM / 2 + BN / 2) * 128 + 2 * (BM + BN) * 8;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column)
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of %d", a.N, BN);
     SAT_CHECK_ARG(a.K % 128 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): K=%d must be a multiple of 128", a.K);
     SAT_CHECK_ARG((uint64_t)a.M * (uint64_t)a.K * 2u < (1ull << 31), SAT_E_UNSUPPORTED, "gemm(8-phase): A larger than 2 GiB");
@@ -1154,26 +1045,9 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
         SAT_CHECK_ARG(!a.heads.xa_k, SAT_E_UNSUPPORTED, "gemm(8-phase): the fused cross-attention epilogue lives in the 128 x 64 tile");
     }
     Ph8Sched sc;
-    // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements); bit 20: contiguous stream-K shares
-    const int split = (a.variant & 0x100000) ? 2 : (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;
-    {
-        // launch path: the few shapes of a plan are found in a thread-local table without taking the lock
-        struct Hit { int dev, M, N, K, split; float* slab; Ph8Sched s; };
-        static thread_local Hit hits[16];
-        static thread_local int n_hits = 0;
-        int dev = 0;
-        SAT_HIP(hipGetDevice(&dev));
-        Hit* h = nullptr;
-        for (int i = 0; i < n_hits; ++i)
-            if (hits[i].dev == dev && hits[i].M == a.M && hits[i].N == a.N && hits[i].K == a.K && hits[i].split == split) h = &hits[i];
-        if (h && h->slab == slab_of_device(dev)) {
-            sc = h->s;
-        } else {
-            SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, BM, BN, BM == 256 ? 1 : 2, sc));
-            if (!h && n_hits < 16) h = &hits[n_hits++];
-            if (h) *h = Hit{dev, a.M, a.N, a.K, split, slab_of_device(dev), sc};
-        }
-    }
+    // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements, tests)
+    const int split = (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;
+    SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, BM, BN, BM == 256 ? 1 : 2, sc));
     auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ, FP8>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     unsigned long long* ts = nullptr;
@@ -1184,9 +1058,8 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
         ts = g_ts_buf;
     }
 #endif
-    sc.dump = (EPI == EPI_F32 && sc.sk_slab != nullptr) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(sc.G), dim3(NT), LDS, stream, a, sc, ts);
-    if (sc.dump && sc.any_split) hipLaunchKernelGGL(ph8_reduce_f32_kernel, dim3(sc.sk_tiles * 8), dim3(512), 0, stream, a, sc);
+    if (sc.split) hipLaunchKernelGGL(ph8_reduce_f32_kernel, dim3(sc.sk_tiles * 8), dim3(512), 0, stream, a, sc);
     SAT_LAUNCH_CHECK();
     return 0;
 }
@@ -1217,7 +1090,20 @@ extern "C" int sat_gemm_ph8_timestamps(unsigned long long* out_host) {
 #endif
 
 bool SAT_OPNS::sat_gemm_ph8_splits(int epi, const GemmArgs& a) {
-    return ph8_auto_split(a, epi == EPI_F32 || epi == EPI_RESID, 256);
+    int cus = 0;
+    if (ph8_cus(cus) != 0 || !a.slab || a.slab_bytes < (size_t)cus * 65536 * sizeof(float)) return false;
+    return ph8_auto_split(a, epi == EPI_F32 || epi == EPI_RESID, cus);
+}
+
+// bytes of slab workspace (GemmArgs::slab) with which the launcher's automatic schedule splits the remainder round of this shape
+// along K; 0 = it would not split (callers size their workspace with this: sat_dit_workspace_bytes)
+size_t SAT_OPNS::sat_gemm_ph8_slab_bytes(int epi, int M, int N, int K) {
+    int cus = 0;
+    if (ph8_cus(cus) != 0) return 0;
+    GemmArgs a{};
+    a.M = M; a.N = N; a.K = K;
+    if (N % 256 || K % 128 || !ph8_auto_split(a, epi == EPI_F32 || epi == EPI_RESID, cus)) return 0;
+    return (size_t)cus * 65536 * sizeof(float);
 }
 
 int SAT_OPNS::sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {

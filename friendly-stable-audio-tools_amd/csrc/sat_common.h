@@ -77,6 +77,7 @@ void sat_set_error(const char* fmt, ...);
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: raise it once per (kernel, device), not once
 // per process (a second GPU in the same process would otherwise launch with the 64 KiB default and fail).  Thread-safe.
 int sat_ensure_dynamic_lds(const void* kernel, int bytes);
+int sat_device_cus();          // compute units of the current device (cached per device; 0 + sat_last_error on failure)
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -321,12 +322,18 @@ struct GemmArgs {
     const float* ln_c1;        // consumer: [N] sum_k bf16(gamma_k W_nk), epilogue channel order
     const float* ln_c2;        // consumer: [N] sum_k beta_k W_nk (+ bias_n)
     float ln_eps;
+    // ---- scratch of the 8-phase kernel's K-split (fp32 output, long reductions: FF-out at the SA-2.0 shape): raw accumulator images
+    // of the remainder round's partial K-ranges, [workgroups][65536] floats, added up by a second launch.  Caller-owned (the plan's
+    // workspace), used by this launch only; nullptr = the remainder round's tiles stay whole.
+    float* slab;
+    size_t slab_bytes;
 };
 
 // bf16 build: checks a.f16 and forwards fp16 work to sat_launch_gemm_f16 (the fp16 build of the same file)
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream);
 bool sat_gemm_ph8_supports(int epi, const GemmArgs& a);
 bool sat_gemm_ph8_splits(int epi, const GemmArgs& a);       // the automatic schedule would split the remainder round along K
+size_t sat_gemm_ph8_slab_bytes(int epi, int M, int N, int K);      // slab workspace that makes it do so (0: never for this shape)
 int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream);     // gemm_ph8.hip: the 8-wave / 8-phase 256x256 tile
 // out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
 // q_scale: what the kernel still has to multiply in -- SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e) for a plain Q, 1.0f for a Q the

@@ -83,6 +83,11 @@ _SIGNATURES = {
     "sat_resample_sinc": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "sat_gemm_bf16_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_void_p]),
+    "sat_gemm_f32_workspace_bytes": (c_int32, [c_int32, c_int32, c_int32, c_int32, POINTER(c_size_t)]),
+    "sat_gemm_bf16_f32_ws": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                       c_void_p, c_size_t, c_void_p]),
+    "sat_gemm_resid_ln_bf16_ws": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                            c_void_p, c_size_t, c_void_p]),
     "sat_gemm_swiglu_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                        c_int32, c_void_p]),
     "sat_attention_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -108,7 +113,7 @@ _SIGNATURES = {
 }
 
 # the same unit-level entry points on IEEE fp16 operands (gemm_dtype = 3): identical signatures
-for _n in ("sat_layernorm_bf16", "sat_cast_bf16", "sat_gemm_bf16_f32", "sat_gemm_swiglu_bf16", "sat_attention_bf16", "sat_cross_attention_fused_bf16", "sat_attention_prescaled_bf16", "sat_qkv_rope_bf16", "sat_gemm_resid_ln_bf16", "sat_gemm_swiglu_ln_bf16", "sat_qkv_rope_ln_bf16"):
+for _n in ("sat_layernorm_bf16", "sat_cast_bf16", "sat_gemm_bf16_f32", "sat_gemm_swiglu_bf16", "sat_attention_bf16", "sat_cross_attention_fused_bf16", "sat_attention_prescaled_bf16", "sat_qkv_rope_bf16", "sat_gemm_resid_ln_bf16", "sat_gemm_swiglu_ln_bf16", "sat_qkv_rope_ln_bf16", "sat_gemm_bf16_f32_ws", "sat_gemm_resid_ln_bf16_ws"):
     _SIGNATURES[_n.replace("bf16", "f16")] = _SIGNATURES[_n]
 
 _lib = None

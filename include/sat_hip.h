@@ -262,9 +262,18 @@ int sat_cast_bf16(const float* x_dev, void* y_bf16_dev, int64_t n, sat_stream_t 
  * n % 128 == 0, k % 64 == 0.  variant selects a tile configuration (0 = default). */
 int sat_gemm_bf16_f32(const void* a_bf16_dev, const void* w_bf16_dev, const float* bias_dev, float* c_dev,
                       int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream);
+/* The same GEMM with caller-supplied scratch: the 8-phase 256 x 256 tile cuts the remainder round of a long reduction (k >= 4096 behind
+ * at least one whole round of tiles, e.g. FF-out at the SA-2.0 shape; or forced with variant bit 16) along K -- every partial K-range
+ * stores its raw accumulators to a slab in `ws`, a second launch adds them in a fixed order.  sat_gemm_f32_workspace_bytes gives the
+ * size (0: this shape does not split).  Without workspace (the entry above) nothing is ever split.  The DiT plan carves this scratch
+ * out of the workspace the caller hands to sat_dit_forward: no call allocates, and plans on different streams never share scratch. */
+int sat_gemm_f32_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t variant, size_t* out_bytes);
+int sat_gemm_bf16_f32_ws(const void* a_bf16_dev, const void* w_bf16_dev, const float* bias_dev, float* c_dev,
+                         int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, void* ws_dev, size_t ws_bytes,
+                         sat_stream_t stream);
 /* Which kernel serves the 256 x 256 tile of the bf16 GEMMs: 80 (default) = 8 waves, 128 x 64 per wave, 8-phase schedule with a
- * counted-vmcnt LDS-DMA ring of half-tiles (csrc/gemm_ph8.hip); 22 = the 16-wave 2-stage tile of rounds 1-2 (A/B measurements;
- * fp8 operands always use it).  Process-wide; not a per-call argument because the tile is chosen inside the plan. */
+ * counted-vmcnt LDS-DMA ring of half-tiles (csrc/gemm_ph8.hip); 22 = the 16-wave 2-stage tile of rounds 1-2 (A/B measurements).  e4m3
+ * operands: the LayerNorm-fed GEMMs (heads / SwiGLU epilogues) follow this switch too, the MXFP8-operand GEMMs always run tile 22.  Process-wide; not a per-call argument because the tile is chosen inside the plan. */
 int sat_gemm_set_wide_tile(int32_t tile);
 /* SwiGLU GEMM (models/transformer.py:211-235): h[m,n/2] (bf16) = (A W_v^T + b_v) * silu(A W_g^T + b_g)
  * with W [n,k] in the REFERENCE row order (value rows then gate rows); re-packed internally
@@ -311,6 +320,9 @@ int sat_qkv_rope_bf16(const void* a_bf16_dev, const void* w_bf16_dev, const floa
  *   (sum, sum of squares) of the rounded row.  n % 128 == 0, k % 64 == 0, k >= 192. */
 int sat_gemm_resid_ln_bf16(const void* a_bf16_dev, const void* w_bf16_dev, const float* bias_dev, float* c_dev, void* xb_dev,
                            float* ln_part_dev, int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream);
+int sat_gemm_resid_ln_bf16_ws(const void* a_bf16_dev, const void* w_bf16_dev, const float* bias_dev, float* c_dev, void* xb_dev,
+                              float* ln_part_dev, int32_t m, int32_t n, int32_t k, int32_t variant, void* ws_dev, size_t ws_bytes,
+                              sat_stream_t stream);      /* with K-split scratch, as sat_gemm_bf16_f32_ws */
 /* Consumers: xb / ln_part as written by the producer (k = its n).  SwiGLU FF-in (transformer.py:222, 232-235) of LayerNorm(x):
  * w_f32 [n, k], gamma / beta [k], bias [n] fp32 (reference layout: value rows then gate rows) -> h [m, n / 2] bf16.
  * wpack [n, k] bf16 and c12 [2 n] fp32 receive the re-packed operands: bf16(gamma (.) w) (value / gate rows interleaved by 32),
@@ -334,6 +346,12 @@ int sat_layernorm_f16(const float* x_dev, const float* gamma_dev, const float* b
 int sat_cast_f16(const float* x_dev, void* y_f16_dev, int64_t n, sat_stream_t stream);
 int sat_gemm_f16_f32(const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, float* c_dev,
                      int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, sat_stream_t stream);
+int sat_gemm_f16_f32_ws(const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, float* c_dev,
+                        int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, void* ws_dev, size_t ws_bytes,
+                        sat_stream_t stream);
+int sat_gemm_resid_ln_f16_ws(const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, float* c_dev, void* xb_dev,
+                             float* ln_part_dev, int32_t m, int32_t n, int32_t k, int32_t variant, void* ws_dev, size_t ws_bytes,
+                             sat_stream_t stream);
 int sat_gemm_swiglu_f16(const void* a_f16_dev, const float* w_f32_dev, const float* bias_f32_dev,
                         void* wpack_dev, float* bpack_dev, void* h_f16_dev,
                         int32_t m, int32_t n, int32_t k, int32_t variant, sat_stream_t stream);

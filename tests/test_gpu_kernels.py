@@ -52,10 +52,22 @@ def test_cast_bf16(dev, fmt):
 
 # the shipped tile configurations (gemm_bf16.hip: launch_epi); 0 = the launcher's own choice
 # 80: the 256x256 tile on 8 waves with the 8-phase schedule (gemm_ph8.hip) -- what variant 0 picks whenever it picks that tile
-# 80 | 0x10000: the same with the remainder round split along K (fp32 output: slabs + ph8_reduce_f32_kernel; SwiGLU / heads: in-kernel
-# last-arriver fix-up) -- forced here, the launcher only splits long reductions behind a whole round
-GEMM_VARIANTS = [1, 5, 15, 16, 22, 30, 80, 80 | 0x10000]
-GEMM_F32_VARIANTS = GEMM_VARIANTS + [44]        # 44: tile 15 with a 4-stage ring (fp32 output, long K)
+# 80 | 0x10000 (fp32 output only): the same with the remainder round split along K -- slabs in caller-supplied workspace + ph8_reduce_f32_kernel --
+# forced here, the launcher only splits long reductions behind a whole round; goes through the *_ws entry points
+GEMM_VARIANTS = [1, 5, 15, 16, 22, 30, 80]
+SPLIT = 80 | 0x10000
+GEMM_F32_VARIANTS = GEMM_VARIANTS + [SPLIT, 44]        # 44: tile 15 with a 4-stage ring (fp32 output, long K)
+
+
+def _split_ws(dev, m, n, k, variant):
+    """workspace of the K-split (sat_gemm_f32_workspace_bytes) -> (tensor or None, bytes)"""
+    import ctypes
+    _hip, lib = _lib()
+    need = ctypes.c_size_t()
+    _hip.check(lib.sat_gemm_f32_workspace_bytes(m, n, k, variant, ctypes.byref(need)))
+    if not need.value:
+        return None, 0
+    return torch.empty(need.value, dtype=torch.uint8, device=dev), need.value
 
 
 def _skip_tile(variant, n, k):
@@ -83,7 +95,16 @@ def test_gemm_f32(dev, variant, m, n, k, fmt):
     c0 = _rand((m, n), 8)
     want = a.float() @ w.float().T + bias + c0
     ad, wd, bd, cd = a.to(dev), w.to(dev), bias.to(dev), c0.to(dev)
-    _hip.check(fmt.fn(lib, "sat_gemm_bf16_f32")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1, variant, _hip.stream()))
+    if variant & 0x10000:
+        ws, ws_bytes = _split_ws(dev, m, n, k, variant)
+        assert ws_bytes == 256 * 65536 * 4
+        _hip.check(fmt.fn(lib, "sat_gemm_bf16_f32_ws")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1, variant, _hip.ptr(ws),
+                                                       ws_bytes, _hip.stream()))
+        # a forced split without scratch is refused, not silently run whole (a single tile with a single K unit has nothing to split)
+        rc = -4 if (m, n, k) == (130, 256, 128) else fmt.fn(lib, "sat_gemm_bf16_f32")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(torch.empty_like(cd)), m, n, k, 1, variant, _hip.stream())
+        assert rc == -4, f"forced K-split without workspace returned {rc}, expected SAT_E_WORKSPACE"
+    else:
+        _hip.check(fmt.fn(lib, "sat_gemm_bf16_f32")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1, variant, _hip.stream()))
     assert_close(f"gemm v{variant} {m}x{n}x{k}", cd, want, 1e-3 if not fmt.f16 else 1e-5)      # same operands: fp32 summation order only
 
 
@@ -321,8 +342,13 @@ def _ln_fold_producer(dev, m, d, k, variant, seed=40, fmt=FORMATS[0], x_scale=2.
     ad, wd, bd, cd = a.to(dev), w.to(dev), bias.to(dev), x0.to(dev)
     xb = torch.full((m, d), float("nan"), dtype=fmt.dtype, device=dev)
     part = torch.full((m, d // 64, 2), float("nan"), dtype=torch.float32, device=dev)
-    _hip.check(fmt.fn(lib, "sat_gemm_resid_ln_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), _hip.ptr(xb), _hip.ptr(part), m, d, k,
-                                                     variant, _hip.stream()))
+    if variant & 0x10000:
+        ws, ws_bytes = _split_ws(dev, m, d, k, variant)
+        _hip.check(fmt.fn(lib, "sat_gemm_resid_ln_bf16_ws")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), _hip.ptr(xb), _hip.ptr(part), m, d, k,
+                                                            variant, _hip.ptr(ws), ws_bytes, _hip.stream()))
+    else:
+        _hip.check(fmt.fn(lib, "sat_gemm_resid_ln_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), _hip.ptr(xb), _hip.ptr(part), m, d, k,
+                                                         variant, _hip.stream()))
     assert_close(f"ln-fold producer v{variant}", cd, want, 1e-3)
     assert torch.equal(xb, cd.clamp(-65504.0, 65504.0).to(fmt.dtype)), "xb must be the 16-bit rounding (fp16: saturating) of the fp32 rows just written"
     blocks = xb.float().view(m, d // 64, 64).double()
@@ -344,7 +370,7 @@ def _ln_fold_reference(xb, w, gamma, beta, bias, fmt=FORMATS[0]):
 
 @pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("m", [300, 770])
-@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (0, 0), (80, 80), (15, 80), (80, 30), (80 | 0x10000, 80 | 0x10000)])
+@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (0, 0), (80, 80), (15, 80), (80, 30), (SPLIT, 80)])
 def test_ln_fold_swiglu(dev, prod, cons, m, fmt):
     """LayerNorm folded into FF-in (sat_dit_cfg.ln_fold): producer epilogue -> bf16 rows + partial sums -> SwiGLU GEMM that finishes
     the normalisation.  Gates: 4e-3 against the same arithmetic in fp64 (one bf16 rounding of the output), 1e-2 against the plain fp32
@@ -415,7 +441,7 @@ def test_ln_fold_rows_with_common_mode(dev, row_mean, outlier):
 
 @pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
-@pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (0, 0), (80, 80), (16, 80), (80, 15), (80 | 0x10000, 80 | 0x10000)])
+@pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (0, 0), (80, 80), (16, 80), (80, 15), (SPLIT, 80)])
 def test_ln_fold_qkv_rope(dev, prod, cons, s, s_pad, fmt):
     """LayerNorm folded into to_qkv + RoPE + head split (transformer.py:692, 314, 430-452): q / k through the transposed epilogue,
     V^T through the un-swapped one -- both have to apply the per-row statistics."""

@@ -5,12 +5,12 @@
 #   stats [bench.py args]   rocprofv3 --kernel-trace --stats of bench.py     -> gpurun_out/${TAG}_kernel_stats.csv + _summary.md
 #   pmc                     FETCH_SIZE / WRITE_SIZE / SQ counter passes of tools/gpu_probe.py full (separate passes, no traces)
 #   probe <sections...>     tools/ph8_probe.py sections with the experiments build
-# TAG (default r03) names the outputs.
+# TAG (default r04) names the outputs.
 cd "$(dirname "$0")/.."
 R=$PWD
 mkdir -p gpurun_out
 export PYTHONPATH=$R/friendly-stable-audio-tools_amd:$PYTHONPATH
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 stage=$1; shift
 case $stage in
   pytest)
