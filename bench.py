@@ -275,6 +275,8 @@ def main():
     cond = conditioning(model, prompt_ids, dev)
     dit = model.model.model
     dit.set_gemm_dtype(args.dtype)
+    if args.dtype == "fp16":        # the codec too (the reference's model_half)
+        model.pretransform.model.set_gemm_dtype("fp16")
     dit.set_layernorm_fusion(args.layernorm == "fused")
     from stable_audio_tools import _hip
     _hip.check(_hip.lib().sat_set_cross_attention_fusion(1 if args.cross_attention == "fused" else 0))

@@ -586,7 +586,7 @@ extern "C" int sat_resample_sinc(const float* x_dev, const float* bank_dev, floa
                                  int32_t orig, int32_t newr, int32_t width, sat_stream_t stream) {
     SAT_CHECK_ARG(x_dev && bank_dev && y_dev, SAT_E_INVALID, "resample: null pointer");
     SAT_CHECK_ARG(rows > 0 && in_len > 0 && out_len > 0 && orig > 0 && newr > 0 && width >= 0, SAT_E_INVALID, "resample: bad dims");
-    SAT_CHECK_ARG((int64_t)out_len <= ((int64_t)in_len * newr + orig - 1) / orig + newr, SAT_E_INVALID,
+    SAT_CHECK_ARG((int64_t)out_len <= ((int64_t)in_len * newr + orig - 1) / orig, SAT_E_INVALID,
                   "resample: out_len %d exceeds ceil(in_len * new / orig) = %lld", out_len, (long long)(((int64_t)in_len * newr + orig - 1) / orig));
     const long total = (long)rows * out_len;
     hipLaunchKernelGGL(resample_sinc_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x_dev, bank_dev, y_dev, in_len, out_len,

@@ -28,16 +28,16 @@
 namespace {
 
 struct ConvArgs {
-    const bf16_t* in;        // [B][Tin][Cin]
+    const op_t* in;        // [B][Tin][Cin]
     int Tin, Cin;
-    const bf16_t* W;         // [taps][N][Cin]
+    const op_t* W;         // [taps][N][Cin]
     int taps, N, M;          // M GEMM rows per batch item
     int stride, off0, doff;
     const float* bias;       // [Cout] or null ; n -> bias[n % Cout]
     int Cout;
-    const bf16_t* res;       // residual (raw), same indexing as out ; or null
-    bf16_t* out_raw;         // or null
-    bf16_t* out_snk;         // or null
+    const op_t* res;       // residual (raw), same indexing as out ; or null
+    op_t* out_raw;         // or null
+    op_t* out_snk;         // or null
     const float* sn_a;       // exp(alpha)[Cout]
     const float* sn_ib;      // 1/(exp(beta)+1e-9)[Cout]
     long long out_bstride;   // elements per batch item
@@ -45,7 +45,7 @@ struct ConvArgs {
     long long out_limit;
     float* out_cf;           // channel-first fp32 output [B][cf_channels][M] (final convs) or null
     int cf_channels;
-    const bf16_t* zero_page; // >= 128 B of zeros: LDS-DMA source of the rows that fall into the conv padding
+    const op_t* zero_page; // >= 128 B of zeros: LDS-DMA source of the rows that fall into the conv padding
 };
 
 __device__ __forceinline__ float snake_f(float v, float a, float ib) {
@@ -77,9 +77,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& g, f32x16 (&acc)[M
         }
         return;
     }
-    const bf16_t* res = g.res ? g.res + (size_t)b * g.out_bstride : nullptr;
-    bf16_t* oraw = g.out_raw ? g.out_raw + (size_t)b * g.out_bstride : nullptr;
-    bf16_t* __restrict__ osnk = g.out_snk ? g.out_snk + (size_t)b * g.out_bstride : nullptr;
+    const op_t* res = g.res ? g.res + (size_t)b * g.out_bstride : nullptr;
+    op_t* oraw = g.out_raw ? g.out_raw + (size_t)b * g.out_bstride : nullptr;
+    op_t* __restrict__ osnk = g.out_snk ? g.out_snk + (size_t)b * g.out_bstride : nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = mw + i * 32 + l31;
@@ -105,12 +105,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& g, f32x16 (&acc)[M
                     }
                 }
                 if (res && ok) {
-                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(res + flat);
+                    const opx8 rv = *reinterpret_cast<const opx8*>(res + flat);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] += bf16_to_f32(rv[e]);
+                    for (int e = 0; e < 8; ++e) x[e] += op_to_f32(rv[e]);
                 }
                 if (oraw && ok)
-                    *reinterpret_cast<u32x4*>(oraw + flat) = u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
+                    *reinterpret_cast<u32x4*>(oraw + flat) = u32x4{pack_op2(x[0], x[1]), pack_op2(x[2], x[3]), pack_op2(x[4], x[5]), pack_op2(x[6], x[7])};
                 if (osnk) {
                     const f32x4 a0 = *reinterpret_cast<const f32x4*>(g.sn_a + co), a1 = *reinterpret_cast<const f32x4*>(g.sn_a + co + 4);
                     const f32x4 i0 = *reinterpret_cast<const f32x4*>(g.sn_ib + co), i1 = *reinterpret_cast<const f32x4*>(g.sn_ib + co + 4);
@@ -121,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& g, f32x16 (&acc)[M
                         y[4 + e] = snake_f(x[4 + e], a1[e], i1[e]);
                     }
                     if (ok)
-                        *reinterpret_cast<u32x4*>(osnk + flat) = u32x4{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+                        *reinterpret_cast<u32x4*>(osnk + flat) = u32x4{pack_op2(y[0], y[1]), pack_op2(y[2], y[3]), pack_op2(y[4], y[5]), pack_op2(y[6], y[7])};
                 }
             }
         }
@@ -156,7 +156,7 @@ __device__ __forceinline__ void conv_main_loop(const ConvArgs& g, char* smem, co
     const int Cin = g.Cin, Tin = g.Tin;
     const int cpt = Cin >> 6;
     const int nk = g.taps * cpt;
-    const bf16_t* __restrict__ inb = g.in + (size_t)b * Tin * Cin;
+    const op_t* __restrict__ inb = g.in + (size_t)b * Tin * Cin;
 
     int a_m[A_CH], a_coff[A_CH];
 #pragma unroll
@@ -183,11 +183,11 @@ __device__ __forceinline__ void conv_main_loop(const ConvArgs& g, char* smem, co
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             const int r = a_m[i] + off;
-            const bf16_t* src = (r >= 0 && r < Tin) ? inb + (size_t)r * Cin + ci0 + a_coff[i] : g.zero_page + a_coff[i];
+            const op_t* src = (r >= 0 && r < Tin) ? inb + (size_t)r * Cin + ci0 + a_coff[i] : g.zero_page + a_coff[i];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sa + (i * NT + wave * 64) * 16), 16, 0, 0);
         }
-        const bf16_t* wt = g.W + ((size_t)tap * g.N + n0) * Cin + ci0;
+        const op_t* wt = g.W + ((size_t)tap * g.N + n0) * Cin + ci0;
 #pragma unroll
         for (int i = 0; i < B_CH; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + b_off[i]),
@@ -196,14 +196,14 @@ __device__ __forceinline__ void conv_main_loop(const ConvArgs& g, char* smem, co
     auto compute = [&](int stage) {
         const char* sa = smem + stage * STAGE_BYTES;
         const char* sb = sa + BM * 128;
-        bf16x8 af[2][MI], bfr[2][NI];
+        opx8 af[2][MI], bfr[2][NI];
         auto frag = [&](int ks, int buf) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[buf][i] = *reinterpret_cast<const bf16x8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+                af[buf][i] = *reinterpret_cast<const opx8*>(sa + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                bfr[buf][j] = *reinterpret_cast<const bf16x8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+                bfr[buf][j] = *reinterpret_cast<const opx8*>(sb + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
         };
         frag(0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
@@ -214,7 +214,7 @@ __device__ __forceinline__ void conv_main_loop(const ConvArgs& g, char* smem, co
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);      // C^T: lane = output row
+                    acc[i][j] = mfma_32x32x16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j]);      // C^T: lane = output row
             if (ks + 1 < 4) {
                 constexpr int NR = MI + NI, NM = MI * NI;
 #pragma unroll
@@ -251,6 +251,7 @@ __device__ __forceinline__ void conv_main_loop(const ConvArgs& g, char* smem, co
 
 template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void conv_pipe_kernel(ConvArgs g) {
+    sat_f16_saturate();
     constexpr int TM = BM / WM;
     constexpr int TN = BN / WN;
     constexpr int MI = TM / 32;
@@ -290,6 +291,7 @@ struct RuArgs {
 
 template <int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void ru_fused_kernel(RuArgs ga) {
+    sat_f16_saturate();
     constexpr int BM = 128;
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(WM * WN * 64) void ru_fused_kernel(RuArgs ga) {
                     y[4 + e] = snake_f(v[grp * 8 + 4 + e] + b1[e], a1[e], i1[e]);
                 }
                 *reinterpret_cast<u32x4*>(smem + (n >> 6) * (BM * 128) + lds_tile_off(row, (n & 63) >> 3)) =
-                    u32x4{pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+                    u32x4{pack_op2(y[0], y[1]), pack_op2(y[2], y[3]), pack_op2(y[4], y[5]), pack_op2(y[6], y[7])};
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -376,15 +378,15 @@ __global__ __launch_bounds__(WM * WN * 64) void ru_fused_kernel(RuArgs ga) {
         const char* sb_ = sw + (kt & 1) * W_TILE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[MI], bfr[2];
+            opx8 af[MI], bfr[2];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa_ + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const opx8*>(sa_ + lds_tile_off(wm * TM + i * 32 + l31, ks * 2 + half));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb_ + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
+            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const opx8*>(sb_ + lds_tile_off(wn * TN + j * 32 + l31, ks * 2 + half));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16(bfr[j], af[i], acc[i][j]);
         }
         if (kt + 2 < KT1) {
             __builtin_amdgcn_s_barrier();              // stage kt & 1 is free again
@@ -395,7 +397,8 @@ __global__ __launch_bounds__(WM * WN * 64) void ru_fused_kernel(RuArgs ga) {
 }
 
 // z [B][C][T] fp32 (channel-first) -> [B][T][C] bf16
-__global__ __launch_bounds__(256) void cf_to_cl_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int C, int T) {
+__global__ __launch_bounds__(256) void cf_to_cl_kernel(const float* __restrict__ x, op_t* __restrict__ y, int C, int T) {
+    sat_f16_saturate();
     __shared__ float tile[64][65];
     const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256) void cf_to_cl_kernel(const float* __restrict__
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         int t = i >> 6, c = i & 63;
-        if (c0 + c < C && t0 + t < T) y[((size_t)b * T + t0 + t) * C + c0 + c] = f32_to_bf16(tile[c][t]);
+        if (c0 + c < C && t0 + t < T) y[((size_t)b * T + t0 + t) * C + c0 + c] = f32_to_op(tile[c][t]);
     }
 }
 
@@ -413,8 +416,9 @@ __global__ __launch_bounds__(256) void cf_to_cl_kernel(const float* __restrict__
 // k=7 pad 3 -> Cout channels; writes raw + snaked channels-last bf16.  VALU (K = 14).
 __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict__ x, const float* __restrict__ w /*[Cout][Cin][7]*/,
                                                          const float* __restrict__ bias, const float* __restrict__ sn_a,
-                                                         const float* __restrict__ sn_ib, bf16_t* __restrict__ out_raw,
-                                                         bf16_t* __restrict__ out_snk, int Cin, int Cout, int L) {
+                                                         const float* __restrict__ sn_ib, op_t* __restrict__ out_raw,
+                                                         op_t* __restrict__ out_snk, int Cin, int Cout, int L) {
+    sat_f16_saturate();
     __shared__ float xs[2][64 + 6];
     const int b = blockIdx.y, t0 = blockIdx.x * 64;
     for (int i = threadIdx.x; i < 2 * 70; i += 256) {
@@ -438,8 +442,8 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
 #pragma unroll
                 for (int k = 0; k < 7; ++k) acc += wr[c][k] * xs[c][tt + k];
             size_t o = ((size_t)b * L + t0 + tt) * Cout + co;
-            out_raw[o] = f32_to_bf16(acc);
-            out_snk[o] = f32_to_bf16(snake_f(acc, a, ib));
+            out_raw[o] = f32_to_op(acc);
+            out_snk[o] = f32_to_op(snake_f(acc, a, ib));
         }
     }
 }
@@ -447,6 +451,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const float* __restrict
 // ---- weight-norm folding (dac WNConv1d == torch weight_norm dim 0): w = g * v / ||v||
 __global__ __launch_bounds__(256) void wn_invnorm_kernel(const float* __restrict__ v, const float* __restrict__ gsc,
                                                          float* __restrict__ scale, int slice) {
+    sat_f16_saturate();
     __shared__ float red[4];
     const int i = blockIdx.x;
     float s = 0.f;
@@ -460,24 +465,27 @@ __global__ __launch_bounds__(256) void wn_invnorm_kernel(const float* __restrict
     if (threadIdx.x == 0) scale[i] = gsc[i] / sqrtf(red[0] + red[1] + red[2] + red[3]);
 }
 // Conv1d v[co][ci][k] -> W[j][co_pad][ci] bf16 (rows co >= Cout are zero)
-__global__ void wn_pack_conv_kernel(const float* __restrict__ v, const float* __restrict__ scale, bf16_t* __restrict__ W,
+__global__ void wn_pack_conv_kernel(const float* __restrict__ v, const float* __restrict__ scale, op_t* __restrict__ W,
                                     int Cout, int Cin, int k, int Npad) {
+    sat_f16_saturate();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)k * Npad * Cin) return;
     int ci = (int)(i % Cin);
     int n = (int)((i / Cin) % Npad);
     int j = (int)(i / ((size_t)Cin * Npad));
-    W[i] = f32_to_bf16(n < Cout ? v[((size_t)n * Cin + ci) * k + j] * scale[n] : 0.f);
+    W[i] = f32_to_op(n < Cout ? v[((size_t)n * Cin + ci) * k + j] * scale[n] : 0.f);
 }
 // same, fp32, original layout (for the VALU first conv)
 __global__ void wn_fold_f32_kernel(const float* __restrict__ v, const float* __restrict__ scale, float* __restrict__ w, int slice,
                                    size_t n) {
+    sat_f16_saturate();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) w[i] = v[i] * scale[i / slice];
 }
 // ConvTranspose1d v[ci][co][k=2s] -> W[j][phi*Cout+co][ci] = w[ci][co][phi + j*s]
-__global__ void wn_pack_convT_kernel(const float* __restrict__ v, const float* __restrict__ scale, bf16_t* __restrict__ W,
+__global__ void wn_pack_convT_kernel(const float* __restrict__ v, const float* __restrict__ scale, op_t* __restrict__ W,
                                      int Cin, int Cout, int s) {
+    sat_f16_saturate();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int N = s * Cout;
     if (i >= (size_t)2 * N * Cin) return;
@@ -485,10 +493,11 @@ __global__ void wn_pack_convT_kernel(const float* __restrict__ v, const float* _
     int n = (int)((i / Cin) % N);
     int j = (int)(i / ((size_t)Cin * N));
     int phi = n / Cout, co = n - phi * Cout;
-    W[i] = f32_to_bf16(v[((size_t)ci * Cout + co) * (2 * s) + phi + j * s] * scale[ci]);
+    W[i] = f32_to_op(v[((size_t)ci * Cout + co) * (2 * s) + phi + j * s] * scale[ci]);
 }
 __global__ void snake_params_kernel(const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ a,
                                     float* __restrict__ ib, int C) {
+    sat_f16_saturate();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C) return;
     a[i] = expf(alpha[i]);
@@ -532,16 +541,17 @@ const bool g_ru_unfused = [] {
 constexpr bool g_ru_unfused = false;
 #endif
 struct ConvW {
-    bf16_t* W = nullptr;
+    op_t* W = nullptr;
     float* bias = nullptr;
     int Cin = 0, Cout = 0, taps = 0, N = 0;
-    const bf16_t* zero = nullptr;   // the plan's zero page (LDS-DMA source for padding rows)
+    const op_t* zero = nullptr;   // the plan's zero page (LDS-DMA source for padding rows)
 };
 
 }  // namespace
 
-struct sat_oobleck_plan {
-    sat_oobleck_cfg cfg;
+namespace SAT_OPNS {
+struct OobPlan {
+    sat_oobleck_cfg cfg;          // first member: the C entry points read cfg.gemm_dtype through the opaque pointer to pick the build
     std::map<std::string, std::pair<const float*, int64_t>> tensors;
     bool finalized = false;
     char* arena = nullptr;
@@ -559,8 +569,10 @@ struct sat_oobleck_plan {
     };
     std::vector<Block> blocks;
     Snake final_snake;
-    bf16_t* zero_page = nullptr;
+    op_t* zero_page = nullptr;
 };
+}  // namespace SAT_OPNS
+using SAT_OPNS::OobPlan;
 
 namespace {
 
@@ -575,7 +587,7 @@ struct Arena {
     }
 };
 
-int get_tensor(sat_oobleck_plan* p, const std::string& name, int64_t numel, const float** out) {
+int get_tensor(OobPlan* p, const std::string& name, int64_t numel, const float** out) {
     auto it = p->tensors.find(name);
     SAT_CHECK_ARG(it != p->tensors.end(), SAT_E_MISSING, "oobleck plan: tensor '%s' was never set", name.c_str());
     SAT_CHECK_ARG(it->second.second == numel, SAT_E_INVALID, "oobleck plan: tensor '%s' has %lld elements, expected %lld", name.c_str(),
@@ -584,7 +596,7 @@ int get_tensor(sat_oobleck_plan* p, const std::string& name, int64_t numel, cons
     return 0;
 }
 
-int make_snake(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int C, Snake* sn, hipStream_t s) {
+int make_snake(OobPlan* p, Arena& ar, const std::string& pfx, int C, Snake* sn, hipStream_t s) {
     sn->a = (float*)ar.take((size_t)C * 4);
     sn->ib = (float*)ar.take((size_t)C * 4);
     if (ar.dry) return 0;
@@ -597,13 +609,13 @@ int make_snake(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int C, Sn
 }
 
 // Conv1d weight [Cout][Cin][k]
-int make_conv(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, int Cout, int k, bool has_bias, ConvW* cw,
+int make_conv(OobPlan* p, Arena& ar, const std::string& pfx, int Cin, int Cout, int k, bool has_bias, ConvW* cw,
               hipStream_t s, float** w_f32 = nullptr) {
     const int Npad = (int)round_up(Cout, 64);
     cw->Cin = Cin; cw->Cout = Cout; cw->taps = k; cw->N = Npad; cw->zero = p->zero_page;
     float* scale = (float*)ar.take((size_t)Cout * 4);
     if (w_f32) *w_f32 = (float*)ar.take((size_t)Cout * Cin * k * 4);
-    else cw->W = (bf16_t*)ar.take((size_t)k * Npad * Cin * 2);
+    else cw->W = (op_t*)ar.take((size_t)k * Npad * Cin * 2);
     cw->bias = has_bias ? (float*)ar.take((size_t)Cout * 4) : nullptr;
     if (ar.dry) return 0;
     const float *g, *v, *bsrc;
@@ -626,10 +638,10 @@ int make_conv(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, i
 }
 
 // ConvTranspose1d weight [Cin][Cout][2s]
-int make_convT(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, int Cout, int stride, ConvW* cw, hipStream_t s) {
+int make_convT(OobPlan* p, Arena& ar, const std::string& pfx, int Cin, int Cout, int stride, ConvW* cw, hipStream_t s) {
     cw->Cin = Cin; cw->Cout = Cout; cw->taps = 2; cw->N = stride * Cout; cw->zero = p->zero_page;
     float* scale = (float*)ar.take((size_t)Cin * 4);
-    cw->W = (bf16_t*)ar.take((size_t)2 * cw->N * Cin * 2);
+    cw->W = (op_t*)ar.take((size_t)2 * cw->N * Cin * 2);
     cw->bias = (float*)ar.take((size_t)Cout * 4);
     if (ar.dry) return 0;
     const float *g, *v, *bsrc;
@@ -644,7 +656,7 @@ int make_convT(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int Cin, 
     return 0;
 }
 
-int make_ru(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int C, sat_oobleck_plan::Block& blk, int r, hipStream_t s) {
+int make_ru(OobPlan* p, Arena& ar, const std::string& pfx, int C, OobPlan::Block& blk, int r, hipStream_t s) {
     SAT_TRY(make_snake(p, ar, pfx + "layers.0.", C, &blk.ru_sn1[r], s));
     SAT_TRY(make_conv(p, ar, pfx + "layers.1.", C, C, 7, true, &blk.ru_c7[r], s));
     SAT_TRY(make_snake(p, ar, pfx + "layers.2.", C, &blk.ru_sn2[r], s));
@@ -652,11 +664,11 @@ int make_ru(sat_oobleck_plan* p, Arena& ar, const std::string& pfx, int C, sat_o
     return 0;
 }
 
-int build(sat_oobleck_plan* p, Arena& ar, hipStream_t s) {
+int build(OobPlan* p, Arena& ar, hipStream_t s) {
     const sat_oobleck_cfg& c = p->cfg;
     const int nb = c.n_blocks;
     p->blocks.resize(nb);
-    p->zero_page = (bf16_t*)ar.take(256);
+    p->zero_page = (op_t*)ar.take(256);
     if (!ar.dry) SAT_HIP(hipMemsetAsync(p->zero_page, 0, 256, s));
     if (c.is_decoder) {
         // autoencoders.py:174-191: channel list c_mults=[1]+c_mults ; blocks from deepest to shallowest
@@ -696,10 +708,10 @@ int build(sat_oobleck_plan* p, Arena& ar, hipStream_t s) {
 }
 
 struct Bufs {
-    bf16_t *R, *S0, *S1, *Y;
+    op_t *R, *S0, *S1, *Y;
     size_t total;
 };
-Bufs carve(const sat_oobleck_plan* p, int B, int T, char* base) {
+Bufs carve(const OobPlan* p, int B, int T, char* base) {
     // largest channels-last tensor of the network, in elements per batch item
     const sat_oobleck_cfg& c = p->cfg;
     size_t len = (size_t)T, mx = 0;
@@ -720,15 +732,15 @@ Bufs carve(const sat_oobleck_plan* p, int B, int T, char* base) {
     }
     size_t per = (size_t)round_up((int64_t)(mx * B * 2), 256);
     Bufs o;
-    o.R = (bf16_t*)(base ? base : nullptr);
-    o.S0 = (bf16_t*)(base ? base + per : nullptr);
-    o.S1 = (bf16_t*)(base ? base + 2 * per : nullptr);
-    o.Y = (bf16_t*)(base ? base + 3 * per : nullptr);
+    o.R = (op_t*)(base ? base : nullptr);
+    o.S0 = (op_t*)(base ? base + per : nullptr);
+    o.S1 = (op_t*)(base ? base + 2 * per : nullptr);
+    o.Y = (op_t*)(base ? base + 3 * per : nullptr);
     o.total = 4 * per;
     return o;
 }
 
-ConvArgs base_args(const ConvW& w, const bf16_t* in, int Tin, int M) {
+ConvArgs base_args(const ConvW& w, const op_t* in, int Tin, int M) {
     ConvArgs a{};
     a.zero_page = w.zero;
     a.in = in; a.Tin = Tin; a.Cin = w.Cin; a.W = w.W; a.taps = w.taps; a.N = w.N; a.M = M;
@@ -748,7 +760,7 @@ int launch_ru_fused(const RuArgs& a, int B, hipStream_t s) {
 }
 
 // one ResidualUnit (autoencoders.py:45-68): in S (snaked x) + R (raw x) -> R (raw x') and/or Sout (snake_next(x'))
-int run_ru(const sat_oobleck_plan::Block& blk, int r, int C, int L, int B, bf16_t* R, const bf16_t* S, bf16_t* Y, bf16_t* Sout,
+int run_ru(const OobPlan::Block& blk, int r, int C, int L, int B, op_t* R, const op_t* S, op_t* Y, op_t* Sout,
            const Snake& next, bool need_raw, hipStream_t s) {
     static const int dil[3] = {1, 3, 9};
     ConvArgs a = base_args(blk.ru_c7[r], S, L, L);
@@ -773,14 +785,16 @@ int run_ru(const sat_oobleck_plan::Block& blk, int r, int C, int L, int B, bf16_
 
 }  // namespace
 
-extern "C" int sat_oobleck_plan_create(const sat_oobleck_cfg* cfg, sat_oobleck_plan** out_plan) {
+namespace SAT_OPNS {
+
+int oob_plan_create(const sat_oobleck_cfg* cfg, OobPlan** out_plan) {
     SAT_CHECK_ARG(cfg && out_plan, SAT_E_INVALID, "oobleck_plan_create: null argument");
     SAT_CHECK_ARG(cfg->n_blocks >= 1 && cfg->n_blocks <= 8, SAT_E_UNSUPPORTED, "oobleck_plan_create: n_blocks %d not in 1..8", cfg->n_blocks);
     SAT_CHECK_ARG(cfg->channels % 64 == 0 && cfg->channels > 0, SAT_E_UNSUPPORTED, "oobleck_plan_create: channels %d must be a multiple of 64", cfg->channels);
     SAT_CHECK_ARG(cfg->io_channels >= 1 && cfg->io_channels <= 2, SAT_E_UNSUPPORTED, "oobleck_plan_create: io_channels must be 1 or 2");
     if (cfg->is_decoder)
         SAT_CHECK_ARG(cfg->latent_dim % 64 == 0, SAT_E_UNSUPPORTED, "oobleck_plan_create: decoder latent_dim %d must be a multiple of 64", cfg->latent_dim);
-    sat_oobleck_plan* p = new (std::nothrow) sat_oobleck_plan();
+    OobPlan* p = new (std::nothrow) OobPlan();
     SAT_CHECK_ARG(p, SAT_E_INVALID, "oobleck_plan_create: out of host memory");
     p->cfg = *cfg;
     p->ratio = 1;
@@ -792,19 +806,19 @@ extern "C" int sat_oobleck_plan_create(const sat_oobleck_cfg* cfg, sat_oobleck_p
     return 0;
 }
 
-extern "C" void sat_oobleck_plan_destroy(sat_oobleck_plan* p) {
+void oob_plan_destroy(OobPlan* p) {
     if (!p) return;
     if (p->arena) (void)hipFree(p->arena);
     delete p;
 }
 
-extern "C" int sat_oobleck_plan_set_tensor(sat_oobleck_plan* p, const char* name, const float* data_dev, int64_t numel) {
+int oob_plan_set_tensor(OobPlan* p, const char* name, const float* data_dev, int64_t numel) {
     SAT_CHECK_ARG(p && name && data_dev && numel > 0, SAT_E_INVALID, "oobleck_plan_set_tensor: bad argument");
     p->tensors[name] = {data_dev, numel};
     return 0;
 }
 
-extern "C" int sat_oobleck_plan_finalize(sat_oobleck_plan* p, sat_stream_t stream) {
+int oob_plan_finalize(OobPlan* p, sat_stream_t stream) {
     SAT_CHECK_ARG(p, SAT_E_INVALID, "oobleck_plan_finalize: null plan");
     hipStream_t s = (hipStream_t)stream;
     if (p->arena) {
@@ -825,14 +839,14 @@ extern "C" int sat_oobleck_plan_finalize(sat_oobleck_plan* p, sat_stream_t strea
     return 0;
 }
 
-extern "C" int sat_oobleck_workspace_bytes(const sat_oobleck_plan* p, int32_t b, int32_t t_len, size_t* out_bytes) {
+int oob_workspace_bytes(const OobPlan* p, int32_t b, int32_t t_len, size_t* out_bytes) {
     SAT_CHECK_ARG(p && out_bytes && b > 0 && t_len > 0, SAT_E_INVALID, "oobleck_workspace_bytes: bad argument");
     SAT_CHECK_ARG(p->finalized, SAT_E_STATE, "oobleck_workspace_bytes: plan not finalized");
     *out_bytes = carve(p, b, t_len, nullptr).total;
     return 0;
 }
 
-extern "C" int sat_oobleck_decode(sat_oobleck_plan* p, const float* z, float* audio, int32_t B, int32_t T, void* ws, size_t ws_bytes,
+int oob_decode(OobPlan* p, const float* z, float* audio, int32_t B, int32_t T, void* ws, size_t ws_bytes,
                                   sat_stream_t stream) {
     SAT_CHECK_ARG(p && p->finalized && p->cfg.is_decoder, SAT_E_STATE, "oobleck_decode: not a finalized decoder plan");
     SAT_CHECK_ARG(z && audio && ws && B > 0 && T > 0, SAT_E_INVALID, "oobleck_decode: bad arguments");
@@ -845,8 +859,8 @@ extern "C" int sat_oobleck_decode(sat_oobleck_plan* p, const float* z, float* au
     // latents -> channels-last bf16 (in Y), first conv (autoencoders.py:175) -> S0 = snake_block1(x)
     hipLaunchKernelGGL(cf_to_cl_kernel, dim3(cdiv(T, 64), cdiv(c.latent_dim, 64), B), dim3(256), 0, s, z, bf.Y, c.latent_dim, T);
     SAT_LAUNCH_CHECK();
-    bf16_t* S = bf.S0;
-    bf16_t* Sn = bf.S1;
+    op_t* S = bf.S0;
+    op_t* Sn = bf.S1;
     {
         ConvArgs a = base_args(p->first, bf.Y, T, T);
         a.off0 = -3;
@@ -882,7 +896,7 @@ extern "C" int sat_oobleck_decode(sat_oobleck_plan* p, const float* z, float* au
     return 0;
 }
 
-extern "C" int sat_oobleck_encode(sat_oobleck_plan* p, const float* audio, float* out, int32_t B, int32_t T, void* ws,
+int oob_encode(OobPlan* p, const float* audio, float* out, int32_t B, int32_t T, void* ws,
                                   size_t ws_bytes, sat_stream_t stream) {
     SAT_CHECK_ARG(p && p->finalized && !p->cfg.is_decoder, SAT_E_STATE, "oobleck_encode: not a finalized encoder plan");
     SAT_CHECK_ARG(audio && out && ws && B > 0 && T > 0, SAT_E_INVALID, "oobleck_encode: bad arguments");
@@ -893,8 +907,8 @@ extern "C" int sat_oobleck_encode(sat_oobleck_plan* p, const float* audio, float
     const sat_oobleck_cfg& c = p->cfg;
     const int nb = c.n_blocks;
     int L = T * p->ratio;
-    bf16_t* S = bf.S0;
-    bf16_t* Sn = bf.S1;
+    op_t* S = bf.S0;
+    op_t* Sn = bf.S1;
     hipLaunchKernelGGL(first_conv_kernel, dim3(cdiv(L, 64), B), dim3(256), 0, s, audio, p->first_w_f32, p->first.bias,
                        p->blocks[0].ru_sn1[0].a, p->blocks[0].ru_sn1[0].ib, bf.R, S, c.io_channels, c.channels, L);
     SAT_LAUNCH_CHECK();
@@ -923,3 +937,54 @@ extern "C" int sat_oobleck_encode(sat_oobleck_plan* p, const float* audio, float
     SAT_TRY(launch_conv(a, B, s));
     return 0;
 }
+
+}  // namespace SAT_OPNS
+
+#ifndef SAT_OPERAND_F16
+// ---- C ABI (bf16 build only): the plan's operand format (sat_oobleck_cfg.gemm_dtype, first member of both builds' plan) picks the build
+namespace f16 {
+struct OobPlan;
+int oob_plan_create(const sat_oobleck_cfg* cfg, OobPlan** out_plan);
+void oob_plan_destroy(OobPlan* p);
+int oob_plan_set_tensor(OobPlan* p, const char* name, const float* data_dev, int64_t numel);
+int oob_plan_finalize(OobPlan* p, sat_stream_t stream);
+int oob_workspace_bytes(const OobPlan* p, int32_t b, int32_t t_len, size_t* out_bytes);
+int oob_decode(OobPlan* p, const float* z, float* audio, int32_t B, int32_t T, void* ws, size_t ws_bytes, sat_stream_t stream);
+int oob_encode(OobPlan* p, const float* audio, float* out, int32_t B, int32_t T, void* ws, size_t ws_bytes, sat_stream_t stream);
+}  // namespace f16
+static inline bool oob_f16(const void* p) { return p && static_cast<const sat_oobleck_cfg*>(p)->gemm_dtype == SAT_GEMM_FP16; }
+
+extern "C" int sat_oobleck_plan_create(const sat_oobleck_cfg* cfg, sat_oobleck_plan** out_plan) {
+    SAT_CHECK_ARG(cfg && out_plan, SAT_E_INVALID, "oobleck_plan_create: null argument");
+    SAT_CHECK_ARG(cfg->gemm_dtype == SAT_GEMM_BF16 || cfg->gemm_dtype == SAT_GEMM_FP16, SAT_E_UNSUPPORTED,
+                  "oobleck_plan_create: gemm_dtype must be 0 (bf16) or 3 (fp16)");
+    return cfg->gemm_dtype == SAT_GEMM_FP16 ? f16::oob_plan_create(cfg, reinterpret_cast<f16::OobPlan**>(out_plan))
+                                            : bf16::oob_plan_create(cfg, reinterpret_cast<bf16::OobPlan**>(out_plan));
+}
+extern "C" void sat_oobleck_plan_destroy(sat_oobleck_plan* p) {
+    if (oob_f16(p)) f16::oob_plan_destroy(reinterpret_cast<f16::OobPlan*>(p));
+    else bf16::oob_plan_destroy(reinterpret_cast<bf16::OobPlan*>(p));
+}
+extern "C" int sat_oobleck_plan_set_tensor(sat_oobleck_plan* p, const char* name, const float* data_dev, int64_t numel) {
+    return oob_f16(p) ? f16::oob_plan_set_tensor(reinterpret_cast<f16::OobPlan*>(p), name, data_dev, numel)
+                      : bf16::oob_plan_set_tensor(reinterpret_cast<bf16::OobPlan*>(p), name, data_dev, numel);
+}
+extern "C" int sat_oobleck_plan_finalize(sat_oobleck_plan* p, sat_stream_t stream) {
+    return oob_f16(p) ? f16::oob_plan_finalize(reinterpret_cast<f16::OobPlan*>(p), stream)
+                      : bf16::oob_plan_finalize(reinterpret_cast<bf16::OobPlan*>(p), stream);
+}
+extern "C" int sat_oobleck_workspace_bytes(const sat_oobleck_plan* p, int32_t b, int32_t t_len, size_t* out_bytes) {
+    return oob_f16(p) ? f16::oob_workspace_bytes(reinterpret_cast<const f16::OobPlan*>(p), b, t_len, out_bytes)
+                      : bf16::oob_workspace_bytes(reinterpret_cast<const bf16::OobPlan*>(p), b, t_len, out_bytes);
+}
+extern "C" int sat_oobleck_decode(sat_oobleck_plan* p, const float* z_dev, float* audio_dev, int32_t b, int32_t t_len, void* ws, size_t ws_bytes,
+                                  sat_stream_t stream) {
+    return oob_f16(p) ? f16::oob_decode(reinterpret_cast<f16::OobPlan*>(p), z_dev, audio_dev, b, t_len, ws, ws_bytes, stream)
+                      : bf16::oob_decode(reinterpret_cast<bf16::OobPlan*>(p), z_dev, audio_dev, b, t_len, ws, ws_bytes, stream);
+}
+extern "C" int sat_oobleck_encode(sat_oobleck_plan* p, const float* audio_dev, float* out_dev, int32_t b, int32_t t_len, void* ws, size_t ws_bytes,
+                                  sat_stream_t stream) {
+    return oob_f16(p) ? f16::oob_encode(reinterpret_cast<f16::OobPlan*>(p), audio_dev, out_dev, b, t_len, ws, ws_bytes, stream)
+                      : bf16::oob_encode(reinterpret_cast<bf16::OobPlan*>(p), audio_dev, out_dev, b, t_len, ws, ws_bytes, stream);
+}
+#endif

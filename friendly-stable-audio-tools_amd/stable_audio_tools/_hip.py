@@ -32,7 +32,7 @@ class SatT5Cfg(Structure):
 
 class SatOobleckCfg(Structure):
     _fields_ = [("is_decoder", c_int32), ("io_channels", c_int32), ("channels", c_int32), ("latent_dim", c_int32),
-                ("n_blocks", c_int32), ("c_mults", c_int32 * 8), ("strides", c_int32 * 8)]
+                ("n_blocks", c_int32), ("c_mults", c_int32 * 8), ("strides", c_int32 * 8), ("gemm_dtype", c_int32)]
 
 
 _SIGNATURES = {

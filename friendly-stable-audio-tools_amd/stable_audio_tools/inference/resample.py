@@ -41,7 +41,10 @@ def resample(audio: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor
     if int(orig_freq) == int(new_freq):
         return audio
     if not audio.is_cuda:
-        raise RuntimeError("resample: the HIP path needs a device tensor (there is no CPU fallback)")
+        # the same error type as every other op of this package; the reference would resample on the CPU here (T.Resample follows the
+        # audio's device), this build deliberately has no CPU arithmetic anywhere: move the audio to the model's device first
+        raise _hip.SatError("resample: audio is on the CPU; this package computes on a HIP device only (no CPU path) -- "
+                            "call audio.to(model_device) before prepare_audio / preprocess_audio_list_for_encoder")
     key = (int(orig_freq), int(new_freq), audio.device)
     if key not in _BANKS:
         bank, width, orig, new = sinc_resample_bank(orig_freq, new_freq)

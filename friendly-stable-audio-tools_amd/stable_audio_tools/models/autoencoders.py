@@ -97,10 +97,23 @@ class _OobleckHip(nn.Module):
     """Shared plan handling of encoder and decoder."""
     _is_decoder = False
 
+    gemm_dtype = "bf16"
+
     def _init_plan_state(self):
         self._plan = None
         self._plan_version = None
         self._ws = None
+
+    def set_gemm_dtype(self, dtype: str):
+        """Build extension: 16-bit format of the activations and weights inside the convolution kernels -- "bf16" (default) or "fp16"
+        (IEEE fp16 on the fp16 build of the same kernels: same MFMA rate, 8x less rounding; what the reference's ``model_half`` runs,
+        ``models/pretransforms.py:39-59``).  Parameters stay fp32 in the module; rebuilds the plan on next use."""
+        if dtype not in ("bf16", "fp16"):
+            raise ValueError("the codec kernels take 'bf16' or 'fp16' operands")
+        if dtype != self.gemm_dtype:
+            self.gemm_dtype = dtype
+            self._plan_version = None
+        return self
 
     def __del__(self):
         try:
@@ -129,6 +142,7 @@ class _OobleckHip(nn.Module):
         for i, (c, s) in enumerate(zip(self.c_mults, self.strides)):
             cfg.c_mults[i] = c
             cfg.strides[i] = s
+        cfg.gemm_dtype = 3 if self.gemm_dtype == "fp16" else 0          # SAT_GEMM_FP16 / SAT_GEMM_BF16 (include/sat_hip.h)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_oobleck_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
         keep = []
@@ -240,6 +254,13 @@ class AudioAutoencoder(nn.Module):
         self.pretransform = pretransform
         self.soft_clip = soft_clip
         self.is_discrete = self.bottleneck and self.bottleneck.is_discrete
+
+    def set_gemm_dtype(self, dtype: str):
+        """"bf16" | "fp16" for the encoder and decoder kernels (see ``_OobleckHip.set_gemm_dtype``)."""
+        for part in (self.encoder, self.decoder):
+            if isinstance(part, _OobleckHip):
+                part.set_gemm_dtype(dtype)
+        return self
 
     # autoencoders.py:268-304
     def encode(self, audio, return_info=False, skip_pretransform=False, iterate_batch=False, **kwargs):

@@ -2,8 +2,8 @@
 
 Counterpart of the reference's ``models/pretransforms.py:6-91`` (``Pretransform`` / ``AutoencoderPretransform``): same class
 names, constructor arguments and attributes, because ``create_pretransform_from_config``, ``generate_diffusion_cond`` and
-reference checkpoints (key prefix ``pretransform.model.``) rely on them.  The fp16 switch (``model_half``) of the reference has
-no counterpart: the codec kernels store activations in bf16 on their own.
+reference checkpoints (key prefix ``pretransform.model.``) rely on them.  ``model_half`` (pretransforms.py:39-59: the codec in fp16)
+selects the fp16 build of the codec kernels; parameters, inputs and outputs stay fp32 as the reference's ``.float()`` leaves them.
 """
 from torch import nn
 
@@ -30,12 +30,12 @@ class AutoencoderPretransform(Pretransform):
     (pretransforms.py:62, :65); ``chunked`` / ``iterate_batch`` are forwarded to the codec's ``encode_audio`` / ``decode_audio``."""
 
     def __init__(self, model, scale=1.0, model_half=False, iterate_batch=False, chunked=False):
-        if model_half:
-            raise NotImplementedError("model_half: the HIP codec already stores activations in bf16; fp16 mode is not provided")
         bottleneck = model.bottleneck
         super().__init__(enable_grad=False, io_channels=model.io_channels, is_discrete=bool(bottleneck is not None and bottleneck.is_discrete))
         self.model = model.requires_grad_(False).eval()
-        self.scale, self.model_half, self.iterate_batch, self.chunked = scale, False, iterate_batch, chunked
+        self.scale, self.model_half, self.iterate_batch, self.chunked = scale, bool(model_half), iterate_batch, chunked
+        if self.model_half:
+            self.model.set_gemm_dtype("fp16")
         for attr, value in (("downsampling_ratio", model.downsampling_ratio), ("sample_rate", model.sample_rate),
                             ("encoded_channels", model.latent_dim), ("num_quantizers", None), ("codebook_size", None)):
             setattr(self, attr, value)

@@ -217,6 +217,9 @@ typedef struct sat_oobleck_cfg {
     int32_t n_blocks;          /* len(strides) (5) */
     int32_t c_mults[8];        /* WITHOUT the implicit leading 1: e.g. {1,2,4,8,16} */
     int32_t strides[8];        /* e.g. {2,4,4,8,8} */
+    int32_t gemm_dtype;        /* SAT_GEMM_BF16 (0): bf16 activations / weights in the convolutions; SAT_GEMM_FP16 (3): IEEE fp16 (the
+                                  reference's `model_half`, models/pretransforms.py:39-59: encoder / decoder in half precision) -- the
+                                  fp16 build of the same kernels, same MFMA rate, saturating conversions; fp32 accumulation either way */
 } sat_oobleck_cfg;
 
 int sat_oobleck_plan_create(const sat_oobleck_cfg* cfg, sat_oobleck_plan** out_plan);

@@ -14,7 +14,7 @@ Tolerances (bf16 GEMM operands, fp32 accumulate / residual / LN / softmax):
 import pytest
 import torch
 
-from util import assert_close, bf16_round, rel_l2
+from util import assert_close, bf16_round, fp16_round, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -349,41 +349,57 @@ def small_vae(dev):
     return cfg, model, sd
 
 
+# codec gates per operand format: (vs the fp32 oracle / reference, vs the matched-rounding oracle); fp16 = bf16 / 4 (8x less rounding, 2x margin)
+CODEC = {"bf16": (bf16_round, 1.5e-2, 1e-2), "fp16": (fp16_round, 3.75e-3, 2.5e-3)}
+
+
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
 @pytest.mark.parametrize("b,t_len", [(1, 43), (2, 8), (1, 1)])
-def test_oobleck_decode(dev, small_vae, b, t_len):
+def test_oobleck_decode(dev, small_vae, b, t_len, fmt):
     from oracle import oobleck as oob
     from stable_audio_tools import synthetic
     cfg, model, sd = small_vae
+    rnd, tol_f, tol_m = CODEC[fmt]
     strides = cfg["model"]["decoder"]["config"]["strides"]
     z = synthetic.synth_input("z", (b, 64, t_len), 11)
-    got = model.decode(z.to(dev))
+    model.set_gemm_dtype(fmt)
+    try:
+        got = model.decode(z.to(dev))
+    finally:
+        model.set_gemm_dtype("bf16")
     dsd = _sub(sd, "decoder.")
     want_f = oob.oobleck_decoder(dsd, z, strides=strides)
-    want_m = oob.oobleck_decoder(dsd, z, strides=strides, rnd=bf16_round)
+    want_m = oob.oobleck_decoder(dsd, z, strides=strides, rnd=rnd)
     assert got.shape == want_f.shape
-    e_f = assert_close("decode vs fp32 oracle", got, want_f, 1.5e-2)
-    e_m = assert_close("decode vs matched oracle", got, want_m, 1e-2)
-    print(f"\n[decode b={b} T={t_len}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
+    e_f = assert_close("decode vs fp32 oracle", got, want_f, tol_f)
+    e_m = assert_close("decode vs matched oracle", got, want_m, tol_m)
+    print(f"\n[decode b={b} T={t_len}, {fmt}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
 @pytest.mark.parametrize("b,t_len", [(1, 21), (2, 4)])
-def test_oobleck_encode_and_vae(dev, small_vae, b, t_len):
+def test_oobleck_encode_and_vae(dev, small_vae, b, t_len, fmt):
     from oracle import oobleck as oob
     from stable_audio_tools import synthetic
     cfg, model, sd = small_vae
+    rnd, tol_f, tol_m = CODEC[fmt]
     strides = cfg["model"]["encoder"]["config"]["strides"]
     ratio = cfg["model"]["downsampling_ratio"]
     audio = synthetic.synth_input("a", (b, 2, t_len * ratio), 12, 0.4)
-    got = model.encoder(audio.to(dev))
     esd = _sub(sd, "encoder.")
     want_f = oob.oobleck_encoder(esd, audio, strides=strides)
-    want_m = oob.oobleck_encoder(esd, audio, strides=strides, rnd=bf16_round)
-    e_f = assert_close("encode vs fp32 oracle", got, want_f, 1.5e-2)
-    e_m = assert_close("encode vs matched oracle", got, want_m, 1e-2)
-    print(f"\n[encode b={b} T={t_len}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
+    want_m = oob.oobleck_encoder(esd, audio, strides=strides, rnd=rnd)
     noise = synthetic.synth_input("vn", (b, 64, t_len), 13)
-    z = model.encode(audio.to(dev), noise=noise.to(dev))
-    assert_close("encode+vae_sample", z, oob.vae_sample(want_f, noise), 1.5e-2)
+    model.set_gemm_dtype(fmt)
+    try:
+        got = model.encoder(audio.to(dev))
+        z = model.encode(audio.to(dev), noise=noise.to(dev))
+    finally:
+        model.set_gemm_dtype("bf16")
+    e_f = assert_close("encode vs fp32 oracle", got, want_f, tol_f)
+    e_m = assert_close("encode vs matched oracle", got, want_m, tol_m)
+    print(f"\n[encode b={b} T={t_len}, {fmt}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
+    assert_close("encode+vae_sample", z, oob.vae_sample(want_f, noise), tol_f)
 
 
 def test_generate_diffusion_cond_small(dev, small_dit):
@@ -853,7 +869,8 @@ def test_fp8_full_width_slice_vs_matched_oracle(dev):
     print(f"\n[fp8 full-width 2-layer slice] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
 
 
-def test_full_size_decoder_vs_reference_golden(dev):
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
+def test_full_size_decoder_vs_reference_golden(dev, fmt):
     """BASELINE config 1 shape: full-size Oobleck decoder, z[1,64,43] -> [1,2,88064], vs the reference's fp32 output."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
@@ -865,14 +882,14 @@ def test_full_size_decoder_vs_reference_golden(dev):
     with _init.skip_init():
         dec = OobleckDecoder(**cases.vae_kwargs(cases.FULL_VAE, True))
     dec.load_state_dict(synthetic.synth_state_dict(dec.state_dict(), 0))
-    got = dec.to(dev)(synthetic.synth_input("z_full", (1, 64, 43), 1).to(dev))
-    e = assert_close("full-size decode vs reference", got, g["full_decode_T43"], 1.5e-2)
+    got = dec.to(dev).set_gemm_dtype(fmt)(synthetic.synth_input("z_full", (1, 64, 43), 1).to(dev))
+    e = assert_close("full-size decode vs reference", got, g["full_decode_T43"], CODEC[fmt][1])
     with _init.skip_init():
         enc = OobleckEncoder(**cases.vae_kwargs(cases.FULL_VAE, False))
     enc.load_state_dict(synthetic.synth_state_dict(enc.state_dict(), 0))
-    got = enc.to(dev)(synthetic.synth_input("a_full", (1, 2, 2048 * 16), 2, 0.3).to(dev))
-    e2 = assert_close("full-size encode vs reference", got, g["full_encode_T16"], 1.5e-2)
-    print(f"\n[full codec] decode rel-L2 {e:.2e}, encode rel-L2 {e2:.2e} vs the reference's fp32 output")
+    got = enc.to(dev).set_gemm_dtype(fmt)(synthetic.synth_input("a_full", (1, 2, 2048 * 16), 2, 0.3).to(dev))
+    e2 = assert_close("full-size encode vs reference", got, g["full_encode_T16"], CODEC[fmt][1])
+    print(f"\n[full codec, {fmt}] decode rel-L2 {e:.2e}, encode rel-L2 {e2:.2e} vs the reference's fp32 output")
 
 
 def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
