@@ -172,40 +172,71 @@ __device__ __forceinline__ void ph8_tile_of(const Ph8Sched& sc, int id, int& tm,
 }
 
 // fp32 output / residual update of ONE token row piece (transformer.py:692-700), adaLN gate (:674, 688), and the producer side of the
-// LayerNorm fold: bf16 image of the updated row + (sum, sum of squares) of the ROUNDED values over the wave's 64-column block.
+// LayerNorm fold: 16-bit image of the updated row + (sum, sum of squares) of the ROUNDED values over the wave's 64-column block.
 // v[nb] = the accumulators of channels ncol0 + 16 nb + 4 q4 .. + 3 of token row m (lane (l15, q4) of a transposed 16 x 16 block).
 // `old` = the residual values of the same pieces, loaded by the caller in batches (ph8_load_resid): one load -> use -> store round trip
 // per row block would serialise eight memory latencies per tile (measured: 17 us of epilogue per tile at 8 prompts).
-__device__ __forceinline__ void ph8_load_resid(const GemmArgs& g, f32x4_t (&old)[4], int m, int ncol0, int q4) {
-    const int mc = m < g.M ? m : g.M - 1;
-    const float* __restrict__ crow = g.C + (size_t)mc * g.ldc + ncol0 + 4 * q4;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) old[nb] = g.accumulate ? *reinterpret_cast<const f32x4_t*>(crow + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+// Every access goes through a buffer descriptor whose range ends at row M: rows beyond M read zeros and drop their stores in
+// hardware, so the code is straight-line -- no exec-masked branch around a store, and the compiler can COUNT the outstanding
+// vector-memory operations (vmcnt) instead of draining them all whenever the next batch's loads are already in flight (round 4).
+struct Ph8F32Epi {
+    __amdgpu_buffer_rsrc_t rsC, rsXb, rsPart;
+    int ldc, N;
+    bool accumulate, prod;
+    const float* gate;
+    int gate_rows, gate_ld, M;
+};
+__device__ __forceinline__ Ph8F32Epi ph8_f32_epi(const GemmArgs& g) {
+    Ph8F32Epi e;
+    e.rsC = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, 0, (int)((unsigned)g.M * (unsigned)g.ldc * 4u), 0x00020000);
+    e.rsXb = __builtin_amdgcn_make_buffer_rsrc((void*)g.xb, 0, g.xb ? (int)((unsigned)g.M * (unsigned)g.N * 2u) : 0, 0x00020000);
+    e.rsPart = __builtin_amdgcn_make_buffer_rsrc((void*)g.ln_part_out, 0, g.ln_part_out ? (int)((unsigned)g.M * (unsigned)(g.N >> 6) * 8u) : 0, 0x00020000);
+    e.ldc = g.ldc; e.N = g.N; e.accumulate = g.accumulate != 0; e.prod = g.xb != nullptr;
+    e.gate = g.gate; e.gate_rows = g.gate_rows; e.gate_ld = g.gate_ld; e.M = g.M;
+    return e;
 }
-__device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[4], const f32x4_t (&old)[4], const f32x4_t (&bia)[4], int m, int ncol0,
-                                                int q4) {
-    const int M = g.M, N = g.N;
-    const bool prod = g.xb != nullptr;
-    const int mc = m < M ? m : M - 1;
-    float* __restrict__ crow = g.C + (size_t)mc * g.ldc + ncol0 + 4 * q4;
-    const float* grow = g.gate ? g.gate + (size_t)(mc / g.gate_rows) * g.gate_ld + ncol0 + 4 * q4 : nullptr;
+typedef unsigned int ph8_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int ph8_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ph8_load_resid(const Ph8F32Epi& e, f32x4_t (&old)[4], int m, int ncol0, int q4) {
+    const int off = (m * e.ldc + ncol0 + 4 * q4) * 4;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+        old[nb] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(e.rsC, off + nb * 64, 0, 0));      // (always issued: a uniform branch
+}                                                                                                                       //  here would hide the count)
+// RT = true: gate / producer decided at run time (the adaLN path and the reduce kernel: uniform branches, conservative waits);
+// RT = false: no gate, PROD compile-time -- the straight-line code the pipelined tile epilogue needs
+template <bool RT, bool PROD_C>
+__device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t (&v)[4], const f32x4_t (&old)[4], int m, int ncol0, int q4) {
+    const int off = (m * e.ldc + ncol0 + 4 * q4) * 4;
+    [[maybe_unused]] const float* grow = nullptr;
+    bool prod = PROD_C;
+    if constexpr (RT) {
+        prod = e.prod;
+        if (e.gate) {
+            const int mc = m < e.M ? m : e.M - 1;
+            grow = e.gate + (size_t)(mc / e.gate_rows) * e.gate_ld + ncol0 + 4 * q4;
+        }
+    }
     float sum = 0.f, sq = 0.f;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-        f32x4_t x = v[nb] + bia[nb];
-        if (grow) x *= *reinterpret_cast<const f32x4_t*>(grow + nb * 16);
-        x += old[nb];
-        if (m < M) *reinterpret_cast<f32x4_t*>(crow + nb * 16) = x;
+        f32x4_t x = v[nb];          // (the bias is already in: the accumulators of a whole tile start from it, the reduce kernel adds it to its sums)
+        if constexpr (RT) {
+            if (grow) x *= *reinterpret_cast<const f32x4_t*>(grow + nb * 16);
+        }
+        const f32x4_t o = old[nb];
+        x += e.accumulate ? o : f32x4_t{0.f, 0.f, 0.f, 0.f};          // (a select on the loaded value, not a branch around the load)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ph8_u32x4, x), e.rsC, off + nb * 64, 0, 0);
         if (prod) {
             opx4 xr;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                xr[e] = f32_to_op(x[e]);
-                const float f = op_to_f32(xr[e]);
+            for (int k = 0; k < 4; ++k) {
+                xr[k] = f32_to_op(x[k]);
+                const float f = op_to_f32(xr[k]);
                 sum += f;
                 sq += f * f;
             }
-            if (m < M) *reinterpret_cast<opx4*>(g.xb + (size_t)m * N + ncol0 + 4 * q4 + nb * 16) = xr;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ph8_u32x2, xr), e.rsXb, (m * e.N + ncol0 + 4 * q4 + nb * 16) * 2, 0, 0);
         }
     }
     if (prod) {       // add the four lanes (q4 = 0..3) that share the token row
@@ -215,8 +246,9 @@ __device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[
         u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
         sum = __uint_as_float(a[0]) + __uint_as_float(a[1]);
         sq = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-        if (q4 == 0 && m < M)
-            *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (N >> 6) + (ncol0 >> 6)) * 2) = make_float2(sum, sq);
+        // lanes q4 != 0 aim beyond the descriptor's range: their store is dropped (no branch)
+        const int poff = q4 == 0 ? (m * (e.N >> 6) + (ncol0 >> 6)) * 8 : 0x7ffffff0;
+        __builtin_amdgcn_raw_buffer_store_b64(ph8_u32x2{__float_as_uint(sum), __float_as_uint(sq)}, e.rsPart, poff, 0, 0);
     }
 }
 
@@ -235,7 +267,10 @@ __device__ __forceinline__ void ph8_epi_f32_row(const GemmArgs& g, f32x4_t (&v)[
 // One v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales, twice the bf16 MFMA rate) consumes a whole row of the K-tile: a lane's 32
 // operand bytes are logical chunks 2 q and 2 q + 1 of its row, loaded identically for A and W, so the instruction's internal k order does
 // not matter.  The fp32 accumulators are multiplied by a_scale[token] * w_scale[channel] in front of the epilogue.
-template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0>
+// GATED (fp32 output only): the adaLN build of the residual epilogue -- (acc + bias) * gate[sequence] before the add
+// (transformer.py:674, 688).  A kernel of its own: a second copy of the straight-line epilogue inside one kernel made the register
+// allocator spill, a uniform branch inside it hides the vmcnt bookkeeping.
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0, bool GATED = false>
 __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
     sat_f16_saturate();
     constexpr int NW = 2 * WN, NT = NW * 64;
@@ -667,18 +702,34 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         [[maybe_unused]] const float* lc1 = reinterpret_cast<const float*>(smem + RING_BYTES + lb * LN_BYTES + BM * 8) + wc * 64;
         [[maybe_unused]] const float* lc2 = lc1 + BN;
         if constexpr (EPI == EPI_F32) {
-            f32x4_t bia[4];
+            // Batches of two row blocks, double-buffered: the residual loads of batch h + 1 are issued before batch h is finished, so 16
+            // loads per lane are in flight instead of 8 (the fragment registers are dead here).  The read-modify-write of X is latency-
+            // bound per CU -- 640 KB per tile in four dependent round trips took 17 us of a 54-us tile at 8 prompts
+            // (profiles/r03_ph8_ksweep_fixed_overhead.txt) -- and every load in flight is time off that.
+            const Ph8F32Epi fe = ph8_f32_epi(g);
+            auto run = [&](auto rt_c, auto prod_c) {
+                constexpr bool RT = decltype(rt_c)::value, PROD = decltype(prod_c)::value;
+                f32x4_t old[2][2][4];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 2; ++i) ph8_load_resid(fe, old[0][i], mrow0 + i * 16, ncol0, q4);
 #pragma unroll
-            for (int h = 0; h < MB / 2; ++h) {     // batches of two row blocks: 8 residual loads in flight (a batch of four spills)
-                f32x4_t old[2][4];
+                for (int h = 0; h < MB / 2; ++h) {
+                    if (h + 1 < MB / 2) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) ph8_load_resid(g, old[i], mrow0 + (h * 2 + i) * 16, ncol0, q4);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) ph8_epi_f32_row(g, acc[h * 2 + i], old[i], bia, mrow0 + (h * 2 + i) * 16, ncol0, q4);
-            }
+                        for (int i = 0; i < 2; ++i) ph8_load_resid(fe, old[(h + 1) & 1][i], mrow0 + ((h + 1) * 2 + i) * 16, ncol0, q4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // (two batches in flight, not four: straight-line code lets the scheduler hoist every
+#pragma unroll                                                  //  load to the top, which is 128 registers of residual next to 128 accumulators)
+                    for (int i = 0; i < 2; ++i) ph8_epi_f32_row<RT, PROD>(fe, acc[h * 2 + i], old[h & 1][i], mrow0 + (h * 2 + i) * 16, ncol0, q4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // (compile-time variants of the common cases: a wave-uniform branch inside the batch loop hides the number of outstanding
+            // stores from the compiler's vmcnt bookkeeping and brings the drain-everything waits back.  adaLN's gated update keeps them.)
+            // Without a producer role (no xb / ln_part_out) the same code runs: those descriptors then have an empty range and the
+            // hardware drops the stores -- a second straight-line copy next to this one made the register allocator spill.
+            if constexpr (GATED) run(std::true_type{}, std::false_type{});
+            else run(std::false_type{}, std::true_type{});
         } else if constexpr (EPI == EPI_SWIGLU) {
             // H = (v + b_v) * silu(gate + b_g) (transformer.py:232-235): value rows are channels [0, 32) of the wave's 64, gate rows
             // [32, 64) (pack_rows interleave); PERM 1 puts value and gate of hidden columns hc0 + 8 q4 + 4 nf + r into this lane
@@ -855,10 +906,24 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     int lb = 0;
     prepare(cur, lb);
     while (true) {
+        {
+            // fp32 output: the accumulators of a WHOLE tile start from the bias (lane (l15, q4) owns channels 16 nb + 4 q4 .. + 3 of every
+            // row block) -- sixteen registers the epilogue then does not need next to its residual batches; a partial K-range starts
+            // from zero, ph8_reduce_f32_kernel adds the bias to the sums
+            f32x4_t b0[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if constexpr (EPI == EPI_F32) {
+                if (g.bias && cur.whole) {
+                    int q4 = q4_;
+                    asm volatile("" : "+v"(q4));
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
+                    for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const f32x4_t*>(g.bias + cur.n0 + wc * 64 + 4 * q4 + j * 16);
+                }
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = b0[j];
+        }
         // the range's first tiles have landed (and the previous epilogue's stores are out); LayerNorm constants are visible
         wait_vmcnt<0>();
         wait_lgkmcnt<0>();
@@ -883,8 +948,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         const bool more = next_seg(nxt);
         if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
         bool fin = true;
-        if (!cur.whole) {           // a part of a K-split tile (fp32 output): plain stores of the raw accumulators, the kernel boundary publishes
-            float* mine = sc.sk_slab + (size_t)wgi * (BM * BN) + (size_t)(wave * MB * 4) * 256 + lane * 4;       // them to ph8_reduce_f32_kernel
+        if (EPI == EPI_F32 && !cur.whole) {           // a part of a K-split tile (fp32 output only): plain stores of the raw accumulators, the kernel
+            int lane_l = lane;                            // boundary publishes them to ph8_reduce_f32_kernel
+            asm volatile("" : "+v"(lane_l));              // (keeps the per-lane slab address out of the state carried across the main loop)
+            float* mine = sc.sk_slab + (size_t)wgi * (BM * BN) + (size_t)(wave * MB * 4) * 256 + lane_l * 4;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -933,9 +1000,12 @@ __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sche
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
         bia[nb] = g.bias ? *reinterpret_cast<const f32x4_t*>(g.bias + ncol0 + 4 * q4 + nb * 16) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) v[nb] += bia[nb];
     f32x4_t old[4];
-    ph8_load_resid(g, old, m, ncol0, q4);
-    ph8_epi_f32_row(g, v, old, bia, m, ncol0, q4);
+    const Ph8F32Epi fe = ph8_f32_epi(g);
+    ph8_load_resid(fe, old, m, ncol0, q4);
+    ph8_epi_f32_row<true, false>(fe, v, old, m, ncol0, q4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -974,6 +1044,12 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
     const long t_full = (long)s.tiles_m_full * s.tiles_n, t_light = s.light ? s.tiles_n : 0;
     const long t_all = t_full + t_light;
     s.G = (int)std::min<long>((long)cus * wgs_per_cu, split ? t_all * s.nkp : t_all);
+    // Balanced rounds: a launch of more than one and at most two rounds runs on FEWER workgroups, every one with two tiles (390 tiles:
+    // 2 x 195 instead of 256 + 134; FF-in at one prompt: 2 x 216, which is also what the vendor library's stream-K launches for this
+    // shape).  The chip is power-limited under MFMA load -- a tile runs faster when fewer CUs are active -- so the idle CUs cost
+    // less than a half-empty second round: FF-out at 8 prompts 336 -> 311 us, FF-in at one prompt 85.4 -> 82.6 us.  With many rounds it
+    // loses (FF-in at 8 prompts, 12.2 rounds: 479 -> 488 us): profiles/r04_ph8_balanced_rounds.txt.  Variant bit 21 switches it off (A/B).
+    if (!split && !(a.variant & 0x200000) && t_all > s.G && t_all <= 2L * s.G) s.G = (int)((t_all + 1) / 2);
     s.dp_rounds = (int)((split ? t_all : t_full) / s.G);
     // K-split with at least one whole round: the light tiles go FIRST (they idle their workgroup for half of round 0 -- a handful of
     // them) so that the remainder round holds full tiles only and splits evenly
@@ -1015,7 +1091,7 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
 unsigned long long* g_ts_buf = nullptr;
 #endif
 
-template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0>
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0, bool GATED = false>
 int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if constexpr (FP8 != 0) {
@@ -1033,6 +1109,8 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of %d", a.N, BN);
     SAT_CHECK_ARG(a.K % 128 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): K=%d must be a multiple of 128", a.K);
     SAT_CHECK_ARG((uint64_t)a.M * (uint64_t)a.K * 2u < (1ull << 31), SAT_E_UNSUPPORTED, "gemm(8-phase): A larger than 2 GiB");
+    if constexpr (EPI == EPI_F32)         // the epilogue addresses C / xb / ln_part through buffer descriptors with 32-bit byte offsets
+        SAT_CHECK_ARG(((uint64_t)a.M + 256) * (uint64_t)a.ldc * 4u < (1ull << 31) && a.ldc >= a.N, SAT_E_UNSUPPORTED, "gemm(8-phase): C larger than 2 GiB");
     constexpr bool LN_CONS = EPI == EPI_SWIGLU || EPI == EPI_HEADS;
     SAT_CHECK_ARG(LN_CONS || !a.ln_part, SAT_E_UNSUPPORTED, "gemm(8-phase): the LayerNorm fold is finished by the SwiGLU / heads epilogues");
     SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (EPI == EPI_F32 && a.xb && a.ln_part_out), SAT_E_UNSUPPORTED,
@@ -1048,7 +1126,8 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements, tests)
     const int split = (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;
     SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, BM, BN, BM == 256 ? 1 : 2, sc));
-    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ, FP8>;
+    SAT_CHECK_ARG(GATED == (a0.gate != nullptr), SAT_E_INVALID, "gemm(8-phase): gated / plain build mismatch");
+    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ, FP8, GATED>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     unsigned long long* ts = nullptr;
 #ifdef SAT_GEMM_EXPERIMENTS
@@ -1130,6 +1209,7 @@ int SAT_OPNS::sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream
                     if (a.variant & 0x40000) return launch_ph8<EPI_F32, 0, false>(a, stream);          // bit 18: the four-phase loop (A/B)
                     if (a.variant & 0x80000) return launch_ph8<EPI_F32, 0, true, 2>(a, stream);        // bit 19: W-hi issued one phase earlier
 #endif
+                    if (a.gate) return launch_ph8<EPI_F32, 0, true, 1, 4, 4, 0, true>(a, stream);          // adaLN
                     return launch_ph8<EPI_F32>(a, stream);
 #ifdef SAT_GEMM_EXPERIMENTS
                 case 1: return launch_ph8<EPI_F32, 1, false>(a, stream);

@@ -1,0 +1,47 @@
+"""Build-time guard (CPU, hipcc cross-compiles): the register budgets the kernel designs rest on.
+
+The 8-phase GEMM runs 8 waves of 256 registers with NO scratch -- one hoisted address pair is enough to push a handful of values
+into private memory around the main loop (it happened in round 4 when the schedule moved into the kernel arguments); the attention
+kernel's two-KV-group layout needs <= 128 VGPRs for its four waves per SIMD.  Both operand builds are checked."""
+import os
+import re
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "friendly-stable-audio-tools_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _kernels(src, defines, tmp_path):
+    out = os.path.join(tmp_path, "k.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out] + defines,
+                   check=True, capture_output=True)
+    text = open(out).read()
+    meta = {}
+    for blk in text.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1)) for k in ("vgpr_count", "vgpr_spill_count", "private_segment_fixed_size")}
+    return meta
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("defines", [[], ["-DSAT_OPERAND_F16"]], ids=["bf16", "f16"])
+def test_ph8_kernels_use_no_scratch(defines, tmp_path):
+    meta = _kernels("gemm_ph8.hip", defines, str(tmp_path))
+    ph8 = {k: v for k, v in meta.items() if "gemm_ph8_kernel" in k}
+    assert len(ph8) >= 3, sorted(meta)
+    for name, m in ph8.items():
+        assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{name}: {m}"
+        assert m["vgpr_count"] <= 256, f"{name}: {m}"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("defines", [[], ["-DSAT_OPERAND_F16"]], ids=["bf16", "f16"])
+def test_attention_kernels_fit_four_waves_per_simd(defines, tmp_path):
+    meta = _kernels("attention.hip", defines, str(tmp_path))
+    att = {k: v for k, v in meta.items() if "attention_kernel" in k}
+    assert att, sorted(meta)
+    for name, m in att.items():
+        assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{name}: {m}"
+        assert m["vgpr_count"] <= 128, f"{name}: {m}"

@@ -32,7 +32,18 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
+_WS = {}
+
+
 def gemm_fn(a, w, c, m, n, k, v, accumulate=0, bias=None):
+    if v & 0x10000 or v == 0:          # K-split of the remainder round: slabs in caller-supplied scratch
+        import ctypes
+        need = ctypes.c_size_t()
+        _hip.check(lib.sat_gemm_f32_workspace_bytes(m, n, k, v, ctypes.byref(need)))
+        if need.value:
+            ws = _WS.setdefault(need.value, torch.empty(need.value, dtype=torch.uint8, device=dev))
+            return lambda: _hip.check(lib.sat_gemm_bf16_f32_ws(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias) if bias is not None else None, _hip.ptr(c), m, n, k,
+                                                                accumulate, v, _hip.ptr(ws), need.value, _hip.stream()))
     return lambda: _hip.check(lib.sat_gemm_bf16_f32(_hip.ptr(a), _hip.ptr(w), _hip.ptr(bias) if bias is not None else None, _hip.ptr(c), m, n, k,
                                                      accumulate, v, _hip.stream()))
 
@@ -95,6 +106,81 @@ def shapes():
     for name, m, n, k in [("ff_in B1", 2050, 12288, 1536), ("qkv B1", 2050, 4608, 1536), ("ff_out B1", 2050, 1536, 6144), ("ff_in B8", 16400, 12288, 1536),
                           ("qkv B8", 16400, 4608, 1536), ("ff_out B8", 16400, 1536, 6144), ("to_out B8", 16400, 1536, 1536), ("ff_in sa2", 12290, 12288, 1536)]:
         arms_bench(name, m, n, k, [22, 80], blas=False, rounds=4)
+
+
+def libcal():
+    """the vendor library (hipBLASLt through torch.matmul, bf16 output -- its cheapest epilogue) against this build's
+    plain fp32-output GEMM (launcher's choice, the 8-phase tile, and the narrow tiles) on the PRODUCT's shapes, interleaved in one process"""
+    shapes = []
+    for mname, m in (("B1", 2050), ("B8", 16400), ("sa2", 12290), ("cross B1", 1025)):
+        for nname, n, k in (("ff_in", 12288, 1536), ("qkv", 4608, 1536), ("to_out", 1536, 1536), ("ff_out", 1536, 6144)):
+            if mname == "cross B1" and nname != "to_out":
+                continue
+            shapes.append((f"{nname} {mname}", m, n, k))
+    for name, m, n, k in shapes:
+        vs = [0, 80 | 0x20000]
+        if m <= 2050:
+            vs += [15, 16, 30] if n % 192 == 0 else [15, 16]
+            if k >= 4096:
+                vs += [44, 80 | 0x10000]
+        arms_bench("libcal " + name, m, n, k, vs, rounds=4, iters=10)
+    arms_bench("libcal 4096^3", 4096, 4096, 4096, [80], rounds=3, iters=6)
+    arms_bench("libcal 8192^3", 8192, 8192, 8192, [80], rounds=3, iters=3)
+
+
+def balance(bit=0x200000):
+    """schedule A/B on the real epilogues: every CU a workgroup (256 + remainder) vs balanced rounds on fewer workgroups (variant bit 21)"""
+    def ab(label, mk, flops, arms, rounds=5):
+        fs = {k_: mk(v) for k_, v in arms.items()}
+        res = {k_: [] for k_ in fs}
+        for _ in range(rounds):
+            for k_, f in fs.items():
+                res[k_].append(timeit(f, iters=10, warm=2))
+        print(f"balance {label:42s} " + " | ".join(f"{k_} {statistics.median(t)*1e3:7.1f} us {flops/statistics.median(t)/1e9:7.1f} TF" for k_, t in res.items()), flush=True)
+
+    for name, m in [("B1", 2050), ("B4", 8200), ("B8", 16400), ("sa2", 12290)]:
+        n, k = 12288, 1536
+        xb = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        part = torch.stack([xb.float().view(m, k // 64, 64).sum(-1), (xb.float() ** 2).view(m, k // 64, 64).sum(-1)], -1).contiguous()
+        w = torch.randn(n, k, device=dev) * 0.05
+        gamma = 0.8 + 0.2 * torch.rand(k, device=dev)
+        beta = 0.1 * torch.randn(k, device=dev)
+        bias = torch.randn(n, device=dev) * 0.1
+        wp = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
+        c12 = torch.empty((2 * n,), dtype=torch.float32, device=dev)
+        out = torch.empty((m, n // 2), dtype=torch.bfloat16, device=dev)
+        _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(bias), _hip.ptr(wp),
+                                               _hip.ptr(c12), _hip.ptr(out), m, n, k, 80, _hip.stream()))
+        ab(f"ff_in swiglu+ln {name} {m}x{n}x{k}",
+           lambda v: (lambda: _hip.check(lib.sat_gemm_swiglu_ln_bf16(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(bias),
+                                                                       _hip.ptr(wp), _hip.ptr(c12), _hip.ptr(out), m, n, k, v | 0x4000, _hip.stream()))),
+           2.0 * m * n * k, {"all CUs": 80, "balanced": 80 | bit})
+        for nm, kk in [("ff_out", 6144), ("to_out", 1536)]:
+            nn = 1536
+            a = torch.randn(m, kk, device=dev).to(torch.bfloat16)
+            w2 = (torch.randn(nn, kk, device=dev) * 0.05).to(torch.bfloat16)
+            b2 = torch.randn(nn, device=dev)
+            c = torch.zeros(m, nn, device=dev)
+            xo = torch.empty((m, nn), dtype=torch.bfloat16, device=dev)
+            po = torch.empty((m, nn // 64, 2), dtype=torch.float32, device=dev)
+            ab(f"{nm} resid+ln {name} {m}x{nn}x{kk}",
+               lambda v: (lambda: _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, nn, kk, v,
+                                                                          _hip.stream()))), 2.0 * m * nn * kk,
+               {"launcher": 0, "v22": 22, "v80 all CUs": 80 | 0x20000, "v80 balanced": 80 | 0x20000 | bit})
+    for name, b in [("B1", 2), ("B8", 16), ("sa2", 2)]:
+        s_len = 6145 if name == "sa2" else 1025
+        s_pad, d = (s_len + 3 + 127) // 128 * 128, 1536
+        a = torch.randn(b * s_len, d, device=dev).to(torch.bfloat16)
+        w = (torch.randn(3 * d, d, device=dev) * 0.05).to(torch.bfloat16)
+        inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+        q = torch.empty((b, 24, s_pad, 64), dtype=torch.bfloat16, device=dev)
+        kk = torch.empty_like(q)
+        vt = torch.empty((b, 24, 64, s_pad), dtype=torch.bfloat16, device=dev)
+        scratch = torch.empty((2 * s_len * 16,), dtype=torch.float32, device=dev)
+        ab(f"qkv heads+rope {name} {b*s_len}x{3*d}x{d} (+memsets)",
+           lambda v: (lambda: _hip.check(lib.sat_qkv_rope_bf16(_hip.ptr(a), _hip.ptr(w), _hip.ptr(inv_freq), _hip.ptr(q), _hip.ptr(kk), _hip.ptr(vt), _hip.ptr(scratch),
+                                                               b, s_len, s_pad, d, v, _hip.stream()))), 2.0 * b * s_len * 3 * d * d,
+           {"launcher": 0, "v30": 30, "v80 all CUs": 80, "v80 balanced": 80 | bit})
 
 
 def race():
