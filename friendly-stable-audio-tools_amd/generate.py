@@ -47,8 +47,10 @@ def get_args():
     p.add_argument("--batch-size", type=int, default=10)
     p.add_argument("--clip-length", action="store_true")
     p.add_argument("--seed", type=int, default=-1)
-    p.add_argument("--gemm-dtype", choices=["bf16", "fp8"], default="bf16",
-                   help="build extension: fp8 = OCP e4m3 / MXFP8 operands for the transformer GEMMs (faster, ~1e-2 from the bf16 output)")
+    p.add_argument("--gemm-dtype", choices=["fp16", "bf16", "fp8"], default=None,
+                   help="build extension: operand format of the transformer GEMMs / attention (and, for fp16 / bf16, the codec).  Default: the "
+                        "package default (fp16, the reference's own GPU arithmetic); bf16 = 3-4 %% faster, 8x the operand rounding; fp8 = OCP e4m3 "
+                        "/ MXFP8 operands for the block GEMMs (BASELINE config 5)")
     return p.parse_args()
 
 
@@ -130,8 +132,10 @@ def main():
             model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), args.synthetic_weights))
     sample_rate, sample_size = model_config["sample_rate"], model_config["sample_size"]
     model = model.to(device).eval()
-    if args.gemm_dtype != "bf16":
+    if args.gemm_dtype is not None:
         model.model.model.set_gemm_dtype(args.gemm_dtype)
+        if args.gemm_dtype in ("fp16", "bf16") and model.pretransform is not None:
+            model.pretransform.model.set_gemm_dtype(args.gemm_dtype)
     cond_dim = model_config["model"]["conditioning"]["cond_dim"]
     if model.conditioner is not None:
         model.conditioner.set_device(str(device))      # what generate_diffusion_cond does first (generation.py:125); needed by encoders here

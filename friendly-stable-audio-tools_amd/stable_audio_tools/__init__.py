@@ -6,7 +6,8 @@ Same import surface as the reference package for the path (reference
 hand-written HIP kernels for gfx950 behind the C ABI of ``include/sat_hip.h``
 (``lib/libsat_hip.so``); there is no CPU fallback.
 """
+from ._config import default_gemm_dtype, set_default_gemm_dtype
 from .models.factory import create_model_from_config, create_model_from_config_path
 from .models.pretrained import get_pretrained_model
 
-__all__ = ["create_model_from_config", "create_model_from_config_path", "get_pretrained_model"]
+__all__ = ["create_model_from_config", "create_model_from_config_path", "get_pretrained_model", "default_gemm_dtype", "set_default_gemm_dtype"]

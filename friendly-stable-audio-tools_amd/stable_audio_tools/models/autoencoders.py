@@ -14,7 +14,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from .. import _hip
+from .. import _config, _hip
 from . import _init
 from .blocks import SnakeBeta
 from .bottleneck import Bottleneck
@@ -97,17 +97,16 @@ class _OobleckHip(nn.Module):
     """Shared plan handling of encoder and decoder."""
     _is_decoder = False
 
-    gemm_dtype = "bf16"
-
     def _init_plan_state(self):
+        self.gemm_dtype = _config.default_gemm_dtype()
         self._plan = None
         self._plan_version = None
         self._ws = None
 
     def set_gemm_dtype(self, dtype: str):
-        """Build extension: 16-bit format of the activations and weights inside the convolution kernels -- "bf16" (default) or "fp16"
-        (IEEE fp16 on the fp16 build of the same kernels: same MFMA rate, 8x less rounding; what the reference's ``model_half`` runs,
-        ``models/pretransforms.py:39-59``).  Parameters stay fp32 in the module; rebuilds the plan on next use."""
+        """Build extension: 16-bit format of the activations and weights inside the convolution kernels -- "fp16" (the package default,
+        stable_audio_tools/_config.py: IEEE fp16 on the fp16 build of the kernels, what the reference's ``model_half`` runs,
+        ``models/pretransforms.py:39-59``) or "bf16" (8x the rounding error, a few per cent faster).  Parameters stay fp32 in the module; rebuilds the plan on next use."""
         if dtype not in ("bf16", "fp16"):
             raise ValueError("the codec kernels take 'bf16' or 'fp16' operands")
         if dtype != self.gemm_dtype:

@@ -13,7 +13,7 @@ import typing as tp
 import torch
 from torch import nn
 
-from .. import _hip
+from .. import _config, _hip
 from . import _init
 from .blocks import FourierFeatures
 from .transformer import ContinuousTransformer
@@ -71,7 +71,7 @@ class DiffusionTransformer(nn.Module):
         self._plan_version = None
         self._ws = None
         self._ctx_key = None
-        self.gemm_dtype = "bf16"
+        self.gemm_dtype = _config.default_gemm_dtype()
         self.layernorm_fusion = True
 
     def set_layernorm_fusion(self, on: bool):
@@ -84,9 +84,10 @@ class DiffusionTransformer(nn.Module):
 
     def set_gemm_dtype(self, dtype: str):
         """Build extension: operand format of the block GEMMs and attention kernels (accumulation is fp32 in all of them).
-        "bf16" (default); "fp16" -- IEEE fp16 operands on the fp16 build of the same kernels: the same MFMA rate on gfx950, three more
+        "fp16" (the package default, stable_audio_tools/_config.py) -- IEEE fp16 operands on the fp16 build of the kernels: the same MFMA rate on gfx950, three more
         significand bits, and the arithmetic the reference itself uses on a GPU (``torch.cuda.amp.autocast`` in
         ``inference/sampling.py:210``, fp16 flash attention in ``models/transformer.py:496-504``); conversions saturate at +-65504;
+        "bf16" -- the bf16 build: 3-4 % faster, 8x the operand rounding error;
         "fp8" (BASELINE config 5: OCP e4m3 / MXFP8 operands for the block GEMMs); "fp32x" -- the fp32 verification mode (exact fp32
         MFMA, fp32 q / k / v / P; ~20x slower): the same plan and data flow with no operand rounding.  Rebuilds the plan on next use."""
         if dtype not in GEMM_DTYPES:

@@ -58,21 +58,45 @@ def mxfp8_blocks(x, block=32):
     return (q * scale).reshape(shp)
 
 
+FP8_FAMILIES = ("qkv", "cq", "ff1", "ff2", "o")      # to_qkv, cross to_q, FF-in (LayerNorm-fed: per-token scales); FF-out, to_out (MXFP8 A operand)
+
+
 class Fp8Rounding:
-    """Matched-rounding hook of BASELINE config 5 (sat_dit_cfg.gemm_dtype = 1): bf16 everywhere, except that the LayerNorm outputs
-    and the weights of the three GEMMs they feed (to_qkv, cross to_q, FF-in) are e4m3 with per-row scales, and FF-out takes the
-    SwiGLU output as MXFP8 (block-32 power-of-two scales) and per-channel e4m3 weights; the attention outputs feed the to_out
-    projections as MXFP8 too.  I.e. every GEMM of the blocks except the per-generation to_kv of the context."""
+    """Matched-rounding hook of BASELINE config 5 (sat_dit_cfg.gemm_dtype = 1): bf16 everywhere, except that the GEMM families named in
+    ``families`` take e4m3 operands -- the LayerNorm outputs and the weights of the GEMMs they feed ("qkv", "cq", "ff1") with per-row
+    scales; FF-out ("ff2") takes the SwiGLU output as MXFP8 (block-32 power-of-two scales) and per-channel e4m3 weights; the attention
+    outputs feed the to_out projections ("o", self and cross) as MXFP8 too.  Default: every GEMM of the blocks except the
+    per-generation to_kv of the context (the plan's "fp8-all").  A family left out keeps bf16 operands."""
+
+    def __init__(self, families=FP8_FAMILIES):
+        unknown = set(families) - set(FP8_FAMILIES)
+        if unknown:
+            raise ValueError(f"unknown fp8 GEMM families {sorted(unknown)}")
+        self.families = frozenset(families)
 
     def __call__(self, x):
         return bf16_round(x)
 
-    act = staticmethod(fp8_rows)
-    weight = staticmethod(fp8_rows)
-    hidden = staticmethod(mxfp8_blocks)       # SwiGLU output = A operand of FF-out (hardware block scales)
-    weight2 = staticmethod(fp8_rows)          # FF-out weight, per output channel
-    attn_out = staticmethod(mxfp8_blocks)     # attention output = A operand of to_out: MXFP8, one scale per half head
-    weight_o = staticmethod(fp8_rows)         # to_out weights (self and cross), per output channel
+    def _pick(self, fam, q, x):
+        return q(x) if fam in self.families else bf16_round(x)
+
+    def act(self, x, fam="qkv"):               # a LayerNorm output: one scale per token
+        return self._pick(fam, fp8_rows, x)
+
+    def weight(self, w, fam="qkv"):            # the weight behind it: one scale per output channel
+        return self._pick(fam, fp8_rows, w)
+
+    def hidden(self, x):                       # SwiGLU output = A operand of FF-out (hardware block scales)
+        return self._pick("ff2", mxfp8_blocks, x)
+
+    def weight2(self, w):                      # FF-out weight, per output channel
+        return self._pick("ff2", fp8_rows, w)
+
+    def attn_out(self, x):                     # attention output = A operand of to_out: MXFP8, one scale per half head
+        return self._pick("o", mxfp8_blocks, x)
+
+    def weight_o(self, w):                     # to_out weights (self and cross), per output channel
+        return self._pick("o", fp8_rows, w)
 
 
 class _Folded:
@@ -111,26 +135,27 @@ class LnFoldRoundingF16(LnFoldRounding):
     round = staticmethod(fp16_round)
 
 
-def _norm_for_gemm(rnd, x, gamma, beta, fold=True):
-    """LayerNorm whose output feeds a GEMM (transformer.py:692, 695, 700), with the operand rounding of ``rnd``."""
+def _norm_for_gemm(rnd, x, gamma, beta, fold=True, fam="qkv"):
+    """LayerNorm whose output feeds a GEMM (transformer.py:692, 695, 700), with the operand rounding of ``rnd``; ``fam`` names the
+    GEMM family it feeds ("qkv", "cq", "ff1": hooks that treat the families differently, Fp8Rounding)."""
     if fold and getattr(rnd, "ln_fold", False):
         return _Folded(x, gamma, beta)
-    return _ra(rnd, layer_norm(x, gamma, beta))
+    return _ra(rnd, layer_norm(x, gamma, beta), fam)
 
 
-def _lin(rnd, h, w, bias=None):
+def _lin(rnd, h, w, bias=None, fam="qkv"):
     """The Linear behind a LayerNorm."""
     if isinstance(h, _Folded):
         return rnd.folded_linear(h, w, bias)
-    return F.linear(h, _rw(rnd, w), bias)
+    return F.linear(h, _rw(rnd, w, fam), bias)
 
 
-def _ra(rnd, x):      # a LayerNorm output that feeds a GEMM
-    return rnd.act(x) if hasattr(rnd, "act") else _r(rnd, x)
+def _ra(rnd, x, fam="qkv"):      # a LayerNorm output that feeds a GEMM
+    return rnd.act(x, fam) if hasattr(rnd, "act") else _r(rnd, x)
 
 
-def _rw(rnd, w):      # the weight of a GEMM fed by a LayerNorm output
-    return rnd.weight(w) if hasattr(rnd, "weight") else _r(rnd, w)
+def _rw(rnd, w, fam="qkv"):      # the weight of a GEMM fed by a LayerNorm output
+    return rnd.weight(w, fam) if hasattr(rnd, "weight") else _r(rnd, w)
 
 
 # models/transformer.py:188-206 (LayerNorm: F.layer_norm with gamma, beta buffer, eps 1e-5)
@@ -203,7 +228,7 @@ def self_attention(sd, pfx, x, freqs, num_heads, rnd=None):
 
 # models/transformer.py:407-554, cross-attention branch (to_q / to_kv; no RoPE: :438)
 def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
-    q = _heads(_lin(rnd, x, sd[pfx + "to_q.weight"]), num_heads)
+    q = _heads(_lin(rnd, x, sd[pfx + "to_q.weight"], fam="cq"), num_heads)
     kv = F.linear(context, _r(rnd, sd[pfx + "to_kv.weight"]))
     k, v = kv.chunk(2, dim=-1)
     kv_heads = k.shape[-1] // dim_heads
@@ -217,7 +242,7 @@ def cross_attention(sd, pfx, x, context, num_heads, dim_heads, rnd=None):
 
 # models/transformer.py:211-287 (GLU + FeedForward; value = first half, gate = second half)
 def feed_forward(sd, pfx, x, rnd=None):
-    h = _lin(rnd, x, sd[pfx + "ff.0.proj.weight"], sd[pfx + "ff.0.proj.bias"])
+    h = _lin(rnd, x, sd[pfx + "ff.0.proj.weight"], sd[pfx + "ff.0.proj.bias"], fam="ff1")
     val, gate = h.chunk(2, dim=-1)
     h = rnd.hidden(val * F.silu(gate)) if hasattr(rnd, "hidden") else _r(rnd, val * F.silu(gate))
     w2 = rnd.weight2(sd[pfx + "ff.2.weight"]) if hasattr(rnd, "weight2") else _r(rnd, sd[pfx + "ff.2.weight"])
@@ -233,19 +258,19 @@ def transformer_block(sd, pfx, x, context, freqs, num_heads, dim_heads, rnd=None
         h = _ra(rnd, h * (1 + scale_self) + shift_self)                                                   # :671-672
         x = x + self_attention(sd, pfx + "self_attn.", h, freqs, num_heads, rnd) * torch.sigmoid(1 - gate_self)   # :673-675
         if context is not None:                                                                          # :677-678 (un-modulated)
-            h = _ra(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]))
+            h = _ra(rnd, layer_norm(x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"]), "cq")
             x = x + cross_attention(sd, pfx + "cross_attn.", h, context, num_heads, dim_heads, rnd)
         h = layer_norm(x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"])
-        h = _ra(rnd, h * (1 + scale_ff) + shift_ff)                                                        # :685-686
+        h = _ra(rnd, h * (1 + scale_ff) + shift_ff, "ff1")                                                        # :685-686
         x = x + feed_forward(sd, pfx + "ff.", h, rnd) * torch.sigmoid(1 - gate_ff)                        # :687-689
         return x
     # (the first block's pre_norm reads rows that no GEMM epilogue wrote: the ln_fold plan keeps it a standalone LayerNorm)
     h = _norm_for_gemm(rnd, x, sd[pfx + "pre_norm.gamma"], sd[pfx + "pre_norm.beta"], fold=not first)
     x = x + self_attention(sd, pfx + "self_attn.", h, freqs, num_heads, rnd)
     if context is not None:
-        h = _norm_for_gemm(rnd, x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"])
+        h = _norm_for_gemm(rnd, x, sd[pfx + "cross_attend_norm.gamma"], sd[pfx + "cross_attend_norm.beta"], fam="cq")
         x = x + cross_attention(sd, pfx + "cross_attn.", h, context, num_heads, dim_heads, rnd)
-    h = _norm_for_gemm(rnd, x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"])
+    h = _norm_for_gemm(rnd, x, sd[pfx + "ff_norm.gamma"], sd[pfx + "ff_norm.beta"], fam="ff1")
     x = x + feed_forward(sd, pfx + "ff.", h, rnd)
     return x
 

@@ -10,6 +10,14 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# The parity suite was written against the bf16 build (tolerances, matched-rounding hooks); the fp16 build -- the package default since
+# round 4 -- is covered by the tests that are parametrised over the operand format or switch a model to "fp16" explicitly, and by
+# test_package_default_is_fp16 / test_default_path_* which run what a user gets.  Everything else pins bf16 here.
+from stable_audio_tools import _config  # noqa: E402
+
+PACKAGE_DEFAULT_GEMM_DTYPE = _config.set_default_gemm_dtype("bf16")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -124,12 +124,21 @@ _GATES = {"plain": (3e-3, 1.6e-2), "a2a": (2e-3, 1.6e-2), "inpaint": (3e-3, 1.6e
 _GATES_K = {"heun_inpaint": 2e-4, "lms_inpaint": 2e-4, "fast_inpaint": 1e-4, "dpm2_variation": 2e-3, "ancestral_plain": 2.5e-3}
 
 
+def _set_dtype(model, fmt):
+    model.model.model.set_gemm_dtype(fmt)
+    model.pretransform.model.set_gemm_dtype(fmt)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", list(cases.GEN["calls"]))
-def test_product_generate_matches_reference(dev, gpu_model, name):
+def test_product_generate_matches_reference(dev, gpu_model, name, fmt):
+    """fmt = "fp16": the package default (what a user of generate.py gets) -- DiT and codec on the fp16 build; gates = the bf16 gates / 4."""
     from stable_audio_tools.inference.generation import generate_diffusion_cond
     gold = cases.load("generate")
     cfg, model, sd = gpu_model
+    _set_dtype(model, fmt)
+    scale = 0.25 if fmt == "fp16" else 1.0
     cond = _cond(cfg, model, dev)
     kw = dict(cases.GEN["calls"][name])
     ratio = cfg["model"]["pretransform"]["config"]["downsampling_ratio"]
@@ -151,9 +160,10 @@ def test_product_generate_matches_reference(dev, gpu_model, name):
                                                     inpaint_noise=(lambda i: renoise[i].to(dev)) if renoise else None, **kw)
     finally:
         bn.encode = orig
-    e_l = assert_close(f"{name}: product latents vs reference", outs[True], gold[f"{name}.latents"], _GATES[name][0])
-    e_a = assert_close(f"{name}: product audio vs reference", outs[False], gold[f"{name}.audio"], _GATES[name][1])
-    print(f"\n[reference generate_diffusion_cond / {name}] rel-L2 latents {e_l:.2e}, audio {e_a:.2e}")
+        _set_dtype(model, "bf16")
+    e_l = assert_close(f"{name}: product latents vs reference", outs[True], gold[f"{name}.latents"], _GATES[name][0] * scale)
+    e_a = assert_close(f"{name}: product audio vs reference", outs[False], gold[f"{name}.audio"], _GATES[name][1] * scale)
+    print(f"\n[reference generate_diffusion_cond / {name}, {fmt}] rel-L2 latents {e_l:.2e}, audio {e_a:.2e}")
 
 
 @pytest.mark.gpu
