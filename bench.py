@@ -169,10 +169,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None,
                     help="prompts per GPU; default 1 at --gpus 1 (BASELINE config 2) and 8 at --gpus > 1 (config 3: 64 prompts on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=("bf16", "fp16", "fp8"), default="fp16",
+    ap.add_argument("--dtype", choices=("bf16", "fp16", "fp8", "fp8-all"), default="fp16",
                     help="GEMM / attention / codec operand type: fp16 (default: the reference's own GPU arithmetic and the build that meets the "
                          "1e-3 target against its fp32 outputs), bf16 (the same kernels on the bf16 MFMAs: 3-4 %% faster, 8x the operand "
-                         "rounding) or fp8 = BASELINE config 5 (e4m3 block GEMMs, rest bf16)")
+                         "rounding) fp8 = BASELINE config 5 (e4m3 cross to_q / FF-in / FF-out, rest bf16) or fp8-all (every block GEMM e4m3: round 3's mode)")
     ap.add_argument("--layernorm", choices=("fused", "standalone"), default="fused",
                     help="LayerNorms of the blocks inside the GEMM epilogues (sat_dit_cfg.ln_fold, default) or as three kernels per block")
     ap.add_argument("--cross-attention", choices=("fused", "separate"), default="fused",
@@ -304,13 +304,13 @@ def main():
         # HBM traffic of the dominant kernel cannot be measured inside a timed run (PMC passes serialise the kernels): it is the
         # figure of the latest committed rocprofv3 --pmc pass of this same command (FETCH_SIZE x2 + WRITE_SIZE, separate passes)
         traffic, traffic_source = None, None
-        for tname in ("r03_ffn_traffic.json", "r02_ffn_traffic.json", "r01_ffn_traffic.json"):
+        for tname in ("r04_ffn_traffic.json", "r03_ffn_traffic.json", "r02_ffn_traffic.json", "r01_ffn_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and args.batch == 1 and args.dtype in ("bf16", "fp16") and args.workload == "sa_open":
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 traffic_source = f"profiles/{tname} (rocprofv3 --pmc passes of this command, not measured in this run)"
                 break
-        mfma_peak = FP8_MFMA_PEAK_TFLOPS if args.dtype == "fp8" else BF16_MFMA_PEAK_TFLOPS          # fp16 and bf16 MFMAs: the same dense peak
+        mfma_peak = FP8_MFMA_PEAK_TFLOPS if args.dtype.startswith("fp8") else BF16_MFMA_PEAK_TFLOPS          # fp16 and bf16 MFMAs: the same dense peak
         line = {
             "metric": "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-Open-1.0 shape" if args.workload == "sa_open" else
                       "audio-seconds/sec @44.1kHz stereo, 100-step DPM++, SA-2.0 shape audio-to-audio (encode + sample + decode)",
@@ -323,7 +323,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.dtype if args.dtype != "fp8" else "fp8 e4m3 (to_qkv, cross to_q, FF-in; per-token x per-channel scales) + bf16, fp32 accumulate",
+            "dtype": args.dtype if not args.dtype.startswith("fp8") else
+                     {"fp8": "fp8 e4m3 (cross to_q, FF-in, FF-out; per-token / MX-32 x per-channel scales) + bf16, fp32 accumulate",
+                      "fp8-all": "fp8 e4m3 (every GEMM of the blocks) + bf16, fp32 accumulate"}[args.dtype],
             "data": "synthetic (random-init weights of the SA-Open-1.0 / SA-2.0 DiT + Oobleck architecture, random text embeddings)",
             "config": {"workload": ("Stable-Audio-Open-1.0 DiT shape (24 layers, D=1536, S=1025, CFG 7 -> 2 sequences/prompt) + Oobleck decode, "
                                     f"{args.batch} prompt(s)/GPU x 47.55 s, 100 DPM-Solver++(3M) SDE steps") if args.workload == "sa_open" else

@@ -117,6 +117,8 @@ struct sat_dit_plan {
     int f16 = 0;                    // cfg.gemm_dtype == 3: every 16-bit operand buffer holds IEEE fp16 and the fp16 build of the kernels runs
     bool ln_fold = false;           // cfg.ln_fold, bf16 / fp16 operands, "prepend" conditioning: LayerNorms run inside the GEMM epilogues
     int fp8_mode = 2;               // 2: v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, 2x rate); 1: v_mfma_f32_32x32x16_fp8_fp8
+    // gemm_dtype == 1: which GEMM families take e4m3 operands (sat_dit_cfg.fp8_families; SAT_FP8_* bits); 0 in every other mode
+    bool f8_qkv = false, f8_cq = false, f8_ff1 = false, f8_ff2 = false, f8_o = false;
     float* ssg_w = nullptr;         // adaLN: [depth * 6D, D] stacked to_scale_shift_gate weights
     // per-generation context (sat_dit_prepare_context)
     char* ctx_buf = nullptr;
@@ -236,7 +238,6 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
         SAT_TRY(copy_f32(p, ar, pf + "pre_norm.beta", D, &L.pre_b, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.gamma", D, &L.ff_g, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff_norm.beta", D, &L.ff_b, s));
-        const bool f8 = c.gemm_dtype == 1;
         if (c.gemm_dtype == 2) {      // fp32 verification mode: the reference's own fp32 weights, no re-packing (f32_ref.hip)
             auto w32 = [&](const std::string& name, int64_t numel, op_t** dst) { return copy_f32(p, ar, pf + name, numel, (float**)dst, s); };
             SAT_TRY(w32("self_attn.to_qkv.weight", (int64_t)3 * D * D, &L.w_qkv));
@@ -256,22 +257,22 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
         }
         const bool lf = p->ln_fold;
         L.fold_qkv = lf && l > 0;
-        if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, &L.s_qkv, s));
+        if (p->f8_qkv) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, &L.s_qkv, s));
         else if (L.fold_qkv) SAT_TRY(pack_w_ln(p, ar, pf + "self_attn.to_qkv.weight", L.pre_g, L.pre_b, "", 3 * D, D, 0, &L.w_qkv, &L.c1_qkv, &L.c2_qkv, s));
         else SAT_TRY(pack_w(p, ar, pf + "self_attn.to_qkv.weight", 3 * D, D, 0, &L.w_qkv, s));
-        if (f8) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, &L.s_o, s));
+        if (p->f8_o) SAT_TRY(pack_w8(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, &L.s_o, s));
         else SAT_TRY(pack_w(p, ar, pf + "self_attn.to_out.weight", D, D, 0, &L.w_o, s));
         if (Dct > 0) {
             SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.gamma", D, &L.cross_g, s));
             SAT_TRY(copy_f32(p, ar, pf + "cross_attend_norm.beta", D, &L.cross_b, s));
-            if (f8) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, &L.s_cq, s));
+            if (p->f8_cq) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, &L.s_cq, s));
             else if (lf) SAT_TRY(pack_w_ln(p, ar, pf + "cross_attn.to_q.weight", L.cross_g, L.cross_b, "", D, D, 0, &L.w_cq, &L.c1_cq, &L.c2_cq, s));
             else SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_q.weight", D, D, 0, &L.w_cq, s));
             SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_kv.weight", 2 * Dc, Dc, 0, &L.w_ckv, s));
-            if (f8) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, &L.s_co, s));
+            if (p->f8_o) SAT_TRY(pack_w8(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, &L.s_co, s));
             else SAT_TRY(pack_w(p, ar, pf + "cross_attn.to_out.weight", D, D, 0, &L.w_co, s));
         }
-        if (f8) SAT_TRY(pack_w8(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, &L.s_ff1, s));
+        if (p->f8_ff1) SAT_TRY(pack_w8(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, &L.s_ff1, s));
         else if (lf) SAT_TRY(pack_w_ln(p, ar, pf + "ff.ff.0.proj.weight", L.ff_g, L.ff_b, pf + "ff.ff.0.proj.bias", 2 * inner, D, 1, &L.w_ff1, &L.c1_ff1,
                                        &L.c2_ff1, s));
         else SAT_TRY(pack_w(p, ar, pf + "ff.ff.0.proj.weight", 2 * inner, D, 1, &L.w_ff1, s));
@@ -281,7 +282,7 @@ int build(sat_dit_plan* p, Arena& ar, hipStream_t s) {
             SAT_TRY(get_tensor(p, pf + "ff.ff.0.proj.bias", 2 * inner, &b1));
             SAT_TRY(sat_launch_pack_bias(b1, L.b_ff1, 2 * inner, 1, s));
         }
-        if (f8) SAT_TRY(pack_w8(p, ar, pf + "ff.ff.2.weight", D, inner, 0, &L.w_ff2, &L.s_ff2, s));
+        if (p->f8_ff2) SAT_TRY(pack_w8(p, ar, pf + "ff.ff.2.weight", D, inner, 0, &L.w_ff2, &L.s_ff2, s));
         else SAT_TRY(pack_w(p, ar, pf + "ff.ff.2.weight", D, inner, 0, &L.w_ff2, s));
         SAT_TRY(copy_f32(p, ar, pf + "ff.ff.2.bias", D, &L.b_ff2, s));
     }
@@ -374,7 +375,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     Workspace w = carve(p, bf, T, (char*)ws);
     SAT_CHECK_ARG(ws_bytes >= w.total, SAT_E_WORKSPACE, "dit forward: workspace %zu < required %zu", ws_bytes, w.total);
     const int D = c.embed_dim, H = c.num_heads, C = c.io_channels;
-    const bool adaln = c.adaln != 0, f8 = c.gemm_dtype == 1, f32 = c.gemm_dtype == 2;
+    const bool adaln = c.adaln != 0, f32 = c.gemm_dtype == 2;
     const int f16 = p->f16;
     const int S = T + (adaln ? 0 : 1), M = bf * S, Spad = (int)round_up(S + 3, 128);
     const int ssg_ld = c.depth * 6 * D;      // per-sequence stride of the adaLN modulation vectors
@@ -438,21 +439,21 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         auto fold_out = [&](GemmArgs& ga) {
             if (lf) { ga.xb = w.A; ga.ln_part_out = w.ln_part; }
         };
-        if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.pre_g, L.pre_b, w.A, w.As, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
+        if (p->f8_qkv) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.pre_g, L.pre_b, w.A, w.As, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
         else if (!L.fold_qkv) SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s, f16));
         g = GemmArgs{}; g.f16 = f16;
         g.A = w.A; g.W = L.w_qkv; g.M = M; g.N = 3 * D; g.K = D;
         if (L.fold_qkv) fold_in(g, L.c1_qkv, L.c2_qkv);
-        if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_qkv; }
+        if (p->f8_qkv) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_qkv; }
         g.heads.out[0] = w.Q; g.heads.out[1] = w.K; g.heads.out[2] = w.Vt;
         g.heads.kind[0] = 2 | 8; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4; g.heads.qscale = SAT_ATTN_QSCALE;
         g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
         g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
         SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
-        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, f8 ? w.AOs : nullptr, 1.0f, f16));
+        SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, p->f8_o ? w.AOs : nullptr, 1.0f, f16));
         g = GemmArgs{}; g.f16 = f16;
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
-        if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
+        if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         fold_out(g);
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
@@ -464,19 +465,19 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             const int bc = (p->ctx_null_from >= 0 && p->ctx_null_from < bf) ? p->ctx_null_from : bf;
             const int Mc = bc * S;
             if (bc > 0) {
-                if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.cross_g, L.cross_b, w.A, w.As, Mc, D, nullptr, nullptr, 1, 0, s));
+                if (p->f8_cq) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.cross_g, L.cross_b, w.A, w.As, Mc, D, nullptr, nullptr, 1, 0, s));
                 else if (!lf) SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s, f16));
                 g = GemmArgs{}; g.f16 = f16;
                 g.A = w.A; g.W = L.w_cq; g.M = Mc; g.N = D; g.K = D;
                 if (lf) fold_in(g, L.c1_cq, L.c2_cq);
-                if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_cq; }
+                if (p->f8_cq) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_cq; }
                 g.heads.out[0] = w.Q; g.heads.kind[0] = 8; g.heads.qscale = SAT_ATTN_QSCALE;
                 g.heads.parts = 1; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
                 const size_t per_layer = (size_t)bf * p->kvh_cross * p->ctx_lcpad * 64;
                 // One launch for to_q + softmax(q k^T) v where the 128 x 64 tile is the choice anyway and its workgroups fit one round
                 // (one prompt: 9 x 24 = 216): the projection's epilogue keeps Q in registers and attends to the <= 189 context keys
                 // staged in LDS (gemm_bf16.hip, XA_OK).  Saves the attention launch and the Q round trip.
-                const bool fuse = g_cross_fusion && !f8 && D >= 192 && p->ctx_lc + 3 <= 192 && cdiv(Mc, 128) * (D / 64) <= 256;
+                const bool fuse = g_cross_fusion && !p->f8_cq && !p->f8_o && D >= 192 && p->ctx_lc + 3 <= 192 && cdiv(Mc, 128) * (D / 64) <= 256;
                 if (fuse) {
                     g.heads.xa_k = p->kc + l * per_layer; g.heads.xa_vt = p->vct + l * per_layer; g.heads.xa_out = w.AO;
                     g.heads.xa_kvh = p->kvh_cross; g.heads.xa_sk = p->ctx_lc; g.heads.xa_sk_pad = p->ctx_lcpad;
@@ -484,23 +485,26 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
                 if (!fuse)
                     SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
-                                                 p->ctx_lc, Spad, p->ctx_lcpad, s, f8 ? w.AOs : nullptr, 1.0f, f16));
+                                                 p->ctx_lc, Spad, p->ctx_lcpad, s, p->f8_o ? w.AOs : nullptr, 1.0f, f16));
                 g = GemmArgs{}; g.f16 = f16;
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
-                if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
+                if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
                 fold_out(g);
                 SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
             }
         }
         // ---- feed-forward branch (transformer.py:700)
-        if (f8) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.ff_g, L.ff_b, w.A, w.As, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr,
-                                                 S, ssg_ld, s));
+        if (p->f8_ff1) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.ff_g, L.ff_b, w.A, w.As, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr,
+                                                       S, ssg_ld, s));
         else if (!lf) SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
                                                        ssg_ld, s, f16));
         g = GemmArgs{}; g.f16 = f16;
         g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
         if (lf) { g.bias = nullptr; fold_in(g, L.c1_ff1, L.c2_ff1); }
-        if (f8) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_ff1; g.H8 = (unsigned char*)w.Hh; g.Hs = w.Hs; }
+        if (p->f8_ff1) {
+            g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_ff1;
+            if (p->f8_ff2) { g.H8 = (unsigned char*)w.Hh; g.Hs = w.Hs; }          // FF-out's MXFP8 operand; otherwise the e4m3 GEMM writes a bf16 hidden state
+        }
         const bool prof = p->prof_on && l == c.depth / 2 && p->prof_n < kProfMaxPairs;
         if (prof) {
             if ((int)p->prof_ev.size() < 2 * (p->prof_n + 1)) {
@@ -520,7 +524,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         }
         g = GemmArgs{}; g.f16 = f16;
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
-        if (f8) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.Hs; g.w_scale = L.s_ff2; }
+        if (p->f8_ff2) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.Hs; g.w_scale = L.s_ff2; }
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         if (l + 1 < c.depth) fold_out(g);       // nobody normalises the output of the last block
@@ -555,6 +559,12 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
     SAT_CHECK_ARG(cfg->gemm_dtype >= 0 && cfg->gemm_dtype <= 3, SAT_E_INVALID,
                   "dit_plan_create: gemm_dtype must be 0 (bf16), 1 (e4m3), 2 (fp32 verification) or 3 (fp16)");
     SAT_CHECK_ARG(cfg->gemm_dtype != 1 || cfg->embed_dim % 256 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: gemm_dtype needs embed_dim %% 256 == 0");
+    const int fam = cfg->fp8_families ? cfg->fp8_families : SAT_FP8_DEFAULT;
+    if (cfg->gemm_dtype == 1) {
+        SAT_CHECK_ARG((fam & ~SAT_FP8_ALL) == 0, SAT_E_INVALID, "dit_plan_create: unknown bits in fp8_families 0x%x", fam);
+        SAT_CHECK_ARG(!(fam & SAT_FP8_FF_OUT) || (fam & SAT_FP8_FF_IN), SAT_E_UNSUPPORTED,
+                      "dit_plan_create: FF-out's MXFP8 operand is written by the e4m3 FF-in epilogue: SAT_FP8_FF_OUT needs SAT_FP8_FF_IN");
+    }
     sat_dit_plan* p = new (std::nothrow) sat_dit_plan();
     SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_plan_create: out of host memory");
     p->cfg = *cfg;
@@ -562,6 +572,10 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
     // the fold lives in the bf16 pipelined GEMM tiles (K >= 192); adaLN modulates between LayerNorm and GEMM per sequence, the e4m3
     // path quantises the LayerNorm output per token: both keep the standalone kernels
     p->f16 = cfg->gemm_dtype == 3 ? 1 : 0;
+    if (cfg->gemm_dtype == 1) {
+        p->f8_qkv = fam & SAT_FP8_QKV; p->f8_cq = fam & SAT_FP8_CROSS_Q; p->f8_ff1 = fam & SAT_FP8_FF_IN; p->f8_ff2 = fam & SAT_FP8_FF_OUT;
+        p->f8_o = fam & SAT_FP8_TO_OUT;
+    }
     p->ln_fold = cfg->ln_fold != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
     return 0;

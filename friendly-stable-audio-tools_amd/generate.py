@@ -47,7 +47,7 @@ def get_args():
     p.add_argument("--batch-size", type=int, default=10)
     p.add_argument("--clip-length", action="store_true")
     p.add_argument("--seed", type=int, default=-1)
-    p.add_argument("--gemm-dtype", choices=["fp16", "bf16", "fp8"], default=None,
+    p.add_argument("--gemm-dtype", choices=["fp16", "bf16", "fp8", "fp8-all"], default=None,
                    help="build extension: operand format of the transformer GEMMs / attention (and, for fp16 / bf16, the codec).  Default: the "
                         "package default (fp16, the reference's own GPU arithmetic); bf16 = 3-4 %% faster, 8x the operand rounding; fp8 = OCP e4m3 "
                         "/ MXFP8 operands for the block GEMMs (BASELINE config 5)")

@@ -19,7 +19,10 @@ from .blocks import FourierFeatures
 from .transformer import ContinuousTransformer
 
 
-GEMM_DTYPES = {"bf16": 0, "fp8": 1, "fp32x": 2, "fp16": 3}      # sat_dit_cfg.gemm_dtype (include/sat_hip.h)
+GEMM_DTYPES = {"bf16": 0, "fp8": 1, "fp8-all": 1, "fp32x": 2, "fp16": 3}      # sat_dit_cfg.gemm_dtype (include/sat_hip.h)
+# sat_dit_cfg.fp8_families (SAT_FP8_*): "fp8" = cross to_q + FF-in + FF-out in e4m3 (the subset whose quantisation the 12-step trajectory
+# tolerates: tools/fp8_budget.py), "fp8-all" = every GEMM of the blocks (round 3's mode: to_qkv and the to_out projections as well)
+FP8_FAMILIES = {"fp8": 2 | 4 | 8, "fp8-all": 31}
 
 
 class DiffusionTransformer(nn.Module):
@@ -88,7 +91,9 @@ class DiffusionTransformer(nn.Module):
         significand bits, and the arithmetic the reference itself uses on a GPU (``torch.cuda.amp.autocast`` in
         ``inference/sampling.py:210``, fp16 flash attention in ``models/transformer.py:496-504``); conversions saturate at +-65504;
         "bf16" -- the bf16 build: 3-4 % faster, 8x the operand rounding error;
-        "fp8" (BASELINE config 5: OCP e4m3 / MXFP8 operands for the block GEMMs); "fp32x" -- the fp32 verification mode (exact fp32
+        "fp8" (BASELINE config 5: OCP e4m3 / MXFP8 operands for cross to_q, FF-in and FF-out -- 56 % of the block's FLOPs, the families
+        whose quantisation the sampler trajectory tolerates; the rest bf16), "fp8-all" (every GEMM of the blocks in e4m3: round 3's mode,
+        3e-1 off after 12 steps -- the to_out projections on MXFP8 attention outputs are what breaks it); "fp32x" -- the fp32 verification mode (exact fp32
         MFMA, fp32 q / k / v / P; ~20x slower): the same plan and data flow with no operand rounding.  Rebuilds the plan on next use."""
         if dtype not in GEMM_DTYPES:
             raise ValueError(f"gemm_dtype must be one of {sorted(GEMM_DTYPES)}")
@@ -118,7 +123,7 @@ class DiffusionTransformer(nn.Module):
             self._plan = None
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
                              self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
-                             1 if self.global_cond_type == "adaLN" else 0, GEMM_DTYPES[self.gemm_dtype],
+                             1 if self.global_cond_type == "adaLN" else 0, GEMM_DTYPES[self.gemm_dtype], FP8_FAMILIES.get(self.gemm_dtype, 0),
                              1 if self.layernorm_fusion else 0)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))

@@ -58,6 +58,14 @@ typedef struct sat_dit_plan sat_dit_plan;
 #define SAT_GEMM_FP8 1
 #define SAT_GEMM_FP32X 2
 #define SAT_GEMM_FP16 3
+/* sat_dit_cfg.fp8_families */
+#define SAT_FP8_QKV 1       /* self-attention to_qkv   (transformer.py:314), LayerNorm-fed: one scale per token */
+#define SAT_FP8_CROSS_Q 2   /* cross-attention to_q    (transformer.py:311), LayerNorm-fed */
+#define SAT_FP8_FF_IN 4     /* FF-in (SwiGLU)          (transformer.py:222), LayerNorm-fed */
+#define SAT_FP8_FF_OUT 8    /* FF-out                  (transformer.py:270), MXFP8 A operand from the FF-in epilogue */
+#define SAT_FP8_TO_OUT 16   /* to_out, self and cross  (transformer.py:319), MXFP8 A operand from the attention kernels */
+#define SAT_FP8_ALL 31
+#define SAT_FP8_DEFAULT (SAT_FP8_CROSS_Q | SAT_FP8_FF_IN | SAT_FP8_FF_OUT)
 
 typedef struct sat_dit_cfg {
     int32_t io_channels;       /* config "io_channels" (64) */
@@ -87,6 +95,14 @@ typedef struct sat_dit_cfg {
                                   2 (SAT_GEMM_FP32X): fp32 VERIFICATION mode -- every contraction of the blocks on the exact fp32 MFMA
                                   (v_mfma_f32_32x32x2_f32), fp32 LayerNorm output, fp32 q / k / v / P, fp32 weights: same plan, data flow
                                   and index arithmetic, no operand rounding (~20x slower; meets 1e-3 vs the reference's outputs) */
+    int32_t fp8_families;      /* gemm_dtype == 1 only: which GEMM families take e4m3 operands, an OR of SAT_FP8_* (0 = SAT_FP8_DEFAULT).  The
+                                  full-size 12-step CFG-7 trajectory (tests/golden/traj_full.npz; tools/fp8_budget.py) prices each family's
+                                  quantisation separately (rel-L2 vs fp32 after 12 steps; bf16 everywhere: 8e-3): the to_out projections
+                                  on MXFP8 attention outputs 3.3e-1 -- that one family was round 3's whole fidelity problem --, to_qkv 6e-2
+                                  (attention scores under CFG 7 do not tolerate 3-bit mantissas), cross to_q 1.2e-2, FF-in 9.5e-3, FF-out
+                                  1.3e-2.  The default therefore quantises cross to_q, FF-in and FF-out (56 % of the block's FLOPs) and keeps
+                                  to_qkv / to_out in bf16; SAT_FP8_ALL is round 3's mode.  SAT_FP8_FF_OUT needs SAT_FP8_FF_IN (the
+                                  MXFP8 hidden state is written by the e4m3 FF-in epilogue) */
     int32_t ln_fold;           /* 1 (gemm_dtype 0 or 3, adaln == 0, embed_dim >= 256; ignored otherwise): no standalone LayerNorm launches
                                   after the first one.  LN(x) W^T = rstd (x (gamma.W)^T - mean rowsum(gamma.W)) + beta W^T: the GEMM
                                   that updates the residual stream (to_out, FF-out; transformer.py:692-700) also writes bf16(x) and

@@ -59,16 +59,18 @@ def mxfp8_blocks(x, block=32):
 
 
 FP8_FAMILIES = ("qkv", "cq", "ff1", "ff2", "o")      # to_qkv, cross to_q, FF-in (LayerNorm-fed: per-token scales); FF-out, to_out (MXFP8 A operand)
+FP8_DEFAULT_FAMILIES = ("cq", "ff1", "ff2")          # SAT_FP8_DEFAULT: what gemm_dtype "fp8" quantises; FP8_FAMILIES = "fp8-all" (SAT_FP8_ALL)
 
 
 class Fp8Rounding:
     """Matched-rounding hook of BASELINE config 5 (sat_dit_cfg.gemm_dtype = 1): bf16 everywhere, except that the GEMM families named in
     ``families`` take e4m3 operands -- the LayerNorm outputs and the weights of the GEMMs they feed ("qkv", "cq", "ff1") with per-row
     scales; FF-out ("ff2") takes the SwiGLU output as MXFP8 (block-32 power-of-two scales) and per-channel e4m3 weights; the attention
-    outputs feed the to_out projections ("o", self and cross) as MXFP8 too.  Default: every GEMM of the blocks except the
-    per-generation to_kv of the context (the plan's "fp8-all").  A family left out keeps bf16 operands."""
+    outputs feed the to_out projections ("o", self and cross) as MXFP8 too.  Default = the plan's "fp8" (cross to_q, FF-in, FF-out);
+    ``families=FP8_FAMILIES`` = "fp8-all": every GEMM of the blocks except the per-generation to_kv of the context.  A family left out
+    keeps bf16 operands."""
 
-    def __init__(self, families=FP8_FAMILIES):
+    def __init__(self, families=FP8_DEFAULT_FAMILIES):
         unknown = set(families) - set(FP8_FAMILIES)
         if unknown:
             raise ValueError(f"unknown fp8 GEMM families {sorted(unknown)}")

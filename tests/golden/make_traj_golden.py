@@ -3,7 +3,7 @@
 12 steps of DPM-Solver++(3M) SDE (sigma 500 -> 0.3, polyexponential) with batched CFG 7 on the FULL-size SA-Open DiT (24 layers,
 D = 1536, T = 1024, synthetic weights seed 0), initial and per-step noise injected, evaluated by the CPU oracle (oracle/dit.py +
 oracle/sampler.py) four times: fp32, with the bf16 matched-rounding hook of the default plan (LnFoldRounding), with the e4m3 /
-MXFP8 hook of BASELINE config 5 (Fp8Rounding) and with the fp16 hook of gemm_dtype "fp16" (LnFoldRoundingF16).  Stored: the latents after steps 4, 8 and 12 of each run.  The oracle takes ~20 s
+MXFP8 hooks of BASELINE config 5 (Fp8Rounding: "fp8" = cross to_q + FF-in + FF-out, "fp8all" = every block GEMM) and with the fp16 hook of gemm_dtype "fp16" (LnFoldRoundingF16).  Stored: the latents after steps 4, 8 and 12 of each run.  The oracle takes ~20 s
 per CFG evaluation on 8 cores, which is why this is a committed fixture and not recomputed in the -m gpu test.
 
     python tests/golden/make_traj_golden.py            (any machine with the repo; no GPU, no reference needed)
@@ -37,7 +37,8 @@ def main():
     c, g, noise, step_noise = inputs()
     sig = osamp.get_sigmas_polyexponential(STEPS, SIGMA_MIN, SIGMA_MAX, 1.0)
     out = {}
-    hooks = (("fp32", None), ("bf16", odit.LnFoldRounding()), ("fp8", odit.Fp8Rounding()), ("fp16", odit.LnFoldRoundingF16()))
+    hooks = (("fp32", None), ("bf16", odit.LnFoldRounding()), ("fp8", odit.Fp8Rounding()), ("fp8all", odit.Fp8Rounding(odit.FP8_FAMILIES)),
+             ("fp16", odit.LnFoldRoundingF16()))
     path = os.path.join(cases.GOLDEN_DIR, "traj_full.npz")
     only = sys.argv[1:]                 # e.g. `make_traj_golden.py fp16`: add these runs to the existing file, leave the others as they are
     if only:
@@ -60,9 +61,9 @@ def main():
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
     for i in SNAP:
-        a, b, f, h = (torch.from_numpy(out[f"{t}_step{i}"]) for t in ("fp32", "bf16", "fp8", "fp16"))
-        print(f"step {i}: bf16-matched vs fp32 {((b - a).norm() / a.norm()).item():.3e}   fp8-matched vs fp32 {((f - a).norm() / a.norm()).item():.3e}"
-              f"   fp16-matched vs fp32 {((h - a).norm() / a.norm()).item():.3e}")
+        a = torch.from_numpy(out[f"fp32_step{i}"])
+        print(f"step {i}: " + "   ".join(f"{t}-matched vs fp32 {((torch.from_numpy(out[f'{t}_step{i}']) - a).norm() / a.norm()).item():.3e}"
+                                          for t in ("bf16", "fp16", "fp8", "fp8all") if f"{t}_step{i}" in out))
 
 
 if __name__ == "__main__":

@@ -272,5 +272,11 @@ def test_fp8_rounding_hooks_of_the_oracle():
     assert (mb.abs().amax(dim=-1) <= amax * (1 + 2.0 ** -3)).all() and torch.isfinite(m).all()
     assert rel_l2(m, x * torch.logspace(-3, 2, 256)[None, :]) < 4e-2
     assert torch.equal(odit.mxfp8_blocks(m), m)
-    r = odit.Fp8Rounding()
-    assert torch.equal(r(x), odit.bf16_round(x)) and r.act is odit.fp8_rows and r.hidden is odit.mxfp8_blocks
+    r = odit.Fp8Rounding()                      # the plan's "fp8": cross to_q, FF-in, FF-out; to_qkv and the to_out projections stay bf16
+    assert r.families == frozenset(odit.FP8_DEFAULT_FAMILIES) == frozenset(("cq", "ff1", "ff2"))
+    assert torch.equal(r(x), odit.bf16_round(x)) and torch.equal(r.act(x, "ff1"), odit.fp8_rows(x)) and torch.equal(r.hidden(x), odit.mxfp8_blocks(x))
+    assert torch.equal(r.act(x, "qkv"), odit.bf16_round(x)) and torch.equal(r.attn_out(x), odit.bf16_round(x))
+    ra = odit.Fp8Rounding(odit.FP8_FAMILIES)    # "fp8-all"
+    assert torch.equal(ra.act(x, "qkv"), odit.fp8_rows(x)) and torch.equal(ra.attn_out(x), odit.mxfp8_blocks(x))
+    with pytest.raises(ValueError):
+        odit.Fp8Rounding(("ff3",))

@@ -23,7 +23,7 @@ with open(os.path.join(root, "profiles", f"{tag}_pmc_fetch_write_per_kernel.csv"
 
 lines = [f"# {tag} -- SQ / GRBM counters per kernel: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
          "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -- python tools/gpu_probe.py full` (12 CFG denoiser steps + "
-         "4 decodes, 1 prompt, bf16, LayerNorm fold on; tools/gpu_session.sh pmc)", "",
+         "4 decodes, 1 prompt, the package default operand format (fp16 since round 4), LayerNorm fold on; tools/gpu_session.sh pmc)", "",
          "Derived per launch: busy cycles per shader engine = SQ_BUSY_CYCLES / 32; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x busy "
          "cycles per SE); wave-time split = SQ_WAIT_ANY (parked at s_waitcnt / s_barrier), SQ_WAIT_INST_ANY (ready, pipe busy / dependency), "
          "SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES.", "",
@@ -44,11 +44,12 @@ if ffn:
     json.dump({"kernel": k, "launches_sampled": int(fetch[k]["launches"]), "FETCH_SIZE_KB_raw": fk, "WRITE_SIZE_KB_raw": wk,
                "hbm_bytes_per_launch": (2 * fk + wk) * 1024, "algorithmic_bytes_per_launch": 2 * (2050 * 1536 + 12288 * 1536 + 2050 * 6144),
                "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (counters only, with --kernel-trace) over `tools/gpu_probe.py "
-                       "full` (12 CFG denoise steps, 1 prompt, M=2050 N=12288 K=1536, LayerNorm fold on: A = the bf16 image of the residual stream); "
+                       "full` (12 CFG denoise steps, 1 prompt, M=2050 N=12288 K=1536, LayerNorm fold on: A = the 16-bit image of the residual stream); "
                        "FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM (gfx950 reports half of a wide coalesced read stream); WRITE_SIZE as "
-                       "reported (= the 25.2 MB bf16 output).  Fabric-side bytes: the excess over the algorithmic 69.2 MB is what 8 private L2s cost -- "
-                       "per round every XCD's 32 concurrent tiles (8 row tiles x 4 column tiles) pull 8 A panels + 4 W panels = 9.4 MB through its "
-                       "own L2, 8 XCDs x 1.69 rounds = 127 MB, + 25 MB written = 152 MB expected, matching the measurement; the 6.3 MB A operand does "
-                       "not fit a 4 MiB L2 next to the W stream, so it is re-fetched (from the 256 MiB Infinity Cache) every round."},
+                       "reported (= the 25.2 MB 16-bit output).  Fabric-side bytes: the excess over the algorithmic 69.2 MB is what 8 private L2s cost -- "
+                       "round 4 runs this launch as two balanced rounds of 216 workgroups (27 per XCD: 8 row tiles x 3.4 column tiles): every XCD "
+                       "pulls the 8 A panels (6.3 MB) + its W panels through its own L2 in both rounds; the 6.3 MB A operand does not fit a 4 MiB "
+                       "L2 next to the W stream, so it is re-fetched (from the 256 MiB Infinity Cache).  At ~2.5 TB/s over the launch this is not "
+                       "the bound (MFMA / LDS issue is, DESIGN.md section 4)."},
               open(os.path.join(root, "profiles", f"{tag}_ffn_traffic.json"), "w"), indent=1)
     print("FF-in traffic per launch: %.1f MB" % ((2 * fk + wk) * 1024 / 1e6))
