@@ -1474,6 +1474,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 12: return launch_pipe<256, 128, 64, 4, 2, 3, EPI>(a, stream);
         case 13: return launch_pipe<256, 256, 32, 2, 4, 3, EPI>(a, stream);
         case 39: return launch_pipe<128, 128, 128, 4, 2, 2, EPI>(a, stream);       // 256-B rows: half the barriers per k
+        case 48: return launch_pipe<128, 128, 128, 2, 2, 2, EPI>(a, stream);       // the same on 4 waves of 64x64 (the vendor library's pick for FF-out at one prompt)
         case 41: return launch_pipe<256, 128, 32, 4, 2, 3, EPI>(a, stream);        // 72 KiB, <= 128 VGPRs: two workgroups per CU
         case 45:                                                                    //                               distance 4 (160 KiB)
             if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 2, 5, EPI>(a, stream);
