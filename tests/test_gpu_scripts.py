@@ -19,6 +19,16 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture
+def package_default(request):
+    """The operand format a freshly built model starts with: the suite pins "bf16" (conftest.py); "fp16" is what a user of the scripts
+    gets (stable_audio_tools/_config.py).  The scripts and the direct calls they are compared with are built under the same default."""
+    from stable_audio_tools import _config
+    prev = _config.set_default_gemm_dtype(request.param)
+    yield request.param
+    _config.set_default_gemm_dtype(prev)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "friendly-stable-audio-tools_amd")
 
@@ -32,7 +42,8 @@ def _run_script(name, argv):
         sys.argv = old
 
 
-def test_checkpoint_roundtrip_and_generate_script(dev, tmp_path):
+@pytest.mark.parametrize("package_default", ["bf16", "fp16"], indirect=True)
+def test_checkpoint_roundtrip_and_generate_script(dev, tmp_path, package_default):
     import stable_audio_tools as S
     from safetensors.torch import save_file
     from stable_audio_tools import model_configs as MC, synthetic
@@ -107,7 +118,8 @@ def test_checkpoint_roundtrip_and_generate_script(dev, tmp_path):
                                     str(cfg_path), "--ckpt-path", str(ckpt_path), "--text-embeds", "random"])
 
 
-def test_reconstruct_audios_script(dev, tmp_path):
+@pytest.mark.parametrize("package_default", ["bf16", "fp16"], indirect=True)
+def test_reconstruct_audios_script(dev, tmp_path, package_default):
     import stable_audio_tools as S
     from safetensors.torch import save_file
     from stable_audio_tools import model_configs as MC, synthetic
