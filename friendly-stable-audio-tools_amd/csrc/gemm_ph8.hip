@@ -1050,6 +1050,12 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
     // less than a half-empty second round: FF-out at 8 prompts 336 -> 311 us, FF-in at one prompt 85.4 -> 82.6 us.  With many rounds it
     // loses (FF-in at 8 prompts, 12.2 rounds: 479 -> 488 us): profiles/r04_ph8_balanced_rounds.txt.  Variant bit 21 switches it off (A/B).
     if (!split && !(a.variant & 0x200000) && t_all > s.G && t_all <= 2L * s.G) s.G = (int)((t_all + 1) / 2);
+#ifdef SAT_GEMM_EXPERIMENTS
+    if (!split && (a.variant & 0x400000) && t_all > s.G) {          // bit 22 (A/B): balanced rounds at any round count
+        const long rounds = (t_all + s.G - 1) / s.G;
+        s.G = (int)((t_all + rounds - 1) / rounds);
+    }
+#endif
     s.dp_rounds = (int)((split ? t_all : t_full) / s.G);
     // K-split with at least one whole round: the light tiles go FIRST (they idle their workgroup for half of round 0 -- a handful of
     // them) so that the remainder round holds full tiles only and splits evenly

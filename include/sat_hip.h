@@ -81,8 +81,9 @@ typedef struct sat_dit_cfg {
                                   global embedding drives per-layer scale/shift/gate of the self-attention and FF branches;
                                   needs "transformer.layers.N.to_scale_shift_gate.1.weight" [6*embed_dim, embed_dim] */
     int32_t gemm_dtype;        /* operand format of the block GEMMs and the attention kernels (fp32 accumulation throughout):
-                                  0 (SAT_GEMM_BF16): bf16 operands everywhere (the default, the headline path);
-                                  3 (SAT_GEMM_FP16): IEEE fp16 operands everywhere -- the same kernels built on v_mfma_f32_*_f16, which
+                                  0 (SAT_GEMM_BF16): bf16 operands everywhere (the C default of a zeroed struct; 3-4 % faster than fp16, 8x its operand rounding);
+                                  3 (SAT_GEMM_FP16): IEEE fp16 operands everywhere (what the Python package selects by default and bench.py measures) -- the same
+                                  kernels built on v_mfma_f32_*_f16, which
                                   gfx950 issues at the bf16 rate; three more significand bits (8x less operand rounding), and what the
                                   reference computes in on a GPU (inference/sampling.py:210 autocast, transformer.py:496-504).  Range
                                   policy: every fp32 -> fp16 conversion SATURATES at +-65504 (MODE.FP16_OVFL); values below 6e-8 flush;

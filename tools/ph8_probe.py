@@ -205,6 +205,11 @@ def narrow():
         print(f"narrow resid+ln {name} {m}x{n}x{k}: " + "  ".join(f"v{v} {statistics.median(t)*1e3:.1f} us ({fl/statistics.median(t)/1e9:.0f} TF)" for v, t in res.items()), flush=True)
 
 
+def balance_any():
+    """experiments build: balanced rounds at ANY round count (variant bit 22, the 'balanced' arm) against the shipped policy (only 1 < rounds <= 2)"""
+    balance(bit=0x400000)
+
+
 def race():
     # The same launch 40 times, alternating between two different A operands: every output must be bit-identical to the first run on
     # that operand and equal to its fp32 reference (a DMA / ds_read race shows up as rare differing tiles; a stale stream-K slab or
