@@ -56,6 +56,18 @@ def test_bench_dry_run_8_gpus():
     assert ids[3] == list(range(3, 64, 8))
 
 
+def test_bench_defaults_to_config3_at_n_gt_1():
+    """without --batch, N > 1 means BASELINE config 3 (8 prompts per GPU: 64 on 8 GPUs); one GPU means config 2 (one prompt).
+    The stub run also checks that every rank's own prompts survive the gather + host copy that the timed step ends with."""
+    line = _run(["bench.py", "--gpus", "8", "--dry-run"])
+    assert line["prompts_per_gpu"] == 8 and line["global_batch"] == 64
+    line = _run(["bench.py", "--gpus", "1", "--dry-run"])
+    assert line["prompts_per_gpu"] == 1 and line["global_batch"] == 1
+    line = _run(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], {"SAT_BENCH_STUB": "1"})
+    assert line["n_gpus"] == 2 and line["gathered_shape"] == [16, 2, 64]
+    assert line["gathered_first_samples"] == [(pid * 131 + 2000) % 30000 for pid in range(16)]
+
+
 def test_bench_rejects_mismatched_world():
     env = dict(os.environ, SAT_BENCH_STUB="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
