@@ -1525,7 +1525,7 @@ int SAT_OPNS::sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
                                  (((uintptr_t)a.ln_part | (uintptr_t)a.ln_c1 | (uintptr_t)a.ln_c2) & 15) == 0),
                   SAT_E_INVALID, "gemm: LayerNorm fold needs ln_c1 / ln_c2 / ln_eps, no separate bias (it is part of ln_c2), 16-byte aligned vectors");
     SAT_CHECK_ARG((((uintptr_t)a.xb | (uintptr_t)a.ln_part_out) & 15) == 0, SAT_E_INVALID, "gemm: xb / ln_part_out must be 16-byte aligned");
-    if ((a.variant & 0xfff) % 100 == 80 || (a.variant & 0xfff) % 100 == 81 || (a.variant & 0xfff) % 100 == 84 || (a.variant & 0xfff) % 100 == 85 || (a.variant & 0xfff) % 100 == 86) return sat_launch_gemm_ph8(epi, a, stream);      // 256x256x64, 8 waves, 8-phase schedule (gemm_ph8.hip)
+    if ((a.variant & 0xfff) % 100 == 80 || (a.variant & 0xfff) % 100 == 81) return sat_launch_gemm_ph8(epi, a, stream);      // 256x256x64, 8 waves, 8-phase schedule (gemm_ph8.hip)
     switch (epi) {
         case EPI_F32:
         case EPI_RESID: return launch_epi<EPI_F32>(a, stream);

@@ -206,7 +206,7 @@ __device__ __forceinline__ void ph8_load_resid(const Ph8F32Epi& e, f32x4_t (&old
 // RT = true: gate / producer decided at run time (the adaLN path and the reduce kernel: uniform branches, conservative waits);
 // RT = false: no gate, PROD compile-time -- the straight-line code the pipelined tile epilogue needs
 template <bool RT, bool PROD_C>
-__device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t* v, const f32x4_t (&old)[4], int m, int ncol0, int q4) {
+__device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t (&v)[4], const f32x4_t (&old)[4], int m, int ncol0, int q4) {
     const int off = (m * e.ldc + ncol0 + 4 * q4) * 4;
     [[maybe_unused]] const float* grow = nullptr;
     bool prod = PROD_C;
@@ -270,29 +270,16 @@ __device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t* v, 
 // GATED (fp32 output only): the adaLN build of the residual epilogue -- (acc + bias) * gate[sequence] before the add
 // (transformer.py:674, 688).  A kernel of its own: a second copy of the straight-line epilogue inside one kernel made the register
 // allocator spill, a uniform branch inside it hides the vmcnt bookkeeping.
-template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0, bool GATED = false, int W4 = 0>
-__global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0, bool GATED = false>
+__global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sched sc, unsigned long long* ts = nullptr) {
     sat_f16_saturate();
-    // W4: the same tile, LDS image, DMA sources and epilogues with FOUR waves of 128 x 128 (one per SIMD, 256 accumulator registers: the
-    // 512-register budget of a lone wave) -- a wave owns two of the four 64-column groups ("virtual wave columns" wc, wc + 1)
-    static_assert(!W4 || (WN == 4 && MFQ == 4 && FP8 == 0), "the four-wave loop is written for the 256 x 256 tile");
-    constexpr int NW = W4 ? 4 : 2 * WN, NT = NW * 64;
-    constexpr int NBW = W4 ? 8 : 4;               // 16-column blocks of a wave
+    constexpr int NW = 2 * WN, NT = NW * 64;
     constexpr int QR = MFQ * 16;                 // rows of one quadrant of a wave
     constexpr int WR = 2 * QR;                   // rows of a wave
     constexpr int BM = 2 * WR, BN = WN * 64;
     constexpr int MB = 2 * MFQ;                  // 16-row blocks of a wave
     constexpr int AH = (BM / 2) * 128, WH = (BN / 2) * 128;          // bytes of an A / W half-tile
-    // LDS-DMA instructions (1 KiB = 8 rows each) per wave and half-tile.  WN = 3 (6 waves): the 16 pieces of an A half-tile do not divide by 6 --
-    // every wave issues 3, the last two land on pieces 0 and 1 a second time (same bytes, same place); the counted waits below follow NAI / NWI
-    constexpr int APIECES = (BM / 2) / 8, WPIECES = (BN / 2) / 8;
-    constexpr int NAI = (APIECES + NW - 1) / NW, NWI = WPIECES / NW;
-    static_assert(WPIECES % NW == 0, "a W half-tile is a whole number of pieces per wave");
-    static_assert((PH2 && PH2V == 1) || (NAI == 2 && NWI == 2), "the four-phase and early-W-hi loops are written for 2 + 2 pieces per wave");
-    // LayerNorm prologue: two threads per row where the workgroup has them (8 waves), one per row otherwise (6 waves, 256 rows)
-    constexpr int TPR = NT >= 2 * BM ? 2 : 1;
-    constexpr int LNP = (W4 && TPR == 1) ? 24 : 12;          // partial pairs a row thread preloads on the fast path (K = 1536: 2 x 12, or 1 x 24 with 512 registers)
-    static_assert(NT >= BM, "one thread per row at least");
+    static_assert(NT / 2 == BM, "two threads per row in the LayerNorm prologue");
     [[maybe_unused]] int ts_n = 0;
     constexpr int BUF_BYTES = 2 * (AH + WH), RING_BYTES = 2 * BUF_BYTES;
     auto koff = [](int kind) { return kind == 0 ? 0 : kind == 1 ? WH : kind == 2 ? WH + AH : 2 * WH + AH; };          // W-lo, A-lo, W-hi, A-hi
@@ -301,7 +288,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
     const int tid_ = threadIdx.x;
     const int lane = tid_ & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const int wr = W4 ? wave >> 1 : wave / WN, wc = W4 ? 2 * (wave & 1) : wave % WN;
+    const int wr = wave / WN, wc = wave % WN;
     const int l15_ = lane & 15, q4_ = lane >> 4;
     const int M = g.M, N = g.N, K = g.K;
     const int wgi = xcd_remap(blockIdx.x, sc.G);          // consecutive logical workgroups share an XCD (and so the tiles they split)
@@ -338,26 +325,18 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
     // ---- LDS-DMA sources.  One instruction of one wave fills 8 LDS rows (1 KiB); round i of wave w covers rows 64 i + 8 w + (lane >> 3).
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((unsigned)M * (unsigned)K * 2u), 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = rsA;
-    // (fixed bounds: an array whose bound depends on the template parameters, captured by the generic lambdas below, makes this compiler drop the
-    // kernel's host-side stub without a diagnostic -- the library then fails to load with an undefined kernel symbol)
-    static_assert(NAI <= 4 && NWI <= 4, "voffA / voffW bounds");
-    int voffA[4], voffW[2][4];          // [round] (A: lo; hi = + 64 rows), [ni][round]
+    int voffA[2], voffW[2][2];          // [round] (A: lo; hi = + 64 rows), [ni][round]
     auto setup_dma = [&](const Seg& s) {
         int lane_l = lane;
         asm volatile("" : "+v"(lane_l));
         rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(g.W + (size_t)s.n0 * K), 0, BN * K * 2, 0x00020000);
         const int sub = lane_l >> 3, pos = lane_l & 7;
 #pragma unroll
-        for (int i = 0; i < NAI; ++i) {
-            const int r = (i * (NW * 8) + wave * 8 + sub) % (BM / 2);          // LDS row of the half-tile (wraps for the duplicate pieces)
+        for (int i = 0; i < 2; ++i) {
+            const int r = i * (NW * 8) + wave * 8 + sub;             // LDS row of the half-tile
             const int c = pos ^ ((r >> 1) & 7);
             // A: LDS rows [0,64) belong to wave row 0, [64,128) to wave row 1; rows beyond M are out of range of rsA: zeros
             voffA[i] = (s.m0 + (r / QR) * WR + (r % QR)) * (K * 2) + c * 16;
-        }
-#pragma unroll
-        for (int i = 0; i < NWI; ++i) {
-            const int r = i * (NW * 8) + wave * 8 + sub;
-            const int c = pos ^ ((r >> 1) & 7);
             // W: LDS rows [32 w', 32 w' + 32) belong to wave column w'; row = 16 nf + fragment row
             const int wcol = r >> 5, nf = (r >> 4) & 1, fi = r & 15;
 #pragma unroll
@@ -371,20 +350,14 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
         }
     };
     const int hiA = QR * K * 2;
-    [[maybe_unused]] const int a_wrap = (APIECES % NW != 0 && wave >= APIECES - (NAI - 1) * NW) ? APIECES * 1024 : 0;
     auto issue = [&](int kind, int buf, int kt) {          // kind: 0 W-lo, 1 A-lo, 2 W-hi, 3 A-hi (compile-time after inlining)
         char* dst = smem + buf * BUF_BYTES + koff(kind) + wave * 1024;
         const int soff = __builtin_amdgcn_readfirstlane(kt * 128);      // (stays scalar even if the K-tile counter was spilled to a VGPR lane)
-        if (kind & 1) {
 #pragma unroll
-            for (int i = 0; i < NAI; ++i) {
-                // (the last round of a 6-wave workgroup wraps: waves beyond the half-tile's end land on its first pieces again)
-                char* d = dst + i * (NW * 1024) - ((APIECES % NW != 0 && i == NAI - 1) ? a_wrap : 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_p)d, 16, voffA[i] + (kind == 3 ? hiA : 0), soff, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NWI; ++i)
+        for (int i = 0; i < 2; ++i) {
+            if (kind & 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_p)(dst + i * (NW * 1024)), 16, voffA[i] + (kind == 3 ? hiA : 0), soff, 0, 0);
+            else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_p)(dst + i * (NW * 1024)), 16, voffW[kind >> 1][i], soff, 0, 0);
         }
     };
@@ -400,7 +373,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
         offW[ks] = (wc * 32 + l15_) * 128 + ch;
     }
 
-    f32x4_t acc[MB][NBW];
+    f32x4_t acc[MB][4];
     opx8 fa[MFQ][2], fwl[2][2], fwh[2][2];
     typedef int i32x8_t __attribute__((ext_vector_type(8)));
     [[maybe_unused]] i32x8_t fa8[MFQ], fw8l[2], fw8h[2];          // FP8: one 32-byte fragment per 16-row block and K-tile
@@ -586,7 +559,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
             if constexpr (MODE <= 1) {
                 if constexpr (!EARLY_WHI) issue(2, BUF ^ 1, t + 1);
                 issue(3, BUF ^ 1, t + 1);
-                wait_vmcnt<2 * NAI + 2 * NWI>();
+                wait_vmcnt<8>();
             } else {
                 wait_vmcnt<0>();
             }
@@ -604,9 +577,9 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
                 issue(0, BUF, t + 2);
                 issue(1, BUF, t + 2);
                 if constexpr (EARLY_WHI) issue(2, BUF, t + 2);
-                wait_vmcnt<EARLY_WHI ? 8 : 2 * NAI + NWI>();
+                wait_vmcnt<EARLY_WHI ? 8 : 6>();
             } else if constexpr (MODE == 1) {
-                wait_vmcnt<NAI>();
+                wait_vmcnt<2>();
             }
             __builtin_amdgcn_sched_barrier(0);
             wait_lgkmcnt<0>();
@@ -630,100 +603,6 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
         if (wr == 0) __builtin_amdgcn_s_barrier();
     };
 
-    // W4 main loop.  A K-tile is two k32 steps of 64 MFMAs (8 row blocks x 8 column blocks); the 16 fragments of the NEXT step are read
-    // while the current step's MFMAs issue (register double buffer), the ring is two whole K-tiles:
-    //   step 0 of tile t: read (t, k32..63)        -> lgkmcnt(0), vmcnt(0) [tile t + 1, issued one K-tile ago], s_barrier: everybody is done with
-    //                                                 stage t & 1 and sees tile t + 1
-    //   step 1 of tile t: read (t + 1, k0..31) and issue the 16 DMA pieces of tile t + 2 into stage t & 1
-    // one barrier per K-tile.  VALID: 2 = all rows, 1 = only the wave's first 64 rows lie inside M, 0 = none (the wave stages and joins barriers).
-    [[maybe_unused]] auto main_loop4 = [&](auto swap_c, auto valid_c, const int kt0, const int nk) {
-        constexpr bool SWAP = decltype(swap_c)::value;
-        constexpr int VALID = decltype(valid_c)::value;
-        opx8 fa4[2][8], fw4[2][8];
-        // One k32 step in source order = issue order: NDS fragment reads of the NEXT step, then NVM DMA pieces, each followed by its share of
-        // this step's MFMAs (in-place accumulators in the ACC registers: mfma_16x16x32_acc), pinned by scheduling barriers.
-        auto ld_w = [&](int stage, int ks, int cb) {
-            return *reinterpret_cast<const opx8*>(smem + stage * BUF_BYTES + koff(((cb >> 1) & 1) ? 2 : 0) + offW[ks] + (cb >> 2) * 4096 + (cb & 1) * 2048);
-        };
-        auto ld_a = [&](int stage, int ks, int mb) {
-            return *reinterpret_cast<const opx8*>(smem + stage * BUF_BYTES + koff(mb >= 4 ? 3 : 1) + offA[ks] + (mb & 3) * 2048);
-        };
-        constexpr int NMB = VALID == 2 ? 8 : VALID == 1 ? 4 : 0;
-        // RD: 0 nothing to read, 1 read (rstage, rks) into buffer nb; DMA: issue tile tdma into stage dstage
-        auto step = [&](auto cur_c, auto rd_c, auto dma_c, int rstage, int rks, int dstage, int tdma) {
-            constexpr int CUR = decltype(cur_c)::value, NXT = CUR ^ 1;
-            constexpr bool RD = decltype(rd_c)::value != 0, DMA = decltype(dma_c)::value != 0;
-            constexpr int NSLOT = 16;                 // slots of NMB * 8 / 16 MFMAs
-            constexpr int PER = NMB * 8 / NSLOT;
-#pragma unroll
-            for (int sl = 0; sl < NSLOT; ++sl) {
-                // W4 == 1: one read / one DMA piece per slot; W4 == 2: two per slot in the first eight slots (reads retire, and DMA pieces are in
-                // flight, half a step earlier)
-                constexpr int PS = W4 == 2 ? 2 : 1;
-                if constexpr (RD && NMB > 0) {
-#pragma unroll
-                    for (int u = 0; u < PS; ++u) {
-                        const int e = sl * PS + u;
-                        if (e < 8) fw4[NXT][e] = ld_w(rstage, rks, e);
-                        else if (e < 8 + NMB) fa4[NXT][e - 8] = ld_a(rstage, rks, e - 8);
-                    }
-                }
-                if constexpr (DMA && DBG != 2) {
-#pragma unroll
-                    for (int u = 0; u < PS; ++u) {
-                        // 16 pieces: kind k = e / 4 (W-lo, A-lo, W-hi, A-hi), piece i = e % 4
-                        const int e = sl * PS + u;
-                        if (e < 16) {
-                            const int kind = e >> 2, i = e & 3;
-                            char* dst = smem + dstage * BUF_BYTES + koff(kind) + wave * 1024 + i * (NW * 1024);
-                            const int soff = __builtin_amdgcn_readfirstlane(tdma * 128);
-                            if (kind & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_p)dst, 16, voffA[i] + (kind == 3 ? hiA : 0), soff, 0, 0);
-                            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_p)dst, 16, voffW[kind >> 1][i], soff, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < PER; ++j) {
-                    const int idx = sl * PER + j;          // cb fastest: eight MFMAs share one A fragment
-                    const int mb = idx >> 3, cb = idx & 7;
-                    if constexpr (SWAP) mfma_16x16x32_acc(fw4[CUR][cb], fa4[CUR][mb], acc[mb][cb]);
-                    else mfma_16x16x32_acc(fa4[CUR][mb], fw4[CUR][cb], acc[mb][cb]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        using B0 = std::integral_constant<int, 0>;
-        using B1 = std::integral_constant<int, 1>;
-        // MODE 0: steady state; 1: tile t + 1 is the range's last (nothing to issue); 2: tile t is the last (nothing to read either)
-        auto k_tile4 = [&](auto st_c, auto mode_c, int t) {
-            constexpr int ST = decltype(st_c)::value;
-            constexpr int MODE = decltype(mode_c)::value;
-            step(B0{}, B1{}, B0{}, ST, 1, 0, 0);
-            wait_lgkmcnt<0>();
-            if constexpr (DBG != 1) wait_vmcnt<0>();          // (DBG 1 / 2, wrong results: without the wait / without the DMA)
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MODE == 0) step(B1{}, B1{}, B1{}, ST ^ 1, 0, ST, t + 2);
-            else if constexpr (MODE == 1) step(B1{}, B1{}, B0{}, ST ^ 1, 0, 0, 0);
-            else step(B1{}, B0{}, B0{}, 0, 0, 0, 0);
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) fw4[0][cb] = ld_w(0, 0, cb);          // (tiles kt0, kt0 + 1 are visible: the caller's barrier)
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) fa4[0][mb] = ld_a(0, 0, mb);
-        const int kt_last = kt0 + nk - 2;
-        for (int t = kt0; t < kt_last; t += 2) {
-            k_tile4(I0{}, I0{}, t);
-            k_tile4(I1{}, I0{}, t + 1);
-        }
-        k_tile4(I0{}, I1{}, kt_last);
-        k_tile4(I1{}, I2{}, kt_last + 1);
-        asm volatile("s_nop 15\n\ts_nop 15");          // (the assembler-level MFMAs are invisible to the hazard recogniser: results are read >= 18 wait states later)
-    };
-
     // ---- LayerNorm fold, consumer side (GemmArgs): (mean, 1/std) of the tile's 256 rows from the producer's per-64-column partial
     // sums and the tile's 256 (c1, c2) channel constants go to LDS behind the ring (two buffers: the next K-range's are written
     // while the current epilogue still reads its own).  Without the fold the same epilogues run on (0, 1), 0, bias.
@@ -733,9 +612,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
     constexpr int LN_BYTES = (BM + BN) * 8;          // (mean, rstd) per row, then c1[BN], c2[BN]
     const bool ln_fold = LN_CONS && g.ln_part != nullptr;
     const int np = K >> 6;
-    // 12 partial pairs per thread, held in registers across the DMA issue.  (One thread per row -- the 6-wave geometry -- would need 24: it takes the
-    // plain loop behind the DMA instead, which costs nothing where it is used: single-round launches wait for their first tile right after.)
-    const bool ln_fast = ln_fold && np == LNP * TPR && (TPR == 2 || W4);
+    const bool ln_fast = ln_fold && np == 24;             // 12 partial pairs per thread, held in registers across the DMA issue
     // bf16: rstd (acc - mean c1) + c2.  e4m3 (no fold): the same slots carry the dequantisation -- st = (-, a_scale[row]),
     // c1 = w_scale[channel], c2 = bias -- and the epilogues compute a_scale w_scale acc + bias
     auto fold = [](float a, float mean, float rstd, float c1, float c2) {
@@ -746,20 +623,20 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
     auto prepare = [&](const Seg& s, int lb) {
         int tid = tid_;
         asm volatile("" : "+v"(tid));            // (keeps this block's address arithmetic inside the persistent loop, see the epilogue)
-        [[maybe_unused]] float2 lnp[LNP];         // local: nothing of this is live across the main loop
+        [[maybe_unused]] float2 lnp[12];         // local: nothing of this is live across the main loop
         [[maybe_unused]] f32x4_t lncst = {0.f, 0.f, 0.f, 0.f};
         [[maybe_unused]] float a_sc = 1.f;
         [[maybe_unused]] const int ct = NT - 1 - tid;        // the last BN / 2 threads bring in the channel constants, 16 bytes each
         if constexpr (LN_CONS) {
-            if (ln_fast && tid < BM * TPR) {
-                int m = s.m0 + tid / TPR;
+            if (ln_fast) {
+                int m = s.m0 + (tid >> 1);
                 m = m < M ? m : M - 1;
-                const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np + (tid % TPR);
+                const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np + (tid & 1);
 #pragma unroll
-                for (int i = 0; i < LNP; ++i) lnp[i] = pp[TPR * i];
+                for (int i = 0; i < 12; ++i) lnp[i] = pp[2 * i];
             } else {
 #pragma unroll
-                for (int i = 0; i < LNP; ++i) lnp[i] = make_float2(0.f, 0.f);
+                for (int i = 0; i < 12; ++i) lnp[i] = make_float2(0.f, 0.f);
             }
             if (ct < BN / 2) {
                 const bool first = ct < BN / 4;
@@ -769,7 +646,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
                 if (src) lncst = *reinterpret_cast<const f32x4_t*>(src);
             }
             if constexpr (FP8 != 0) {
-                const int m = s.m0 + (tid / TPR < BM ? tid / TPR : BM - 1);
+                const int m = s.m0 + (tid >> 1);
                 a_sc = g.a_scale[m < M ? m : M - 1];
             }
         }
@@ -778,33 +655,31 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue(j, 0, s.kt0);
 #pragma unroll
-        for (int j = 0; j < (W4 ? 4 : (PH2 && PH2V != 2) ? 2 : 3); ++j) issue(j, 1, s.kt0 + 1);
+        for (int j = 0; j < ((PH2 && PH2V != 2) ? 2 : 3); ++j) issue(j, 1, s.kt0 + 1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LN_CONS) {
             float2* lnst = reinterpret_cast<float2*>(smem + RING_BYTES + lb * LN_BYTES);
             float* lnc = reinterpret_cast<float*>(smem + RING_BYTES + lb * LN_BYTES + BM * 8);
-            const int r = tid / TPR, sub = tid % TPR;           // TPR threads per row
+            const int r = tid >> 1, sub = tid & 1;           // two threads per row
             float sum = 0.f, sq = 0.f;
 #pragma unroll
-            for (int i = 0; i < LNP; ++i) {
+            for (int i = 0; i < 12; ++i) {
                 sum += lnp[i].x;
                 sq += lnp[i].y;
             }
-            if (ln_fold && !ln_fast && r < BM) {             // any other K: plain loop (behind the DMA pieces in the memory queue)
+            if (ln_fold && !ln_fast) {                       // any other K: plain loop (behind the DMA pieces in the memory queue)
                 int m = s.m0 + r;
                 m = m < M ? m : M - 1;
                 const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np;
-                for (int i = sub; i < np; i += TPR) {
+                for (int i = sub; i < np; i += 2) {
                     const float2 v = pp[i];
                     sum += v.x;
                     sq += v.y;
                 }
             }
-            if constexpr (TPR == 2) {
-                sum += dpp_move<0xB1>(sum);
-                sq += dpp_move<0xB1>(sq);
-            }
-            if (sub == 0 && r < BM) {
+            sum += dpp_move<0xB1>(sum);
+            sq += dpp_move<0xB1>(sq);
+            if (sub == 0) {
                 const float inv_k = 1.0f / (float)K;
                 const float mean = sum * inv_k;
                 const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
@@ -816,17 +691,15 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
 
     // ---- epilogues.  Transposed: lane (l15, q4) holds, for block (mb = 0..7, nb = 2 ni + nf): token row m0 + wr*128 + mb*16 + l15,
     //      channels n0 + wc*64 + chan_of(ni, nf, 4 q4 + r), r = 0..3
-    auto epilogue = [&](const Seg& s, int lb, auto half_c) {
-        constexpr int AO = decltype(half_c)::value * 4;          // W4: the wave's second 64-column group = accumulator columns 4..7
-        const int wcE = wc + decltype(half_c)::value;
+    auto epilogue = [&](const Seg& s, int lb) {
         // (laundered copies: keeps the segment-invariant address arithmetic of the epilogue from being hoisted out of the persistent
         // loop, where it would stay live across the main loop and push its 128 + 64 registers into scratch)
         int l15 = l15_, q4 = q4_;
         asm volatile("" : "+v"(l15), "+v"(q4));
         const int mrow0 = s.m0 + wr * WR + l15;
-        const int ncol0 = s.n0 + wcE * 64;
+        const int ncol0 = s.n0 + wc * 64;
         [[maybe_unused]] const float2* ln = reinterpret_cast<const float2*>(smem + RING_BYTES + lb * LN_BYTES) + wr * WR;
-        [[maybe_unused]] const float* lc1 = reinterpret_cast<const float*>(smem + RING_BYTES + lb * LN_BYTES + BM * 8) + wcE * 64;
+        [[maybe_unused]] const float* lc1 = reinterpret_cast<const float*>(smem + RING_BYTES + lb * LN_BYTES + BM * 8) + wc * 64;
         [[maybe_unused]] const float* lc2 = lc1 + BN;
         if constexpr (EPI == EPI_F32) {
             // Batches of two row blocks, double-buffered: the residual loads of batch h + 1 are issued before batch h is finished, so 16
@@ -847,7 +720,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
                     }
                     __builtin_amdgcn_sched_barrier(0);          // (two batches in flight, not four: straight-line code lets the scheduler hoist every
 #pragma unroll                                                  //  load to the top, which is 128 registers of residual next to 128 accumulators)
-                    for (int i = 0; i < 2; ++i) ph8_epi_f32_row<RT, PROD>(fe, acc[h * 2 + i] + AO, old[h & 1][i], mrow0 + (h * 2 + i) * 16, ncol0, q4);
+                    for (int i = 0; i < 2; ++i) ph8_epi_f32_row<RT, PROD>(fe, acc[h * 2 + i], old[h & 1][i], mrow0 + (h * 2 + i) * 16, ncol0, q4);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
@@ -881,8 +754,8 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
                     float hv[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = fold(acc[mb][AO + nf][e], st.x, st.y, c1v[nf][e], c2v[nf][e]);
-                        const float gt = fold(acc[mb][AO + 2 + nf][e], st.x, st.y, c1g[nf][e], c2g[nf][e]);
+                        const float v = fold(acc[mb][nf][e], st.x, st.y, c1v[nf][e], c2v[nf][e]);
+                        const float gt = fold(acc[mb][2 + nf][e], st.x, st.y, c1g[nf][e], c2g[nf][e]);
                         hv[e] = v * silu_fast(gt);
                         if constexpr (FP8 != 0) hv8[4 * nf + e] = hv[e];
                     }
@@ -948,7 +821,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) x[nb][e] = fold(acc[mb][AO + nb][e], st.x, st.y, c1[nb][e], c2[nb][e]);
+                        for (int e = 0; e < 4; ++e) x[nb][e] = fold(acc[mb][nb][e], st.x, st.y, c1[nb][e], c2[nb][e]);
                     if (kind & 2) {
                         const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(he.rope_cos + (size_t)sq_ * 16 + 4 * q4);
                         const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(he.rope_sin + (size_t)sq_ * 16 + 4 * q4);
@@ -1005,7 +878,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
                         for (int e = 0; e < 4; ++e) {
                             const float mean = e < 2 ? st01[2 * e] : st23[2 * e - 4];
                             const float rstd = e < 2 ? st01[2 * e + 1] : st23[2 * e - 3];
-                            v[e] = fold(acc[mb][AO + nb][e], mean, rstd, c1[nb], c2[nb]);
+                            v[e] = fold(acc[mb][nb][e], mean, rstd, c1[nb], c2[nb]);
                         }
                         const size_t drow = (size_t)(nb * 16 + l15) * Spad;
                         if (whole4 && shift) {         // aligned: (ss[0] + ob) % 4 == mbase % 4 == 0
@@ -1037,27 +910,25 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
             // fp32 output: the accumulators of a WHOLE tile start from the bias (lane (l15, q4) owns channels 16 nb + 4 q4 .. + 3 of every
             // row block) -- sixteen registers the epilogue then does not need next to its residual batches; a partial K-range starts
             // from zero, ph8_reduce_f32_kernel adds the bias to the sums
-            f32x4_t b0[NBW];
-#pragma unroll
-            for (int j = 0; j < NBW; ++j) b0[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            f32x4_t b0[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             if constexpr (EPI == EPI_F32) {
                 if (g.bias && cur.whole) {
                     int q4 = q4_;
                     asm volatile("" : "+v"(q4));
 #pragma unroll
-                    for (int j = 0; j < NBW; ++j) b0[j] = *reinterpret_cast<const f32x4_t*>(g.bias + cur.n0 + wc * 64 + 4 * q4 + j * 16);
+                    for (int j = 0; j < 4; ++j) b0[j] = *reinterpret_cast<const f32x4_t*>(g.bias + cur.n0 + wc * 64 + 4 * q4 + j * 16);
                 }
             }
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
-                for (int j = 0; j < NBW; ++j) acc[i][j] = b0[j];
+                for (int j = 0; j < 4; ++j) acc[i][j] = b0[j];
         }
         // the range's first tiles have landed (and the previous epilogue's stores are out); LayerNorm constants are visible
         wait_vmcnt<0>();
         wait_lgkmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if constexpr (DBG == 2 && !W4) {       // ablation: fragments are read once
+        if constexpr (DBG == 2) {       // ablation: fragments are read once
             read_w(0, 0, fwl);
             read_w(0, 1, fwh);
             read_a(0, 0);
@@ -1066,21 +937,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
         if constexpr (DBG == 9) t0 = __builtin_amdgcn_s_memrealtime();
         const int mq = cur.m0 + wr * WR;
         const bool rows_valid = mq < M;
-        if constexpr (W4 != 0) {
-            using V0 = std::integral_constant<int, 0>;
-            using V1 = std::integral_constant<int, 1>;
-            using V2 = std::integral_constant<int, 2>;
-            const int valid = !rows_valid ? 0 : (mq + QR < M ? 2 : 1);
-            if (cur.tr) {
-                if (valid == 2) main_loop4(std::true_type{}, V2{}, cur.kt0, cur.nk);
-                else if (valid == 1) main_loop4(std::true_type{}, V1{}, cur.kt0, cur.nk);
-                else main_loop4(std::true_type{}, V0{}, cur.kt0, cur.nk);
-            } else {
-                if (valid == 2) main_loop4(std::false_type{}, V2{}, cur.kt0, cur.nk);
-                else if (valid == 1) main_loop4(std::false_type{}, V1{}, cur.kt0, cur.nk);
-                else main_loop4(std::false_type{}, V0{}, cur.kt0, cur.nk);
-            }
-        } else if constexpr (PH2) {
+        if constexpr (PH2) {
             if (cur.tr) main_loop2(std::true_type{}, cur.kt0, cur.nk, rows_valid, mq + QR < M);
             else main_loop2(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + QR < M);
         } else {
@@ -1088,12 +945,10 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
             else main_loop(std::false_type{}, cur.kt0, cur.nk, rows_valid, mq + QR < M);
         }
         if constexpr (DBG == 9) t1 = __builtin_amdgcn_s_memrealtime();
-        // (the 6-wave geometry only serves single-round launches -- sat_gemm_ph8_192_supports -- so its workgroups have exactly one K-range: the
-        // next-range machinery drops out at compile time, which is what keeps its heads epilogue inside 256 registers without scratch)
-        const bool more = WN == 3 ? false : next_seg(nxt);
+        const bool more = next_seg(nxt);
         if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
         bool fin = true;
-        if (EPI == EPI_F32 && !W4 && !cur.whole) {           // a part of a K-split tile (fp32 output only): plain stores of the raw accumulators, the kernel
+        if (EPI == EPI_F32 && !cur.whole) {           // a part of a K-split tile (fp32 output only): plain stores of the raw accumulators, the kernel
             int lane_l = lane;                            // boundary publishes them to ph8_reduce_f32_kernel
             asm volatile("" : "+v"(lane_l));              // (keeps the per-lane slab address out of the state carried across the main loop)
             float* mine = sc.sk_slab + (size_t)wgi * (BM * BN) + (size_t)(wave * MB * 4) * 256 + lane_l * 4;
@@ -1104,10 +959,7 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
             fin = false;
         }
         if constexpr (DBG == 9) t2 = __builtin_amdgcn_s_memrealtime();
-        if (fin && rows_valid) {
-            epilogue(cur, lb, std::integral_constant<int, 0>{});
-            if constexpr (W4 != 0) epilogue(cur, lb, std::integral_constant<int, 1>{});
-        }
+        if (fin && rows_valid) epilogue(cur, lb);
         if constexpr (DBG == 9) {
             if (tid_ == 0 && ts_n < 4) {
                 unsigned long long* o = ts + ((size_t)blockIdx.x * 4 + ts_n) * 8;
@@ -1125,11 +977,9 @@ __global__ __launch_bounds__((W4 ? 4 : 2 * WN) * 64) void gemm_ph8_kernel(GemmAr
 // Second launch of a K-split fp32-output GEMM: workgroup (j, mb) adds the slabs of remainder tile j for the row blocks mb of all
 // eight waves -- every contributor's accumulator image in ascending workgroup order, bit-deterministic -- and runs the fp32 /
 // residual / LayerNorm-producer epilogue on the sums.  Same lane <-> element map as the GEMM, so the slab reads are 1-KiB coalesced.
-template <int MFQ>
 __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sched sc) {
     sat_f16_saturate();
-    constexpr int MB = 2 * MFQ, BM = 64 * MFQ;          // row blocks per wave, rows of a tile (256 columns, 8 waves)
-    const int j = blockIdx.x / MB, mb = blockIdx.x % MB;
+    const int j = blockIdx.x >> 3, mb = blockIdx.x & 7;
     int first, parts;
     ph8_tile_parts(sc, j, first, parts);
     if (parts <= 1) return;                          // a whole tile: finished by the GEMM launch itself
@@ -1137,12 +987,12 @@ __global__ __launch_bounds__(512) void ph8_reduce_f32_kernel(GemmArgs g, Ph8Sche
     const int wr = wave >> 2, wc = wave & 3, l15 = lane & 15, q4 = lane >> 4;
     int tm, tn;
     ph8_tile_of(sc, sc.rem0 + j, tm, tn);
-    const int m = tm * BM + wr * (BM / 2) + mb * 16 + l15;
+    const int m = (tm << 8) + wr * 128 + mb * 16 + l15;
     const int ncol0 = (tn << 8) + wc * 64;
-    if (tm * BM + wr * (BM / 2) >= g.M) return;
+    if ((tm << 8) + wr * 128 >= g.M) return;
     f32x4_t v[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     for (int w = first; w < first + parts; ++w) {
-        const float* src = sc.sk_slab + (size_t)w * (BM * 256) + (size_t)(wave * MB * 4 + mb * 4) * 256 + lane * 4;
+        const float* src = sc.sk_slab + (size_t)w * 65536 + (size_t)(wave * 32 + mb * 4) * 256 + lane * 4;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) v[nb] += *reinterpret_cast<const f32x4_t*>(src + nb * 256);
     }
@@ -1184,7 +1034,7 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
     SAT_TRY(ph8_cus(cus));
     const bool have_slab = a.slab != nullptr;
     if (split < 0) split = (bm == 256 && epi_f32 && have_slab && ph8_auto_split(a, epi_f32, cus)) ? 1 : 0;
-    if (bn != 256 || !epi_f32) split = 0;          // the K-split machinery (slabs, reduce kernel) is built for 256-column fp32-output tiles
+    if (bm != 256 || !epi_f32) split = 0;          // the K-split machinery (slabs, reduce kernel) is built for the 256 x 256 fp32-output tile
     Ph8Sched s{};
     const int tiles_m = cdiv(a.M, bm), tail = a.M % bm;
     s.tiles_n = a.N / bn;
@@ -1233,7 +1083,7 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
         s.cls_n[0] = extra; s.cls_p[0] = pf + 1;
         s.cls_n[1] = n_full - extra; s.cls_p[1] = pf;
         s.cls_n[2] = n_light; s.cls_p[2] = pl;
-        const size_t need = (size_t)s.G * bm * bn * sizeof(float);
+        const size_t need = (size_t)s.G * 65536 * sizeof(float);
         SAT_CHECK_ARG(a.slab && a.slab_bytes >= need, SAT_E_WORKSPACE, "gemm(8-phase): the K-split of the remainder round needs %zu bytes of slab workspace, got %zu",
                       need, a.slab ? a.slab_bytes : (size_t)0);
         SAT_CHECK_ARG(((uintptr_t)a.slab & 15) == 0, SAT_E_INVALID, "gemm(8-phase): the slab workspace must be 16-byte aligned");
@@ -1247,7 +1097,7 @@ int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int
 unsigned long long* g_ts_buf = nullptr;
 #endif
 
-template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0, bool GATED = false, int W4 = 0>
+template <int EPI, int DBG = 0, bool PH2 = true, int PH2V = 1, int WN = 4, int MFQ = 4, int FP8 = 0, bool GATED = false>
 int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if constexpr (FP8 != 0) {
@@ -1260,7 +1110,7 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     } else {
         SAT_CHECK_ARG(!a.fp8 && !a.H8, SAT_E_UNSUPPORTED, "gemm(8-phase): built for bf16 operands");
     }
-    constexpr int BM = 64 * MFQ, BN = 64 * WN, NT = (W4 ? 4 : 2 * WN) * 64;
+    constexpr int BM = 64 * MFQ, BN = 64 * WN, NT = 2 * WN * 64;
     constexpr int LDS = 2 * 2 * (BM / 2 + BN / 2) * 128 + 2 * (BM + BN) * 8;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column)
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of %d", a.N, BN);
     SAT_CHECK_ARG(a.K % 128 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): K=%d must be a multiple of 128", a.K);
@@ -1280,13 +1130,10 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     }
     Ph8Sched sc;
     // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements, tests)
-    const int split = W4 ? 0 : (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;          // (the four-wave build has no slab image)
-    SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, BM, BN, (BM == 256 || BN == 256) ? 1 : 2, sc));
-    if constexpr (WN == 3)          // this geometry's kernel is compiled for ONE K-range per workgroup
-        SAT_CHECK_ARG(sc.dp_rounds + (sc.sk_tiles + sc.G - 1) / sc.G <= 1 && !sc.split, SAT_E_UNSUPPORTED,
-                      "gemm(8-phase, 256 x 192): %d x %d tiles do not fit one round of workgroups", cdiv(a.M, BM), a.N / BN);
+    const int split = (a.variant & 0x10000) ? 1 : (a.variant & 0x20000) ? 0 : -1;
+    SAT_TRY(ph8_schedule(a, split, EPI == EPI_F32, BM, BN, BM == 256 ? 1 : 2, sc));
     SAT_CHECK_ARG(GATED == (a0.gate != nullptr), SAT_E_INVALID, "gemm(8-phase): gated / plain build mismatch");
-    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ, FP8, GATED, W4>;
+    auto kern = gemm_ph8_kernel<EPI, DBG, PH2, PH2V, WN, MFQ, FP8, GATED>;
     SAT_TRY(sat_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS));
     unsigned long long* ts = nullptr;
 #ifdef SAT_GEMM_EXPERIMENTS
@@ -1297,7 +1144,7 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     }
 #endif
     hipLaunchKernelGGL(kern, dim3(sc.G), dim3(NT), LDS, stream, a, sc, ts);
-    if (sc.split) hipLaunchKernelGGL(ph8_reduce_f32_kernel<MFQ>, dim3(sc.sk_tiles * 2 * MFQ), dim3(512), 0, stream, a, sc);
+    if (sc.split) hipLaunchKernelGGL(ph8_reduce_f32_kernel, dim3(sc.sk_tiles * 8), dim3(512), 0, stream, a, sc);
     SAT_LAUNCH_CHECK();
     return 0;
 }
@@ -1346,34 +1193,6 @@ size_t SAT_OPNS::sat_gemm_ph8_slab_bytes(int epi, int M, int N, int K) {
 
 int SAT_OPNS::sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream) {
     const int dbg = (a.variant & 0xfff) / 100;
-    // 128 x 256 geometry (8 waves of 64 x 64, MFQ = 2), fp32 output, remainder... see launch below (variant 84): FF-out at one prompt
-#ifdef SAT_GEMM_EXPERIMENTS
-    if ((a.variant & 0xfff) % 100 == 85 && epi == EPI_SWIGLU && !a.fp8 && !a.H8) {
-        if (dbg == 1) return launch_ph8<EPI_SWIGLU, 1, true, 1, 4, 4, 0, false, 1>(a, stream);
-        if (dbg == 2) return launch_ph8<EPI_SWIGLU, 2, true, 1, 4, 4, 0, false, 1>(a, stream);
-        if (dbg == 9) return launch_ph8<EPI_SWIGLU, 9, true, 1, 4, 4, 0, false, 1>(a, stream);
-    }
-    if ((a.variant & 0xfff) % 100 == 86 && epi == EPI_SWIGLU && !a.fp8 && !a.H8) {
-        if (dbg == 0) return launch_ph8<EPI_SWIGLU, 0, true, 1, 4, 4, 0, false, 2>(a, stream);
-        if (dbg == 9) return launch_ph8<EPI_SWIGLU, 9, true, 1, 4, 4, 0, false, 2>(a, stream);
-    }
-#endif
-    // variant 85: the four-wave build of the 256 x 256 tile (128 x 128 per wave)
-    if ((a.variant & 0xfff) % 100 == 85 && dbg == 0 && !a.fp8 && !a.H8) {
-        switch (epi) {
-            case EPI_F32:
-            case EPI_RESID:
-                if (a.gate) return launch_ph8<EPI_F32, 0, true, 1, 4, 4, 0, true, 1>(a, stream);
-                return launch_ph8<EPI_F32, 0, true, 1, 4, 4, 0, false, 1>(a, stream);
-            case EPI_SWIGLU: return launch_ph8<EPI_SWIGLU, 0, true, 1, 4, 4, 0, false, 1>(a, stream);
-            case EPI_HEADS: return launch_ph8<EPI_HEADS, 0, true, 1, 4, 4, 0, false, 1>(a, stream);
-        }
-    }
-    if ((a.variant & 0xfff) % 100 == 84) {
-        if ((epi == EPI_F32 || epi == EPI_RESID) && dbg == 0 && !a.gate) return launch_ph8<EPI_F32, 0, true, 1, 4, 2>(a, stream);
-        sat_set_error("gemm(8-phase, 128 x 256): built for the ungated fp32-output epilogue");
-        return SAT_E_UNSUPPORTED;
-    }
 #ifdef SAT_GEMM_EXPERIMENTS
     // The 128 x 128 geometry (4 waves, two workgroups per CU), experiments build only: measured SLOWER than the 16-wave-family tiles at
     // every one-prompt shape (FF-out 69.5 us vs 62.3, to_out 26.8 vs 22.4, cross 25.0 vs 16.2, QKV 68 vs 51;

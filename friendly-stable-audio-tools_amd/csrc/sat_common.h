@@ -120,17 +120,6 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(opx8 a, opx8 b, f32x4 c) {
 #endif
 }
 
-// The same MFMA with the accumulator pinned to the ACC half of the register file and updated in place (for the one-wave-per-SIMD kernels
-// whose 256 accumulator registers are exactly that half: left to the register allocator, the AGPR form of the builtin gets a rotating
-// assignment with three v_accvgpr copies per MFMA)
-__device__ __forceinline__ void mfma_16x16x32_acc(opx8 a, opx8 b, f32x4& c) {
-#ifdef SAT_OPERAND_F16
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-#endif
-}
-
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // Wave-wide reductions without LDS traffic: four DPP steps reduce every row of 16 lanes (quad xor 1, quad xor 2, row_half_mirror,
