@@ -1407,7 +1407,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             }
         } else if (a.fp8 == 2) {      // block-scaled MFMA with unit scales: 2x the MFMA rate
             const int fv = a.variant & 0xff;
-            if ((fv == 80 || (fv == 0 && v == 22 && sat_g_wide_tile == 80)) && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
+            if ((fv == 80 || (fv == 0 && v == 22 && sat_g_wide_tile >= 80)) && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
             switch (v) {
                 case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 2>(a, stream);
                 case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 2>(a, stream);
@@ -1434,7 +1434,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             // (profiles/r03_ph8_streamk.txt): SwiGLU 1.26, heads 1.07, fp32 output with a long reduction 1.02 -- and with the K-split of the
             // remainder round (sat_gemm_ph8_splits) the last round costs ~0.35 of a round instead of 1.
             double s256 = score(256, 256, 1.0);
-            if (sat_g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) {
+            if (sat_g_wide_tile >= 80 && sat_gemm_ph8_supports(EPI, a)) {
                 const double rate = EPI == EPI_SWIGLU ? 1.26 : EPI == EPI_HEADS ? 1.07 : 1.02;
                 const long t = (long)cdiv(a.M, 256) * (a.N / 256);
                 const double rounds = sat_gemm_ph8_splits(EPI, a) ? (double)(t / cus) + 0.35 : (double)((t + cus - 1) / cus);
@@ -1455,7 +1455,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
     }
     // the 256x256 tile is the 8-wave / 8-phase kernel of gemm_ph8.hip wherever it applies (bf16 operands, K % 128 == 0);
     // sat_gemm_set_wide_tile(22) brings the 16-wave 2-stage tile back for A/B measurements
-    if (v == 22 && !(a.variant & 0xff) && sat_g_wide_tile == 80 && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
+    if (v == 22 && !(a.variant & 0xff) && sat_g_wide_tile >= 80 && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
     switch (v) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
         case 5: return launch_cfg<128, 128, 2, 2, EPI, true>(a, stream);
@@ -1495,7 +1495,8 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
 #ifndef SAT_OPERAND_F16
 int sat_g_wide_tile = 80;
 extern "C" int sat_gemm_set_wide_tile(int32_t tile) {
-    SAT_CHECK_ARG(tile == 22 || tile == 80, SAT_E_INVALID, "sat_gemm_set_wide_tile: 22 (16 waves, 2-stage ring) or 80 (8 waves, 8-phase)");
+    SAT_CHECK_ARG(tile == 22 || tile == 80 || tile == 81, SAT_E_INVALID,
+                  "sat_gemm_set_wide_tile: 22 (16 waves, 2-stage ring), 80 (8 waves, 8-phase) or 81 (80, also for the fp32-output GEMMs with K < 4096: A/B)");
     sat_g_wide_tile = tile;
     return 0;
 }

@@ -452,6 +452,16 @@ def full_model():
     out = torch.empty_like(x)
     ms = timeit(lambda: dit.denoise(x, 3.0, cfg_scale=7.0, out=out), iters=10, warm=2)
     print(f"DiT CFG step B={b}: {ms:.3f} ms  -> {4.544*b/ms:.1f} TFLOP/s effective; 100 steps = {ms/10:.2f} s", flush=True)
+    if os.environ.get("PROBE_WIDE_AB"):          # A/B of the wide-tile policy inside the model: 80 (shipped) vs the listed settings, interleaved
+        import statistics
+        tiles = [80] + [int(t) for t in os.environ["PROBE_WIDE_AB"].split(",")]
+        res = {t: [] for t in tiles}
+        for _ in range(4):
+            for t in tiles:
+                _hip.check(_hip.lib().sat_gemm_set_wide_tile(t))
+                res[t].append(timeit(lambda: dit.denoise(x, 3.0, cfg_scale=7.0, out=out), iters=6, warm=2))
+        _hip.check(_hip.lib().sat_gemm_set_wide_tile(80))
+        print("wide-tile A/B, DiT CFG step ms: " + " | ".join(f"{t}: {statistics.median(v):.3f} (min {min(v):.3f})" for t, v in res.items()), flush=True)
     print("denoise finite:", torch.isfinite(out).all().item(), "std", out.std().item())
     z = torch.randn(b, 64, 1024, device=dev)
     dec = model.pretransform.model
