@@ -742,10 +742,18 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
 // FP8: A and W are e4m3 bytes.  The launcher hands the kernel K/2 "bf16 columns", so staging, LDS layout and swizzle are
 // byte-for-byte those of the bf16 kernel (128-B rows now hold 128 k); a 16-B fragment is two 8-byte MFMA operands:
 // v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16 rate, but every LDS / L2 / HBM byte carries twice the k.
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
+// KG = 2 (round 4, fp32 output): TWO K-groups of WM x WN waves work on the same BM x BN tile, group g on the k-half g of every
+// 2 x BK slice (its own A / W rows in the stage), and exchange half of their partial sums through LDS at the end -- each group then
+// finishes 32 of its waves' 64 rows with the 32 x 64 staged epilogue.  A one-round launch (<= one tile per CU) gets 8 waves of 64 x 64
+// per CU instead of 8 waves of 32 x 64: a third less LDS fragment traffic per MFMA, which is what bounds the narrow tiles
+// (profiles/r04_narrow_tiles_negative.txt: two co-resident 4-wave workgroups of 64 x 64 waves beat the 8-wave tile by 17-21 % wherever
+// there are two workgroups per CU; at one prompt there is only one).
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0, int KG = 1>
+__global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     sat_f16_saturate();
-    constexpr int NT = WM * WN * 64;
+    static_assert(KG == 1 || (KG == 2 && EPI == EPI_F32 && FP8 == 0 && BK == 64 && BM / WM == 64 && BN / WN == 64),
+                  "K-groups: fp32 output, 64 x 64 wave tiles, 128-byte rows");
+    constexpr int NT = KG * WM * WN * 64;
     constexpr int TM = BM / WM;
     constexpr int TN = BN / WN;
     // the fused epilogues need a whole head / a value-gate pair per wave (64 columns); plain fp32 output takes any 32-multiple
@@ -756,16 +764,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // One LDS-DMA instruction of one wave moves 64 chunks = 1 KiB.  A stage holds WL_A + WL_B of them (A rows first, then
     // W rows, contiguous); wave w issues wave-loads w, w+NW, w+2NW, ...  When NW does not divide WL (256x192 on 12 waves:
     // 56 wave-loads) the first WL%NW waves carry one more than the rest, and the counted vmcnt wait is per wave.
-    constexpr int NW = WM * WN;
+    constexpr int NW = KG * WM * WN;                  // every wave loads
     constexpr int WL_A = BM * CPR / 64;
-    constexpr int WL = (BM + BN) * CPR / 64;
+    constexpr int WLG = (BM + BN) * CPR / 64;         // wave-loads of one K-group's rows of a stage
+    constexpr int WL = KG * WLG;
     constexpr int LPT = (WL + NW - 1) / NW;        // max LDS-DMA instructions per tile per wave
     constexpr int N_FULL = WL - (LPT - 1) * NW;    // waves [0, N_FULL) issue LPT, the others LPT-1
     constexpr bool UNIFORM = (WL % NW) == 0;
     constexpr int ROWB = BK * 2;
     constexpr bool MXA = FP8 == 3;                 // MXFP8 A operand: + one dword of E8M0 block scales per A row per stage
     constexpr int SCALE_WAVES = MXA ? BM / 64 : 0; // the first BM/64 waves each DMA 64 scale dwords per stage
-    constexpr int STAGE_BYTES = (BM + BN) * ROWB + (MXA ? BM * 4 : 0);
+    constexpr int GROUP_BYTES = (BM + BN) * ROWB + (MXA ? BM * 4 : 0);
+    constexpr int STAGE_BYTES = KG * GROUP_BYTES;
     constexpr int D = NS - 1;                      // prefetch distance
     static_assert(!MXA || D == 1 || UNIFORM, "MXFP8: counted waits are built for uniform tiles or 2-stage rings");
     static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
@@ -776,8 +786,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN;
-    const int wn = wave % WN;
+    const int grp = KG == 2 ? wave / (WM * WN) : 0;           // K-group
+    const int wv = KG == 2 ? wave % (WM * WN) : wave;
+    const int wm = wv / WN;
+    const int wn = wv % WN;
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
@@ -829,7 +841,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
     // fp32 residual epilogue of the small tiles (one 32-row block per wave, registers to spare): fetch the residual values NOW.
     // They are the oldest entries of the vector-memory queue, so every counted vmcnt wait of the K loop still holds.
-    constexpr bool PRE_RESID = EPI == EPI_F32 && MI == 1 && NI == 2 && NT <= 512;
+    constexpr bool PRE_RESID = EPI == EPI_F32 && (MI == 1 || KG == 2) && NI == 2 && NT <= 512;
+    // K-groups: the 32 rows this wave finishes
+    const int epi_m = m0 + wm * TM + (KG == 2 ? grp * 32 : 0);
+    const bool epi_rows_valid = KG == 2 ? epi_m < M : wave_rows_valid;
     [[maybe_unused]] f32x4 resid[PRE_RESID ? 8 : 1];
     if constexpr (PRE_RESID) {
         // (exactly the condition under which the staged epilogue runs, see the end of the kernel)
@@ -838,10 +853,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 #else
         const bool staged = true;
 #endif
-        const bool want = g.accumulate != 0 && wave_rows_valid && staged;
+        const bool want = g.accumulate != 0 && epi_rows_valid && staged;
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
-            const int m = m0 + wm * TM + ps * 4 + (lane >> 4);
+            const int m = epi_m + ps * 4 + (lane >> 4);
             resid[ps] = (want && m < M) ? *reinterpret_cast<const f32x4*>(g.C + (size_t)m * g.ldc + n0 + wn * TN + (lane & 15) * 4)
                                         : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -856,16 +871,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     const op_t* ld_ptr[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-        const int L = i * NW + wave;               // wave-uniform
-        const bool is_a = L < WL_A;
-        int q = (is_a ? L : L - WL_A) * 64 + lane;
+        const int L = KG == 2 ? grp * WLG + i * (WM * WN) + wv : i * NW + wave;               // wave-uniform; K-groups: a group stages its own rows
+        const int lg = KG == 2 ? grp : 0;
+        const int Lg = KG == 2 ? i * (WM * WN) + wv : L;
+        const bool is_a = Lg < WL_A;
+        int q = (is_a ? Lg : Lg - WL_A) * 64 + lane;
         int row = q / CPR, pos = q % CPR;
         int c = (BK == 128) ? (pos ^ (row & 15)) : (BK == 64) ? (pos ^ ((row >> 1) & 7)) : (pos ^ ((row >> 2) & 3));
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
         int gn = n0 + row;
         gn = gn < N ? gn : N - 1;                  // only reachable by the unused slot of a short wave
-        ld_ptr[i] = is_a ? g.A + (size_t)gm * K + c * 8 : g.W + (size_t)gn * K + c * 8;
+        ld_ptr[i] = (is_a ? g.A + (size_t)gm * K + c * 8 : g.W + (size_t)gn * K + c * 8) + lg * BK;
     }
     const bool wave_full = UNIFORM || wave < N_FULL;
     [[maybe_unused]] const unsigned* sc_ptr = nullptr;
@@ -887,8 +904,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
             if (UNIFORM || i + 1 < LPT || wave_full)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[i] + kt * BK),
-                                                 (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[i] + kt * (BK * KG)),
+                                                 (__attribute__((address_space(3))) void*)(sa + (KG == 2 ? grp * WLG + i * (WM * WN) + wv : i * NW + wave) * 1024), 16, 0, 0);
         if constexpr (MXA) {
             if (wave < SCALE_WAVES)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc_ptr + kt),
@@ -913,7 +930,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     // TRc: operands swapped -> acc holds C^T (lane = token row), see gemm_epilogue_t
     auto compute = [&](int stage, auto trc) {
         constexpr bool TRc = decltype(trc)::value;
-        const char* sa = smem + stage * STAGE_BYTES;
+        const char* sa = smem + stage * STAGE_BYTES + grp * GROUP_BYTES;
         const char* sb = sa + BM * ROWB;
         constexpr int KS = BK / 16;
         if constexpr (FP8 >= 2) {
@@ -1070,10 +1087,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
             }
+            if constexpr (KG == 2) {
+                if (ks == KS / 2 - 1) {          // the OTHER group's iteration boundary (it runs half an iteration out of phase)
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     };
 
-    const int nk = K / BK;
+    const int nk = K / (BK * KG);
     // prologue: tiles 0..D-1 in flight (nk >= D is guaranteed by the launcher)
 #pragma unroll
     for (int s = 0; s < D; ++s) stage_in(s, s);
@@ -1148,11 +1172,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
         tr = tr && !(g.heads.kind[(n0 + wn * TN) / hp] & 1);
     }
     auto main_loop = [&](auto trc) {
+        // K-groups: a group stages and reads only its own rows, so every barrier only has to hold for the group -- group 1 runs half an
+        // iteration behind group 0 (one barrier more up front, one less at the end; compute() passes one in mid-iteration), and on every
+        // SIMD one wave is inside its MFMA stream while the other waits for its tile, issues the next and reads its first fragments
+        if (KG == 2 && grp == 1) __builtin_amdgcn_s_barrier();
         for (int k = 0; k < nk - D; ++k) {
             wait_steady();
             __builtin_amdgcn_s_barrier();
             stage_in(k + D, wr);
             if (wave_rows_valid) compute(rd, trc);
+            else if (KG == 2) __builtin_amdgcn_s_barrier();
             rd = (rd + 1 == NS) ? 0 : rd + 1;
             wr = (wr + 1 == NS) ? 0 : wr + 1;
         }
@@ -1161,8 +1190,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (wave_rows_valid) compute(rd, trc);
+            else if (KG == 2) __builtin_amdgcn_s_barrier();
             rd = (rd + 1 == NS) ? 0 : rd + 1;
         }
+        if (KG == 2 && grp == 0) __builtin_amdgcn_s_barrier();
     };
     if constexpr (ORI == 0) {
         main_loop(std::false_type{});
@@ -1271,6 +1302,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
             }
         }
     }
+    if constexpr (KG == 2) {
+        // exchange: group 0 keeps row block 0 of its 64 x 64 wave tile and sends block 1, group 1 the other way round; lane-contiguous
+        // dwords, 8 KiB per wave in the first half of the (free) ring, the staged epilogue's areas in the second half
+        __builtin_amdgcn_s_barrier();
+        float* mine = reinterpret_cast<float*>(smem) + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64 + lane] = grp ? acc[0][j][r] : acc[1][j][r];
+        __syncthreads();
+        const float* theirs = reinterpret_cast<const float*>(smem) + (wave ^ (WM * WN)) * 2048;
+        f32x16 fin[1][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[0][j][r] = (grp ? acc[1][j][r] : acc[0][j][r]) + theirs[(j * 16 + r) * 64 + lane];
+        static_assert(KG == 1 || NS * STAGE_BYTES >= 2 * NW * 8192, "exchange + staging areas");
+        if (epi_rows_valid)
+            gemm_epilogue_f32_staged<1, true>(g, fin, reinterpret_cast<float*>(smem + NW * 8192) + wave * 2048, epi_m, n0 + wn * TN, lane, resid);
+        return;
+    }
     if constexpr (EPI == EPI_F32 && NI == 2) {
         if (!tr && !direct_f32) {
             __builtin_amdgcn_s_barrier();       // every wave is done reading the ring: it becomes the staging area
@@ -1293,17 +1345,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0, int KG = 1>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
-    constexpr int NT = WM * WN * 64;
+    constexpr int NT = KG * WM * WN * 64;
     constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && FP8 == 0;
-    constexpr int LDS = NS * ((BM + BN) * BK * 2 + (FP8 == 3 ? BM * 4 : 0)) + (LN_CONS ? (BM + BN) * 8 : 0);     // + (mean, rstd) per row, (c1, c2) per column
+    constexpr int LDS = NS * KG * ((BM + BN) * BK * 2 + (FP8 == 3 ? BM * 4 : 0)) + (LN_CONS ? (BM + BN) * 8 : 0);     // + (mean, rstd) per row, (c1, c2) per column
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds 160 KiB");
     SAT_CHECK_ARG(LN_CONS || !a.ln_part, SAT_E_UNSUPPORTED, "gemm: LayerNorm fold needs bf16 operands and a SwiGLU / heads epilogue");
     SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (EPI == EPI_F32 && BN / WN == 64 && FP8 == 0 && a.xb && a.ln_part_out), SAT_E_UNSUPPORTED,
                   "gemm: the bf16 image / row statistics come from the bf16 fp32-output tiles with 64-column wave tiles");
     static_assert(EPI != EPI_F32 || BN / WN != 64 || LDS >= WM * WN * 8192, "the staged fp32 epilogue needs 8 KiB of LDS per wave");
-    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, FP8>;
+    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, FP8, KG>;
     // fused cross-attention (HeadsEpi::xa_k): three K / V^T tiles of 64 keys behind the ring and the LayerNorm constants
     constexpr bool XA_OK = EPI == EPI_HEADS && BM == 128 && BN == 64 && BK == 64 && WM == 4 && WN == 1 && NS == 3 && FP8 == 0;
     constexpr int XA_LDS = XA_OK ? ((NS * (BM + BN) * BK * 2 + (BM + BN) * 8 + 1023) & ~1023) + 3 * 16384 : LDS;
@@ -1327,7 +1379,7 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
         b.K = a.K / 2;       // the kernel counts 16-bit columns: 128-byte LDS rows = 128 e4m3
     }
     SAT_CHECK_ARG(b.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", b.N, BN);
-    SAT_CHECK_ARG(b.K % BK == 0 && b.K / BK >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
+    SAT_CHECK_ARG(b.K % (BK * KG) == 0 && b.K / (BK * KG) >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
     int tiles = cdiv(b.M, BM) * (b.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), xa ? XA_LDS : LDS, stream, b);
     SAT_LAUNCH_CHECK();
@@ -1449,6 +1501,11 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             else v = 15;
             // long reductions (FF-out: 96 K-tiles) gain 4 % from a fourth ring stage (prefetch distance 3); K = 1536 does not care
             if (v == 15 && EPI == EPI_F32 && a.K >= 4096 && !deep_ring_off()) v = 44;
+            // one round of 128 x 128 tiles (to_out / FF-out at one prompt: 204 workgroups on 256 CUs): the two-K-group build puts 8 waves of
+            // 64 x 64 on every CU instead of 8 waves of 32 x 64 -- FF-out 56.5 us against 60.7, to_out 20.6 against 21.4 (tools/ph8_probe.py narrow)
+            if ((v == 15 || v == 44) && EPI == EPI_F32 && !a.fp8 && a.K % 128 == 0 && a.K >= 256 && (long)cdiv(a.M, 128) * (a.N / 128) <= cus &&
+                !(a.variant & 0x800000))
+                v = 49;
         } else {
             v = 5;
         }
@@ -1464,6 +1521,9 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 2, 4, EPI>(a, stream);
             break;
         case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);
+        case 49:           // 128 x 128 on two K-groups of 2 x 2 waves (64 x 64 each), 2 x 64 k per stage, 2 stages
+            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 2, 2, 2, EPI, 0, 2>(a, stream);
+            break;
         case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI>(a, stream);
         case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
 #ifdef SAT_GEMM_EXPERIMENTS

@@ -56,7 +56,9 @@ def test_cast_bf16(dev, fmt):
 # forced here, the launcher only splits long reductions behind a whole round; goes through the *_ws entry points
 GEMM_VARIANTS = [1, 5, 15, 16, 22, 30, 80]
 SPLIT = 80 | 0x10000
-GEMM_F32_VARIANTS = GEMM_VARIANTS + [SPLIT, 44]        # 44: tile 15 with a 4-stage ring (fp32 output, long K)
+# 44: tile 15 with a 4-stage ring (fp32 output, long K); 49: the 128 x 128 tile on two K-groups of 64 x 64 waves (what variant 0 picks for
+# the fp32-output GEMMs that fit one round of workgroups: to_out / FF-out at one prompt)
+GEMM_F32_VARIANTS = GEMM_VARIANTS + [SPLIT, 44, 49]
 
 
 def _split_ws(dev, m, n, k, variant):
@@ -80,6 +82,8 @@ def _skip_tile(variant, n, k):
         pytest.skip("192-column tile needs n % 192 == 0")
     if v >= 9 and k < 256:
         pytest.skip("the deep-prefetch variants need K >= stages * BK")
+    if v == 49 and k % 128:
+        pytest.skip("two K-groups walk K in slices of 2 x 64")
 
 
 @pytest.mark.parametrize("fmt", FORMATS, ids=repr)
@@ -370,7 +374,7 @@ def _ln_fold_reference(xb, w, gamma, beta, bias, fmt=FORMATS[0]):
 
 @pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("m", [300, 770])
-@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (0, 0), (80, 80), (15, 80), (80, 30), (SPLIT, 80)])
+@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (49, 15), (0, 0), (80, 80), (15, 80), (80, 30), (SPLIT, 80)])
 def test_ln_fold_swiglu(dev, prod, cons, m, fmt):
     """LayerNorm folded into FF-in (sat_dit_cfg.ln_fold): producer epilogue -> bf16 rows + partial sums -> SwiGLU GEMM that finishes
     the normalisation.  Gates: 4e-3 against the same arithmetic in fp64 (one bf16 rounding of the output), 1e-2 against the plain fp32
@@ -441,7 +445,7 @@ def test_ln_fold_rows_with_common_mode(dev, row_mean, outlier):
 
 @pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
-@pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (0, 0), (80, 80), (16, 80), (80, 15), (SPLIT, 80)])
+@pytest.mark.parametrize("prod,cons", [(15, 30), (16, 22), (22, 16), (30, 15), (49, 30), (0, 0), (80, 80), (16, 80), (80, 15), (SPLIT, 80)])
 def test_ln_fold_qkv_rope(dev, prod, cons, s, s_pad, fmt):
     """LayerNorm folded into to_qkv + RoPE + head split (transformer.py:692, 314, 430-452): q / k through the transposed epilogue,
     V^T through the un-swapped one -- both have to apply the per-row statistics."""

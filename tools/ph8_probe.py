@@ -185,14 +185,29 @@ def balance(bit=0x200000):
 
 def narrow():
     """the narrow one-prompt GEMMs (fp32 residual + LayerNorm-fold producer epilogue): shipped tiles against the experiments build's 4-wave / BK = 128 tiles"""
-    for name, m, n, k, arms in [("ff_out B1", 2050, 1536, 6144, (44, 15, 39, 42, 43, 10, 48)), ("to_out B1", 2050, 1536, 1536, (15, 16, 39, 42, 43, 10, 48)),
-                                ("cross out B1", 1025, 1536, 1536, (16, 15, 42, 48))]:
+    for name, m, n, k, arms in [("ff_out B1", 2050, 1536, 6144, (44, 15, 49, 39, 42, 43, 10, 48)), ("to_out B1", 2050, 1536, 1536, (15, 49, 16, 39, 42, 43, 10, 48)),
+                                ("cross out B1", 1025, 1536, 1536, (16, 15, 49, 42, 48)),
+                                # two workgroups of tile 43 (4 waves of 64 x 64, 64 KiB) share a CU once there are >= 512 tiles: 8 waves per CU with half
+                                # the LDS reads per MFMA of tile 15 / 44 -- does the fragment traffic bound the narrow tiles?
+                                ("ff_out 4 prompts", 8200, 1536, 6144, (44, 15, 43, 42)), ("to_out 4 prompts", 8200, 1536, 1536, (15, 43, 42)),
+                                ("ff_out 8 prompts", 16400, 1536, 6144, (44, 15, 43, 42)), ("to_out 8 prompts", 16400, 1536, 1536, (15, 43, 42))]:
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w2 = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         b2 = torch.randn(n, device=dev)
         c = torch.zeros(m, n, device=dev)
         xo = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
         po = torch.empty((m, n // 64, 2), dtype=torch.float32, device=dev)
+        if 49 in arms:          # the K-group tile against the shipped one: same sums up to the order of the two k-halves
+            outs = {}
+            for v in (15, 49):
+                c.copy_(torch.arange(m * n, device=dev, dtype=torch.float32).view(m, n) * 1e-6)
+                xo.fill_(float("nan")); po.fill_(float("nan"))
+                _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, n, k, v, _hip.stream()))
+                torch.cuda.synchronize()
+                outs[v] = (c.clone(), xo.float().clone(), po.clone())
+            errs = [((x49 - x15).norm() / x15.norm()).item() for x15, x49 in zip(outs[15], outs[49])]
+            print(f"   v49 vs v15 ({name}): rel-L2 C {errs[0]:.2e}  image {errs[1]:.2e}  partial sums {errs[2]:.2e}  non-finite {sum((~torch.isfinite(x)).sum().item() for x in outs[49])}", flush=True)
+            c.zero_()
         res = {v: [] for v in arms}
         for _ in range(5):
             for v in arms:
