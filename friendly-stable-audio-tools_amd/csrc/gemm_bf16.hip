@@ -928,7 +928,7 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
     // step ks, so the wave waits with a counted lgkmcnt and LDS latency hides behind the matrix pipe
     typedef long i64x2 __attribute__((ext_vector_type(2)));
     // TRc: operands swapped -> acc holds C^T (lane = token row), see gemm_epilogue_t
-    auto compute = [&](int stage, auto trc) {
+    auto compute = [&](int stage, auto trc, [[maybe_unused]] int kt_issue = -1, [[maybe_unused]] int st_issue = 0) {
         constexpr bool TRc = decltype(trc)::value;
         const char* sa = smem + stage * STAGE_BYTES + grp * GROUP_BYTES;
         const char* sb = sa + BM * ROWB;
@@ -1068,6 +1068,17 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) frag(ks + 1, (ks + 1) & 1);
+            if constexpr (KG == 2 && LPT == 8) {
+                // K-groups: the iteration's eight LDS-DMA pieces ride in the MFMA stream of the first two steps (two behind each of the
+                // second and third MFMA) -- in front of the first MFMA they would cost their issue time, 60-180 cycles a piece
+                if (ks < 2 && kt_issue >= 0) {
+                    char* sdst = smem + st_issue * STAGE_BYTES;
+#pragma unroll
+                    for (int i = ks * 4; i < ks * 4 + 4; ++i)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[i] + kt_issue * (BK * KG)),
+                                                         (__attribute__((address_space(3))) void*)(sdst + (grp * WLG + i * (WM * WN) + wv) * 1024), 16, 0, 0);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1077,13 +1088,29 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
             // pin the interleave: one ds_read of the NEXT step's fragments behind each MFMA of this step
             if (ks + 1 < KS) {
                 constexpr int NR = MI + NI, NM = MI * NI;
-#pragma unroll
-                for (int r = 0; r < (NR < NM ? NR : NM); ++r) {
+                if constexpr (KG == 2) {
+                    // all of the next step's fragment reads behind the FIRST MFMA: they get three MFMAs (~100 cycles) of head start on the
+                    // wait in front of the next step instead of one read trailing the last MFMA
                     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+                    if (ks < KS / 2 && LPT == 8) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x8, NM - 1, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < (NR < NM ? NR : NM); ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x8, NM - NR, 0);
+                    if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
                 }
-                if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x8, NM - NR, 0);
-                if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
             }
@@ -1179,9 +1206,18 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
         for (int k = 0; k < nk - D; ++k) {
             wait_steady();
             __builtin_amdgcn_s_barrier();
-            stage_in(k + D, wr);
-            if (wave_rows_valid) compute(rd, trc);
-            else if (KG == 2) __builtin_amdgcn_s_barrier();
+            if constexpr (KG == 2 && LPT == 8) {
+                if (wave_rows_valid) {
+                    compute(rd, trc, k + D, wr);
+                } else {
+                    stage_in(k + D, wr);
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else {
+                stage_in(k + D, wr);
+                if (wave_rows_valid) compute(rd, trc);
+                else if (KG == 2) __builtin_amdgcn_s_barrier();
+            }
             rd = (rd + 1 == NS) ? 0 : rd + 1;
             wr = (wr + 1 == NS) ? 0 : wr + 1;
         }

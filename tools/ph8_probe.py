@@ -183,6 +183,24 @@ def balance(bit=0x200000):
            {"launcher": 0, "v30": 30, "v80 all CUs": 80, "v80 balanced": 80 | bit})
 
 
+def kg():
+    """the two-K-group 128 x 128 tile (variant 49) against the shipped 8-wave tiles on the one-prompt fp32-output GEMMs, product epilogue"""
+    for name, m, n, k, arms in [("ff_out B1", 2050, 1536, 6144, (44, 49)), ("to_out B1", 2050, 1536, 1536, (15, 49)), ("cross out B1", 1025, 1536, 1536, (16, 49))]:
+        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+        w2 = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+        b2 = torch.randn(n, device=dev)
+        c = torch.zeros(m, n, device=dev)
+        xo = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+        po = torch.empty((m, n // 64, 2), dtype=torch.float32, device=dev)
+        res = {v: [] for v in arms}
+        for _ in range(7):
+            for v in arms:
+                res[v].append(timeit(lambda: _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, n, k,
+                                                                                  v, _hip.stream())), iters=10, warm=2))
+        fl = 2.0 * m * n * k
+        print(f"kg {name} {m}x{n}x{k}: " + "  ".join(f"v{v} {statistics.median(t)*1e3:.1f} us ({fl/statistics.median(t)/1e9:.0f} TF, min {min(t)*1e3:.1f})" for v, t in res.items()), flush=True)
+
+
 def narrow():
     """the narrow one-prompt GEMMs (fp32 residual + LayerNorm-fold producer epilogue): shipped tiles against the experiments build's 4-wave / BK = 128 tiles"""
     for name, m, n, k, arms in [("ff_out B1", 2050, 1536, 6144, (44, 15, 49, 39, 42, 43, 10, 48)), ("to_out B1", 2050, 1536, 1536, (15, 49, 16, 39, 42, 43, 10, 48)),
