@@ -207,15 +207,16 @@ def narrow():
                                 ("cross out B1", 1025, 1536, 1536, (16, 15, 49, 42, 48)),
                                 # two workgroups of tile 43 (4 waves of 64 x 64, 64 KiB) share a CU once there are >= 512 tiles: 8 waves per CU with half
                                 # the LDS reads per MFMA of tile 15 / 44 -- does the fragment traffic bound the narrow tiles?
-                                ("ff_out 4 prompts", 8200, 1536, 6144, (44, 15, 43, 42)), ("to_out 4 prompts", 8200, 1536, 1536, (15, 43, 42)),
-                                ("ff_out 8 prompts", 16400, 1536, 6144, (44, 15, 43, 42)), ("to_out 8 prompts", 16400, 1536, 1536, (15, 43, 42))]:
+                                ("ff_out 4 prompts", 8200, 1536, 6144, (44, 49, 43, 80)), ("to_out 4 prompts", 8200, 1536, 1536, (15, 49, 43, 22, 80)),
+                                ("ff_out 8 prompts", 16400, 1536, 6144, (44, 49, 43, 80)), ("to_out 8 prompts", 16400, 1536, 1536, (15, 49, 43, 22, 80)),
+                                ("cross out 8 prompts", 8200, 1536, 1536, (15, 49, 43, 22, 80))]:
         a = torch.randn(m, k, device=dev).to(torch.bfloat16)
         w2 = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
         b2 = torch.randn(n, device=dev)
         c = torch.zeros(m, n, device=dev)
         xo = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
         po = torch.empty((m, n // 64, 2), dtype=torch.float32, device=dev)
-        if 49 in arms:          # the K-group tile against the shipped one: same sums up to the order of the two k-halves
+        if 49 in arms and m < 4000:          # the K-group tile against the shipped one: same sums up to the order of the two k-halves
             outs = {}
             for v in (15, 49):
                 c.copy_(torch.arange(m * n, device=dev, dtype=torch.float32).view(m, n) * 1e-6)
