@@ -748,7 +748,9 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
 // per CU instead of 8 waves of 32 x 64: a third less LDS fragment traffic per MFMA, which is what bounds the narrow tiles
 // (profiles/r04_narrow_tiles_negative.txt: two co-resident 4-wave workgroups of 64 x 64 waves beat the 8-wave tile by 17-21 % wherever
 // there are two workgroups per CU; at one prompt there is only one).
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0, int KG = 1>
+// DIL ("DMA in loop", bf16 / fp16 operands): the iteration's LDS-DMA pieces are issued inside compute(), behind the MFMAs of the first k-steps, instead of
+// in front of it -- always on with K-groups; a per-tile choice otherwise (measured, see launch_epi)
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0, int KG = 1, bool DIL = false>
 __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g) {
     sat_f16_saturate();
     static_assert(KG == 1 || (KG == 2 && EPI == EPI_F32 && FP8 == 0 && BK == 64 && BM / WM == 64 && BN / WN == 64),
@@ -777,6 +779,10 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
     constexpr int GROUP_BYTES = (BM + BN) * ROWB + (MXA ? BM * 4 : 0);
     constexpr int STAGE_BYTES = KG * GROUP_BYTES;
     constexpr int D = NS - 1;                      // prefetch distance
+    constexpr bool DIL_ON = (DIL || KG == 2) && FP8 == 0;
+    constexpr int NDIL = !DIL_ON ? 0 : UNIFORM ? LPT : LPT - 1;          // pieces EVERY wave issues in the loop body (a ragged tile's extra piece stays in front)
+    constexpr int DIL_STEPS = KG == 2 ? BK / 32 : BK / 16 - 1;            // k-steps that carry them (K-groups: the half in front of the mid-iteration barrier)
+    constexpr int DIL_PER = (NDIL + DIL_STEPS - 1) / (DIL_STEPS > 0 ? DIL_STEPS : 1);
     static_assert(!MXA || D == 1 || UNIFORM, "MXFP8: counted waits are built for uniform tiles or 2-stage rings");
     static_assert((BM * CPR) % 64 == 0 && (BN * CPR) % 64 == 0 && (D - 1) * LPT < 64, "bad pipeline geometry");
     static_assert(!FP8 || BK == 64, "fp8: 128-byte rows only");
@@ -1068,15 +1074,15 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) frag(ks + 1, (ks + 1) & 1);
-            if constexpr (KG == 2 && LPT == 8) {
-                // K-groups: the iteration's eight LDS-DMA pieces ride in the MFMA stream of the first two steps (two behind each of the
-                // second and third MFMA) -- in front of the first MFMA they would cost their issue time, 60-180 cycles a piece
-                if (ks < 2 && kt_issue >= 0) {
+            if constexpr (DIL_ON) {
+                // the iteration's LDS-DMA pieces ride in the MFMA stream of the first k-steps -- in front of the first MFMA they cost their
+                // issue time, 60-180 cycles a piece
+                if (ks < DIL_STEPS && kt_issue >= 0) {
                     char* sdst = smem + st_issue * STAGE_BYTES;
 #pragma unroll
-                    for (int i = ks * 4; i < ks * 4 + 4; ++i)
+                    for (int i = ks * DIL_PER; i < (ks + 1) * DIL_PER && i < NDIL; ++i)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[i] + kt_issue * (BK * KG)),
-                                                         (__attribute__((address_space(3))) void*)(sdst + (grp * WLG + i * (WM * WN) + wv) * 1024), 16, 0, 0);
+                                                         (__attribute__((address_space(3))) void*)(sdst + (KG == 2 ? grp * WLG + i * (WM * WN) + wv : i * NW + wave) * 1024), 16, 0, 0);
                 }
             }
 #pragma unroll
@@ -1095,7 +1101,7 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
                     // wait in front of the next step instead of one read trailing the last MFMA
                     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-                    if (ks < KS / 2 && LPT == 8) {
+                    if (ks < KS / 2 && DIL_PER == 4) {
                         __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
                         __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -1112,6 +1118,7 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
                     }
                     if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x8, NM - NR, 0);
                     if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+                    if (DIL_ON && ks < DIL_STEPS) __builtin_amdgcn_sched_group_barrier(0x20, DIL_PER, 0);          // this step's DMA pieces behind its MFMAs
                 }
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x8, MI * NI, 0);
@@ -1208,12 +1215,17 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
         for (int k = 0; k < nk - D; ++k) {
             wait_steady();
             __builtin_amdgcn_s_barrier();
-            if constexpr (KG == 2 && LPT == 8) {
+            if constexpr (DIL_ON) {
                 if (wave_rows_valid) {
+                    if constexpr (!UNIFORM) {          // the extra piece of the first waves of a ragged tile
+                        if (wave_full)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ld_ptr[LPT - 1] + (k + D) * (BK * KG)),
+                                                             (__attribute__((address_space(3))) void*)(smem + wr * STAGE_BYTES + ((LPT - 1) * NW + wave) * 1024), 16, 0, 0);
+                    }
                     compute(rd, trc, k + D, wr);
                 } else {
                     stage_in(k + D, wr);
-                    __builtin_amdgcn_s_barrier();
+                    if (KG == 2) __builtin_amdgcn_s_barrier();
                 }
             } else {
                 stage_in(k + D, wr);
@@ -1383,7 +1395,7 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0, int KG = 1>
+template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0, int KG = 1, bool DIL = false>
 int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = KG * WM * WN * 64;
     constexpr bool LN_CONS = (EPI == EPI_SWIGLU || EPI == EPI_HEADS) && FP8 == 0;
@@ -1393,7 +1405,7 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (EPI == EPI_F32 && BN / WN == 64 && FP8 == 0 && a.xb && a.ln_part_out), SAT_E_UNSUPPORTED,
                   "gemm: the bf16 image / row statistics come from the bf16 fp32-output tiles with 64-column wave tiles");
     static_assert(EPI != EPI_F32 || BN / WN != 64 || LDS >= WM * WN * 8192, "the staged fp32 epilogue needs 8 KiB of LDS per wave");
-    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, FP8, KG>;
+    auto kern = gemm_pipe_kernel<BM, BN, BK, WM, WN, NS, EPI, FP8, KG, DIL>;
     // fused cross-attention (HeadsEpi::xa_k): three K / V^T tiles of 64 keys behind the ring and the LayerNorm constants
     constexpr bool XA_OK = EPI == EPI_HEADS && BM == 128 && BN == 64 && BK == 64 && WM == 4 && WN == 1 && NS == 3 && FP8 == 0;
     constexpr int XA_LDS = XA_OK ? ((NS * (BM + BN) * BK * 2 + (BM + BN) * 8 + 1023) & ~1023) + 3 * 16384 : LDS;
@@ -1558,13 +1570,19 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
         case 44:
             if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 2, 4, EPI>(a, stream);
             break;
-        case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);
+        case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 0, 1, true>(a, stream);      // four waves = one per SIMD: LDS-DMA pieces in the MFMA stream (15.1 vs 16.2 us, cross to_out)
         case 49:           // 128 x 128 on two K-groups of 2 x 2 waves (64 x 64 each), 2 x 64 k per stage, 2 stages
             if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 2, 2, 2, EPI, 0, 2>(a, stream);
             break;
         case 22: return launch_pipe<256, 256, 64, 4, 4, 2, EPI>(a, stream);
         case 30: return launch_pipe<256, 192, 64, 4, 3, 2, EPI>(a, stream);
 #ifdef SAT_GEMM_EXPERIMENTS
+        case 55: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 0, 1, true>(a, stream);      // tiles 15 / 16 / 30 / 44 with the LDS-DMA pieces in the MFMA stream (A/B)
+        case 56: return launch_pipe<128, 64, 64, 4, 1, 3, EPI>(a, stream);                   // tile 16 with its pieces in front of the loop body (A/B)
+        case 60: return launch_pipe<256, 192, 64, 4, 3, 2, EPI, 0, 1, true>(a, stream);
+        case 54:
+            if constexpr (EPI == EPI_F32) return launch_pipe<128, 128, 64, 4, 2, 4, EPI, 0, 1, true>(a, stream);
+            break;
         case 2: return launch_cfg<256, 128, 4, 2, EPI>(a, stream);
         case 3: return launch_cfg<256, 256, 2, 4, EPI>(a, stream);
         case 7: return launch_cfg<256, 256, 2, 4, EPI, true>(a, stream);

@@ -185,17 +185,21 @@ def balance(bit=0x200000):
 
 def kg():
     """the two-K-group 128 x 128 tile (variant 49) against the shipped 8-wave tiles on the one-prompt fp32-output GEMMs, product epilogue"""
-    for name, m, n, k, arms in [("ff_out B1", 2050, 1536, 6144, (44, 49)), ("to_out B1", 2050, 1536, 1536, (15, 49)), ("cross out B1", 1025, 1536, 1536, (16, 49))]:
-        a = torch.randn(m, k, device=dev).to(torch.bfloat16)
-        w2 = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+    f16 = bool(os.environ.get("PROBE_F16"))
+    odt = torch.float16 if f16 else torch.bfloat16
+    fn = lib.sat_gemm_resid_ln_f16 if f16 else lib.sat_gemm_resid_ln_bf16
+    print("operands:", odt)
+    for name, m, n, k, arms in [("ff_out B1", 2050, 1536, 6144, (44, 49)), ("to_out B1", 2050, 1536, 1536, (15, 49)), ("cross out B1", 1025, 1536, 1536, (16, 56))]:
+        a = torch.randn(m, k, device=dev).to(odt)
+        w2 = (torch.randn(n, k, device=dev) * 0.05).to(odt)
         b2 = torch.randn(n, device=dev)
         c = torch.zeros(m, n, device=dev)
-        xo = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+        xo = torch.empty((m, n), dtype=odt, device=dev)
         po = torch.empty((m, n // 64, 2), dtype=torch.float32, device=dev)
         res = {v: [] for v in arms}
         for _ in range(7):
             for v in arms:
-                res[v].append(timeit(lambda: _hip.check(lib.sat_gemm_resid_ln_bf16(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, n, k,
+                res[v].append(timeit(lambda: _hip.check(fn(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, n, k,
                                                                                   v, _hip.stream())), iters=10, warm=2))
         fl = 2.0 * m * n * k
         print(f"kg {name} {m}x{n}x{k}: " + "  ".join(f"v{v} {statistics.median(t)*1e3:.1f} us ({fl/statistics.median(t)/1e9:.0f} TF, min {min(t)*1e3:.1f})" for v, t in res.items()), flush=True)
@@ -591,7 +595,7 @@ def qkv8():
             return f
         mk(0)()
         torch.cuda.synchronize()
-        arms = {"auto": 0x4000, "v80": 80 | 0x4000, "v30": 30 | 0x4000}
+        arms = {"auto": 0x4000, "v80": 80 | 0x4000, "v30": 30 | 0x4000, "v60": 60 | 0x4000}
         res = {k2: [] for k2 in arms}
         for _ in range(5):
             for k2, v in arms.items():
