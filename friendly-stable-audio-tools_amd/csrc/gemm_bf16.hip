@@ -1554,7 +1554,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             // one round of 128 x 128 tiles (to_out / FF-out at one prompt: 204 workgroups on 256 CUs): the two-K-group build puts 8 waves of
             // 64 x 64 on every CU instead of 8 waves of 32 x 64 -- FF-out 56.5 us against 60.7, to_out 20.6 against 21.4 (tools/ph8_probe.py narrow)
             if ((v == 15 || v == 44) && EPI == EPI_F32 && !a.fp8 && a.K % 128 == 0 && a.K >= 256 && (long)cdiv(a.M, 128) * (a.N / 128) <= cus &&
-                !(a.variant & 0x800000))
+                !(a.variant & 0x800000) && sat_g_wide_tile != 82)
                 v = 49;
         } else {
             v = 5;
@@ -1611,8 +1611,9 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
 #ifndef SAT_OPERAND_F16
 int sat_g_wide_tile = 80;
 extern "C" int sat_gemm_set_wide_tile(int32_t tile) {
-    SAT_CHECK_ARG(tile == 22 || tile == 80 || tile == 81, SAT_E_INVALID,
-                  "sat_gemm_set_wide_tile: 22 (16 waves, 2-stage ring), 80 (8 waves, 8-phase) or 81 (80, also for the fp32-output GEMMs with K < 4096: A/B)");
+    SAT_CHECK_ARG(tile == 22 || tile == 80 || tile == 81 || tile == 82, SAT_E_INVALID,
+                  "sat_gemm_set_wide_tile: 22 (16 waves, 2-stage ring), 80 (8 waves, 8-phase), 81 (80, also for the fp32-output GEMMs with K < 4096: A/B) or "
+                  "82 (80 without the two-K-group 128 x 128 tile: A/B)");
     sat_g_wide_tile = tile;
     return 0;
 }

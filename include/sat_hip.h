@@ -293,7 +293,8 @@ int sat_gemm_bf16_f32_ws(const void* a_bf16_dev, const void* w_bf16_dev, const f
                          sat_stream_t stream);
 /* Which kernel serves the 256 x 256 tile of the bf16 GEMMs: 80 (default) = 8 waves, 128 x 64 per wave, 8-phase schedule with a
  * counted-vmcnt LDS-DMA ring of half-tiles (csrc/gemm_ph8.hip); 22 = the 16-wave 2-stage tile of rounds 1-2 (A/B measurements); 81 = 80, also for
- * the fp32-output GEMMs with K < 4096 that the default keeps on the 16-wave tile (A/B: 34.27 vs 34.42 ms per CFG step at 8 prompts).  e4m3
+ * the fp32-output GEMMs with K < 4096 that the default keeps on the 16-wave tile (A/B: 34.27 vs 34.42 ms per CFG step at 8 prompts); 82 = 80
+ * without the two-K-group 128 x 128 tile of the one-round fp32-output GEMMs (A/B).  e4m3
  * operands: the LayerNorm-fed GEMMs (heads / SwiGLU epilogues) follow this switch too, the MXFP8-operand GEMMs always run tile 22.  Process-wide; not a per-call argument because the tile is chosen inside the plan. */
 int sat_gemm_set_wide_tile(int32_t tile);
 /* SwiGLU GEMM (models/transformer.py:211-235): h[m,n/2] (bf16) = (A W_v^T + b_v) * silu(A W_g^T + b_g)

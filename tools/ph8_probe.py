@@ -190,17 +190,24 @@ def kg():
     fn = lib.sat_gemm_resid_ln_f16 if f16 else lib.sat_gemm_resid_ln_bf16
     print("operands:", odt)
     for name, m, n, k, arms in [("ff_out B1", 2050, 1536, 6144, (44, 49)), ("to_out B1", 2050, 1536, 1536, (15, 49)), ("cross out B1", 1025, 1536, 1536, (16, 56))]:
-        a = torch.randn(m, k, device=dev).to(odt)
-        w2 = (torch.randn(n, k, device=dev) * 0.05).to(odt)
+        nset = int(os.environ.get("PROBE_SETS", "1"))          # > 1: rotate through operand sets (cold weights, as in the model: 24 layers x 57 MB)
+        sets = []
+        for i in range(nset):
+            sets.append((torch.randn(m, k, device=dev).to(odt), (torch.randn(n, k, device=dev) * 0.05).to(odt)))
         b2 = torch.randn(n, device=dev)
         c = torch.zeros(m, n, device=dev)
         xo = torch.empty((m, n), dtype=odt, device=dev)
         po = torch.empty((m, n // 64, 2), dtype=torch.float32, device=dev)
+        cnt = [0]
+
+        def call(v):
+            a, w2 = sets[cnt[0] % nset]
+            cnt[0] += 1
+            _hip.check(fn(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, n, k, v, _hip.stream()))
         res = {v: [] for v in arms}
         for _ in range(7):
             for v in arms:
-                res[v].append(timeit(lambda: _hip.check(fn(_hip.ptr(a), _hip.ptr(w2), _hip.ptr(b2), _hip.ptr(c), _hip.ptr(xo), _hip.ptr(po), m, n, k,
-                                                                                  v, _hip.stream())), iters=10, warm=2))
+                res[v].append(timeit(lambda: call(v), iters=10, warm=2))
         fl = 2.0 * m * n * k
         print(f"kg {name} {m}x{n}x{k}: " + "  ".join(f"v{v} {statistics.median(t)*1e3:.1f} us ({fl/statistics.median(t)/1e9:.0f} TF, min {min(t)*1e3:.1f})" for v, t in res.items()), flush=True)
 
