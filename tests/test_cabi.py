@@ -55,6 +55,10 @@ def test_argument_validation_without_gpu():
     ocfg.is_decoder, ocfg.io_channels, ocfg.channels, ocfg.latent_dim, ocfg.n_blocks = 1, 2, 100, 64, 2
     assert lib.sat_oobleck_plan_create(ctypes.byref(ocfg), ctypes.byref(plan)) == -2
     assert lib.sat_dpmpp3m_update(None, None, None, None, None, 0.0, 1.0, 0.0, 0.0, 0.0, 10, None) == -1
+    # the A/B switches of the tile policy take their documented values only (and leave the default behind)
+    for tile in (22, 81, 82, 80):
+        assert lib.sat_gemm_set_wide_tile(tile) == 0
+    assert lib.sat_gemm_set_wide_tile(7) == -1 and b"sat_gemm_set_wide_tile" in lib.sat_last_error()
 
 
 def test_product_has_no_cpu_path():
