@@ -748,6 +748,10 @@ __device__ __forceinline__ int lds_off_bk(int row, int chunk) {
 // per CU instead of 8 waves of 32 x 64: a third less LDS fragment traffic per MFMA, which is what bounds the narrow tiles
 // (profiles/r04_narrow_tiles_negative.txt: two co-resident 4-wave workgroups of 64 x 64 waves beat the 8-wave tile by 17-21 % wherever
 // there are two workgroups per CU; at one prompt there is only one).
+// (Measured and not kept, profiles/r04_kgroup_tile.txt: four PRODUCER waves -- one per SIMD, two per K-group -- that issue all of the LDS-DMA while the eight
+// MFMA waves never touch the vector-memory queue.  Bit-identical results, FF-out 66.5 us against 53.7: the CU's vector-memory path takes one 1-KiB piece per
+// ~16 clocks whoever issues it, and with a two-stage ring the issue of tile k + 1 can only start at boundary k and has to land by boundary k + 1 -- sixteen
+// pieces in a row per producer wave stretch that chain, eight per wave in parallel with the MFMAs do not.  The ablation without any DMA runs 36.9 us.)
 // DIL ("DMA in loop", bf16 / fp16 operands): the iteration's LDS-DMA pieces are issued inside compute(), behind the MFMAs of the first k-steps, instead of
 // in front of it -- always on with K-groups; a per-tile choice otherwise (measured, see launch_epi)
 template <int BM, int BN, int BK, int WM, int WN, int NS, int EPI, int FP8 = 0, int KG = 1, bool DIL = false>
