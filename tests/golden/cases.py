@@ -60,6 +60,19 @@ GEN = {
 TRAJ = dict(steps=12, sigma_min=0.3, sigma_max=500.0, cfg_scale=7.0, snapshots=(4, 8, 12))
 
 
+# the headline's own length (make_traj100_golden.py -> traj100_full.npz): 100 steps, same model / conditioning / schedule family
+TRAJ100 = dict(steps=100, sigma_min=0.3, sigma_max=500.0, cfg_scale=7.0, snapshots=(12, 25, 50, 100),
+               audio_windows={"start": 0, "middle": 1048576}, audio_window_len=65536)
+
+
+def traj100_inputs():
+    """(cross_attn_cond, global_cond, unit initial noise, per-step unit noise) of the 100-step full-size fixture"""
+    _, _, c, g = dit_inputs(1, 1024, 768, 1536, 1)
+    noise = synthetic.synth_input("traj100_noise", (1, 64, 1024), 700)
+    step_noise = [synthetic.synth_input(f"traj100_sn{i}", (1, 64, 1024), 710 + i) for i in range(TRAJ100["steps"])]
+    return c, g, noise, step_noise
+
+
 def traj_inputs():
     """(cross_attn_cond, global_cond, unit initial noise, per-step unit noise) of the full-size trajectory fixture"""
     _, _, c, g = dit_inputs(1, 1024, 768, 1536, 1)
