@@ -220,7 +220,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 //   * SwiGLU / MXFP8 block maximum: value and gate, resp. the 32 channels of a block, sit in one lane pair.
 // V^T (token-contiguous destination) keeps the un-swapped orientation and the epilogue above.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int MI, int NI, bool LNC = false>
+// ROPE_PRE: the rotation table rows of all MI row blocks are fetched up front (not in the 128-register budget of the 16-wave tile)
+template <int EPI, int MI, int NI, bool LNC = false, bool ROPE_PRE = true>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)[MI][NI], const int mw, const int nw, const int half,
                                                 const int l31, const float2* ln = nullptr, const float* lc1 = nullptr,
                                                 const float* lc2 = nullptr, unsigned (*qfrag)[8] = nullptr) {
@@ -346,6 +347,20 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
         const int kind = he.kind[part];
         op_t* __restrict__ dst = he.out[part];
         const int S = he.S, Spad = he.Spad;
+        // the rotation table rows of ALL of the lane's row blocks up front: one round trip instead of one per row block behind the previous
+        // block's stores (round 5)
+        [[maybe_unused]] f32x4 rcs[MI][2], rsn[MI][2];
+        if (ROPE_PRE && (kind & 2)) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = mw + i * 32 + l31;
+                const int s = (m < M ? m : M - 1) % S;
+                rcs[i][0] = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 4 * half);
+                rcs[i][1] = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 8 + 4 * half);
+                rsn[i][0] = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 4 * half);
+                rsn[i][1] = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 8 + 4 * half);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = mw + i * 32 + l31;
@@ -366,10 +381,13 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                     }
             }
             if (kind & 2) {   // partial RoPE on d < 32 (block j = 0): partner of d < 16 is d + 16 = register r + 8 of this lane
-                const f32x4 cs0 = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 4 * half);
-                const f32x4 cs1 = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 8 + 4 * half);
-                const f32x4 sn0 = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 4 * half);
-                const f32x4 sn1 = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 8 + 4 * half);
+                if constexpr (!ROPE_PRE) {
+                    rcs[i][0] = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 4 * half);
+                    rcs[i][1] = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 8 + 4 * half);
+                    rsn[i][0] = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 4 * half);
+                    rsn[i][1] = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 8 + 4 * half);
+                }
+                const f32x4 cs0 = rcs[i][0], cs1 = rcs[i][1], sn0 = rsn[i][0], sn1 = rsn[i][1];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const float cs = (r < 4) ? cs0[r & 3] : cs1[r & 3];
@@ -1391,7 +1409,7 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
     }
     if (wave_rows_valid) {
         if constexpr (NI == 2 || EPI == EPI_F32) {
-            if (tr) gemm_epilogue_t<EPI, MI, NI, LN_CONS>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31, lnst + wm * TM, lnc + wn * TN, lnc + BN + wn * TN);
+            if (tr) gemm_epilogue_t<EPI, MI, NI, LN_CONS, (NT < 1024)>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31, lnst + wm * TM, lnc + wn * TN, lnc + BN + wn * TN);
             else gemm_epilogue<EPI, MI, NI, LN_CONS>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31, lnst + wm * TM, lnc + wn * TN, lnc + BN + wn * TN);
         } else {
             gemm_epilogue<EPI, MI, NI>(g, acc, m0 + wm * TM, n0 + wn * TN, half, l31);

@@ -68,6 +68,46 @@ __device__ __forceinline__ void wait_lgkmcnt() {
 // x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of the IEEE division sequence (10 instructions per element in the epilogue)
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// LDS accesses of the LayerNorm / rotation constants that the COMPILER MUST NOT SEE (round 5).  While an LDS-DMA is in flight -- and
+// in the persistent loop the next range's prologue always is, from `prepare` to the top of the next main loop -- the compiler's wait
+// insertion treats every ds_read / ds_write it emits as a possible access to what the DMA is writing and puts s_waitcnt vmcnt(0) in front of
+// it (it cannot tell the constants behind the ring from the ring).  That cost: the LayerNorm statistics of the next range were written only
+// after its whole DMA prologue had LANDED (the 2 us of "prepare-next" in profiles/r04_ph8_heads_swiglu_timeline.txt), and every row block of
+// an epilogue waited for the write acknowledgement of the previous row block's store before it read its (mean, rstd) -- eight dependent store
+// round trips per tile.  Inline assembly keeps the vector-memory counter out of it; the lgkmcnt waits are then ours (lds_wait).
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(const char*)p;
+}
+__device__ __forceinline__ float lds_ld32(const void* p) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ float2 lds_ld64(const void* p) {
+    float2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ f32x4_t lds_ld128(const void* p) {
+    f32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st64(void* p, float2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st128(void* p, f32x4_t v) { asm volatile("ds_write_b128 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_tie() {}
+template <typename T, typename... Ts>
+__device__ __forceinline__ void lds_tie(T& v, Ts&... vs) {
+    asm volatile("" : "+v"(v));          // (a use of v cannot be scheduled in front of this, and this not in front of the wait)
+    lds_tie(vs...);
+}
+// all LDS reads issued so far have returned; every later use of the listed values sits behind the wait
+template <typename... Ts>
+__device__ __forceinline__ void lds_wait(Ts&... vs) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_tie(vs...);
+}
+
 // Channel (0..63 inside the wave's 64) held by W half-tile `ni` (0 lo / 1 hi), fragment nf (0/1), fragment row i (0..15).
 // After the MFMA lane (i' = l & 15, q = l >> 4) holds rows 4q..4q+3 of the fragment, i.e. fragment rows i = 4q + r.
 //   PERM 0 (fp32 output, V^T):  natural order ni*32 + nf*16 + i  -> 4 lanes q write 64 contiguous bytes of a row per store
@@ -683,15 +723,51 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 const float inv_k = 1.0f / (float)K;
                 const float mean = sum * inv_k;
                 const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
-                lnst[r] = ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, a_sc);
+                lds_st64(lnst + r, ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, a_sc));
             }
-            if (ct < BN / 2) *reinterpret_cast<f32x4_t*>(lnc + ct * 4) = lncst;
+            if (ct < BN / 2) lds_st128(lnc + ct * 4, lncst);
         }
+    };
+
+    // ---- EPI_HEADS, q / k tiles: the rotation (transformer.py:158-183).  Loaded per row block inside the epilogue, the table rows were sixteen
+    // DEPENDENT round trips per tile -- the compiler put an s_waitcnt vmcnt(0) behind every one of them: 8.5 us of epilogue per q / k tile
+    // against 2.8 for SwiGLU (profiles/r04_ph8_heads_swiglu_timeline.txt).  Now a lane fetches the (cos, sin) of its FIRST row block and of
+    // position 16 right after the main loop, in FRONT of the next range's LDS-DMA prologue (oldest entries of the in-order vector-memory
+    // queue; inline assembly, so the compiler's conservative wait insertion neither sees nor serialises them), waits for them with ONE counted
+    // wait behind it, and walks to the next row block -- 16 positions on -- by the angle-addition rotation (16 FMAs; 5e-7 absolute after seven
+    // steps, three orders below the 16-bit rounding of q / k).  A row block in which some lane crosses into the next sequence re-reads the table.
+    // The (cos, sin) of position 16 -- 32 floats, the same for every tile -- sit in LDS behind the LayerNorm constants, written once per workgroup.
+    struct RopePre {
+        f32x4_t cs, sn;
+    };
+    constexpr int ROPE16_OFF = RING_BYTES + 2 * LN_BYTES;          // cos[16], sin[16] of position 16 (min(16, S - 1))
+    if constexpr (EPI == EPI_HEADS) {
+        if (tid_ < 32 && g.heads.rope_cos) {
+            const int r16 = g.heads.S > 16 ? 16 : g.heads.S - 1;
+            reinterpret_cast<float*>(smem + ROPE16_OFF)[tid_] = (tid_ < 16 ? g.heads.rope_cos : g.heads.rope_sin)[r16 * 16 + (tid_ & 15)];
+        }          // (published by the barriers of the first main loop)
+    }
+    constexpr int PRO_DMA = 2 * ((PH2 && PH2V != 2) ? 6 : 7);          // LDS-DMA instructions per wave of a range's prologue (two per half-tile)
+    [[maybe_unused]] auto rope_load = [&](f32x4_t& cs, f32x4_t& sn, int row, int q4) {
+        const unsigned voff = (unsigned)(row * 16 + 4 * q4) * 4u;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(cs) : "v"(voff), "s"(g.heads.rope_cos) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(sn) : "v"(voff), "s"(g.heads.rope_sin) : "memory");
+    };
+    [[maybe_unused]] auto rope_prefetch = [&](const Seg& s, RopePre& rp) {
+        int l15 = l15_, q4 = q4_;
+        asm volatile("" : "+v"(l15), "+v"(q4));
+        const int S = g.heads.S;
+        const int m = s.m0 + wr * WR + l15;
+        rope_load(rp.cs, rp.sn, (m < M ? m : M - 1) % S, q4);
+    };
+    [[maybe_unused]] auto rope_wait = [](auto n_c, RopePre& rp) {
+        wait_vmcnt<decltype(n_c)::value>();
+        asm volatile("" : "+v"(rp.cs), "+v"(rp.sn));          // every use sits behind the wait
     };
 
     // ---- epilogues.  Transposed: lane (l15, q4) holds, for block (mb = 0..7, nb = 2 ni + nf): token row m0 + wr*128 + mb*16 + l15,
     //      channels n0 + wc*64 + chan_of(ni, nf, 4 q4 + r), r = 0..3
-    auto epilogue = [&](const Seg& s, int lb) {
+    auto epilogue = [&](const Seg& s, int lb, [[maybe_unused]] RopePre& rp, [[maybe_unused]] const bool dma_behind) {
         // (laundered copies: keeps the segment-invariant address arithmetic of the epilogue from being hoisted out of the persistent
         // loop, where it would stay live across the main loop and push its 128 + 64 registers into scratch)
         int l15 = l15_, q4 = q4_;
@@ -737,16 +813,22 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             f32x4_t c1v[2], c1g[2], c2v[2], c2g[2];
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
-                c1v[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + q4 * 8 + nf * 4);
-                c1g[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + 32 + q4 * 8 + nf * 4);
-                c2v[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + q4 * 8 + nf * 4);
-                c2g[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + 32 + q4 * 8 + nf * 4);
+                c1v[nf] = lds_ld128(lc1 + q4 * 8 + nf * 4);
+                c1g[nf] = lds_ld128(lc1 + 32 + q4 * 8 + nf * 4);
+                c2v[nf] = lds_ld128(lc2 + q4 * 8 + nf * 4);
+                c2g[nf] = lds_ld128(lc2 + 32 + q4 * 8 + nf * 4);
             }
+            float2 stv[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) stv[mb] = lds_ld64(ln + mb * 16 + l15);
+            lds_wait(c1v[0], c1v[1], c1g[0], c1g[1], c2v[0], c2v[1], c2g[0], c2g[1]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) lds_tie(stv[mb]);
             op_t* __restrict__ hbase = g.H + (ncol0 >> 1) + q4 * 8;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int m = mrow0 + mb * 16;
-                const float2 st = ln[mb * 16 + l15];
+                const float2 st = stv[mb];
                 unsigned pk[4];
                 [[maybe_unused]] float hv8[8];
 #pragma unroll
@@ -804,32 +886,46 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 f32x4_t c1[4], c2[4];
 #pragma unroll
                 for (int nf = 0; nf < 2; ++nf) {
-                    c1[nf] = *reinterpret_cast<const f32x4_t*>(lc1 + nf * 16 + 4 * q4);
-                    c2[nf] = *reinterpret_cast<const f32x4_t*>(lc2 + nf * 16 + 4 * q4);
-                    c1[2 + nf] = *reinterpret_cast<const f32x4_t*>(lc1 + 32 + q4 * 8 + nf * 4);
-                    c2[2 + nf] = *reinterpret_cast<const f32x4_t*>(lc2 + 32 + q4 * 8 + nf * 4);
+                    c1[nf] = lds_ld128(lc1 + nf * 16 + 4 * q4);
+                    c2[nf] = lds_ld128(lc2 + nf * 16 + 4 * q4);
+                    c1[2 + nf] = lds_ld128(lc1 + 32 + q4 * 8 + nf * 4);
+                    c2[2 + nf] = lds_ld128(lc2 + 32 + q4 * 8 + nf * 4);
+                }
+                float2 stv[2];          // (mean, rstd) of the lane's row: read one row block ahead
+                stv[0] = lds_ld64(ln + l15);
+                [[maybe_unused]] f32x4_t c16 = lds_ld128(smem + ROPE16_OFF + 16 * q4), s16 = lds_ld128(smem + ROPE16_OFF + 64 + 16 * q4);
+                lds_wait(c1[0], c1[1], c1[2], c1[3], c2[0], c2[1], c2[2], c2[3], c16, s16, stv[0]);
+                // (sequence, position) of the lane's eight rows: one division, then steps of 16 rows (rows beyond M keep walking: they are never
+                // stored, and their table index stays inside [0, S))
+                int b = 0, sq_ = 0;
+                {
+                    const int mc = mrow0 < M ? mrow0 : M - 1;
+                    b = mc / S;
+                    sq_ = mc - b * S;
+                }
+                if (kind & 2) {
+                    // (requested in front of the next range's prologue: this wait does not hold the epilogue until its `dma_behind` pieces land)
+                    if (dma_behind) rope_wait(std::integral_constant<int, PRO_DMA>{}, rp);
+                    else rope_wait(std::integral_constant<int, 0>{}, rp);
                 }
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     const int m = mrow0 + mb * 16;
-                    const int mc = m < M ? m : M - 1;
-                    const int b = mc / S;
-                    const int sq_ = mc - b * S;
                     const int ob = (kind & 4) ? ((b * S) & 3) : 0;
-                    const float2 st = ln[mb * 16 + l15];
+                    if (mb) lds_wait(stv[mb & 1]);
+                    const float2 st = stv[mb & 1];
+                    if (mb + 1 < MB) stv[(mb + 1) & 1] = lds_ld64(ln + (mb + 1) * 16 + l15);
                     f32x4_t x[4];
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[nb][e] = fold(acc[mb][nb][e], st.x, st.y, c1[nb][e], c2[nb][e]);
                     if (kind & 2) {
-                        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(he.rope_cos + (size_t)sq_ * 16 + 4 * q4);
-                        const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(he.rope_sin + (size_t)sq_ * 16 + 4 * q4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float x1 = x[0][e], x2 = x[1][e];
-                            x[0][e] = x1 * cs[e] - x2 * sn[e];
-                            x[1][e] = x2 * cs[e] + x1 * sn[e];
+                            x[0][e] = x1 * rp.cs[e] - x2 * rp.sn[e];
+                            x[1][e] = x2 * rp.cs[e] + x1 * rp.sn[e];
                         }
                     }
                     if (kind & 8) {   // query: pre-scaled for the attention kernel (one rounding, here)
@@ -843,6 +939,23 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         *reinterpret_cast<u32x4*>(row + 32 + 8 * q4) = u32x4{pack_op2(x[2][0], x[2][1]), pack_op2(x[2][2], x[2][3]),
                                                                              pack_op2(x[3][0], x[3][1]), pack_op2(x[3][2], x[3][3])};
                     }
+                    sq_ += 16;
+                    while (sq_ >= S) {
+                        sq_ -= S;
+                        ++b;
+                    }
+                    if ((kind & 2) && mb + 1 < MB) {
+                        // the next row block is 16 positions on: rotate (cos, sin) by the angle of position 16 -- unless a lane of the wave just
+                        // crossed into the next sequence (its position fell below 16), then the wave re-reads the table (rare: one row block per sequence)
+                        if (__builtin_amdgcn_ballot_w64(sq_ < 16) != 0 || S <= 16) {
+                            rope_load(rp.cs, rp.sn, sq_, q4);
+                            rope_wait(std::integral_constant<int, 0>{}, rp);
+                        } else {
+                            const f32x4_t c = rp.cs, sn_ = rp.sn;
+                            rp.cs = c * c16 - sn_ * s16;
+                            rp.sn = sn_ * c16 + c * s16;
+                        }
+                    }
                 }
             } else {
                 // V^T [B, H, 64, Spad] (no rotation): un-swapped accumulators, lane = channel d = 16 nb + l15, registers = the four
@@ -852,14 +965,23 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 float c1[4], c2[4];
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    c1[nb] = lc1[nb * 16 + l15];
-                    c2[nb] = lc2[nb * 16 + l15];
+                    c1[nb] = lds_ld32(lc1 + nb * 16 + l15);
+                    c2[nb] = lds_ld32(lc2 + nb * 16 + l15);
                 }
+                // (mean, rstd) of the lane's four rows of a row block: read one row block ahead (two register sets)
+                f32x4_t stq[2][2];
+                stq[0][0] = lds_ld128(ln + 4 * q4);
+                stq[0][1] = lds_ld128(ln + 4 * q4 + 2);
+                lds_wait(c1[0], c1[1], c1[2], c1[3], c2[0], c2[1], c2[2], c2[3], stq[0][0], stq[0][1]);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     const int mbase = s.m0 + wr * WR + mb * 16 + 4 * q4;          // multiple of 4
-                    const f32x4_t* sp = reinterpret_cast<const f32x4_t*>(ln + mb * 16 + 4 * q4);
-                    const f32x4_t st01 = sp[0], st23 = sp[1];                    // (mean, rstd) of rows e = 0, 1 / 2, 3
+                    if (mb) lds_wait(stq[mb & 1][0], stq[mb & 1][1]);
+                    const f32x4_t st01 = stq[mb & 1][0], st23 = stq[mb & 1][1];                    // (mean, rstd) of rows e = 0, 1 / 2, 3
+                    if (mb + 1 < MB) {
+                        stq[(mb + 1) & 1][0] = lds_ld128(ln + (mb + 1) * 16 + 4 * q4);
+                        stq[(mb + 1) & 1][1] = lds_ld128(ln + (mb + 1) * 16 + 4 * q4 + 2);
+                    }
                     int bb[4], ss[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -946,6 +1068,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         }
         if constexpr (DBG == 9) t1 = __builtin_amdgcn_s_memrealtime();
         const bool more = next_seg(nxt);
+        [[maybe_unused]] RopePre rp;
+        if constexpr (EPI == EPI_HEADS) {
+            if (rows_valid && cur.tr && (g.heads.kind[cur.n0 / (g.heads.heads * 64)] & 2)) rope_prefetch(cur, rp);
+        }
         if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
         bool fin = true;
         if (EPI == EPI_F32 && !cur.whole) {           // a part of a K-split tile (fp32 output only): plain stores of the raw accumulators, the kernel
@@ -959,7 +1085,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             fin = false;
         }
         if constexpr (DBG == 9) t2 = __builtin_amdgcn_s_memrealtime();
-        if (fin && rows_valid) epilogue(cur, lb);
+        if (fin && rows_valid) epilogue(cur, lb, rp, more);
         if constexpr (DBG == 9) {
             if (tid_ == 0 && ts_n < 4) {
                 unsigned long long* o = ts + ((size_t)blockIdx.x * 4 + ts_n) * 8;
@@ -1111,7 +1237,7 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
         SAT_CHECK_ARG(!a.fp8 && !a.H8, SAT_E_UNSUPPORTED, "gemm(8-phase): built for bf16 operands");
     }
     constexpr int BM = 64 * MFQ, BN = 64 * WN, NT = 2 * WN * 64;
-    constexpr int LDS = 2 * 2 * (BM / 2 + BN / 2) * 128 + 2 * (BM + BN) * 8;          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column)
+    constexpr int LDS = 2 * 2 * (BM / 2 + BN / 2) * 128 + 2 * (BM + BN) * 8 + (EPI == EPI_HEADS ? 128 : 0);          // ring + 2 x ((mean, rstd) per row + (c1, c2) per column) + rotation constants
     SAT_CHECK_ARG(a.N % BN == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): N=%d not a multiple of %d", a.N, BN);
     SAT_CHECK_ARG(a.K % 128 == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): K=%d must be a multiple of 128", a.K);
     SAT_CHECK_ARG((uint64_t)a.M * (uint64_t)a.K * 2u < (1ull << 31), SAT_E_UNSUPPORTED, "gemm(8-phase): A larger than 2 GiB");

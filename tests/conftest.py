@@ -10,12 +10,12 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-# The parity suite was written against the bf16 build (tolerances, matched-rounding hooks); the fp16 build -- the package default since
-# round 4 -- is covered by the tests that are parametrised over the operand format or switch a model to "fp16" explicitly, and by
-# test_package_default_is_fp16 / test_default_path_* which run what a user gets.  Everything else pins bf16 here.
+# The suite runs on the build a user gets: the package default operand format (fp16 since round 4).  SAT_TEST_DTYPE=bf16 runs the same suite
+# on the bf16 build (tests/util.py: SUITE, gates / 4 under fp16); tests parametrised over the format cover both either way.
 from stable_audio_tools import _config  # noqa: E402
+from util import SUITE  # noqa: E402
 
-PACKAGE_DEFAULT_GEMM_DTYPE = _config.set_default_gemm_dtype("bf16")
+PACKAGE_DEFAULT_GEMM_DTYPE = _config.set_default_gemm_dtype(SUITE.gemm_dtype)
 
 
 def pytest_configure(config):

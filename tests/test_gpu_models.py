@@ -14,7 +14,9 @@ Tolerances (bf16 GEMM operands, fp32 accumulate / residual / LN / softmax):
 import pytest
 import torch
 
-from util import assert_close, bf16_round, fp16_round, rel_l2
+from util import SUITE, assert_close, bf16_round, fp16_round, rel_l2
+
+T = SUITE.tol          # a bf16 gate -> the gate of the suite's operand format (fp16: / 4)
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +36,7 @@ def _matched():
     """Rounding hook of the default DiT plan for bf16 / "prepend" models: bf16 operands, LayerNorms folded into the GEMMs
     (sat_dit_cfg.ln_fold; oracle/dit.py LnFoldRounding).  With ``set_layernorm_fusion(False)`` the hook is plain ``bf16_round``."""
     from oracle import dit as odit
-    return odit.LnFoldRounding()
+    return odit.LnFoldRoundingF16() if SUITE.f16 else odit.LnFoldRounding()
 
 
 def _sub(sd, prefix):
@@ -81,7 +83,7 @@ def test_cross_attention_fusion_on_off(dev, small_dit):
         if b == 1:
             assert torch.equal(fused, separate), f"fused vs separate cross-attention: max abs diff {(fused - separate).abs().max().item():.3e}"
         else:
-            assert_close("fused vs separate cross-attention, 3 sequences", fused, separate, 2e-3)
+            assert_close("fused vs separate cross-attention, 3 sequences", fused, separate, T(2e-3))
 
 
 def test_layernorm_fusion_on_off(dev, small_dit):
@@ -102,12 +104,12 @@ def test_layernorm_fusion_on_off(dev, small_dit):
         model.model.model.set_layernorm_fusion(True)
     assert not torch.equal(fused, plain), "the switch did not change the plan"
     want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"])
-    e_p = assert_close("standalone LayerNorm plan vs matched oracle", plain, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=bf16_round), 3e-3)
-    e_f = assert_close("fused plan vs matched oracle", fused, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=_matched()), 3e-3)
-    e_x = assert_close("fused vs standalone plan", fused, plain, 3e-3)
+    e_p = assert_close("standalone LayerNorm plan vs matched oracle", plain, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=SUITE.round), T(3e-3))
+    e_f = assert_close("fused plan vs matched oracle", fused, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=_matched()), T(3e-3))
+    e_x = assert_close("fused vs standalone plan", fused, plain, T(3e-3))
     print(f"\n[ln_fold] standalone vs matched {e_p:.2e}, fused vs matched {e_f:.2e}, fused vs standalone {e_x:.2e}; "
           f"vs fp32: standalone {rel_l2(plain, want_f):.2e}, fused {rel_l2(fused, want_f):.2e}")
-    assert rel_l2(fused, want_f) <= 2.5e-3 and rel_l2(plain, want_f) <= 2.5e-3
+    assert rel_l2(fused, want_f) <= T(2.5e-3) and rel_l2(plain, want_f) <= T(2.5e-3)
 
 
 @pytest.mark.parametrize("t_len", [64, 77])
@@ -121,8 +123,8 @@ def test_dit_forward_no_cfg(dev, small_dit, t_len):
     got = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0)
     want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=_matched())
     want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"])
-    e_m = assert_close("dit forward vs matched oracle", got, want_m, 3e-3)
-    e_f = assert_close("dit forward vs fp32 oracle", got, want_f, 2.5e-3)
+    e_m = assert_close("dit forward vs matched oracle", got, want_m, T(3e-3))
+    e_f = assert_close("dit forward vs fp32 oracle", got, want_f, T(2.5e-3))
     print(f"\n[dit T={t_len}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
 
 
@@ -138,8 +140,8 @@ def test_dit_forward_cfg_and_denoise(dev, small_dit):
                           cross_attn_mask=torch.ones(3, 130, device=dev))
         want_m = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, scale_phi=phi, rnd=_matched())
         want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, scale_phi=phi)
-        e_m = assert_close(f"dit cfg7 phi={phi} vs matched", got, want_m, 1e-2)
-        e_f = assert_close(f"dit cfg7 phi={phi} vs fp32", got, want_f, 1.2e-2)
+        e_m = assert_close(f"dit cfg7 phi={phi} vs matched", got, want_m, T(1e-2))
+        e_f = assert_close(f"dit cfg7 phi={phi} vs fp32", got, want_f, T(1.2e-2))
         print(f"\n[dit cfg7 phi={phi}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
     # fused VDenoiser evaluation == oracle vdenoise around the CFG model
     sigma = 3.7
@@ -149,11 +151,11 @@ def test_dit_forward_cfg_and_denoise(dev, small_dit):
     got = dit.denoise(xs.to(dev), sigma, cfg_scale=7.0)
     fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=_matched())
     want = osamp.vdenoise(fn, xs, torch.full((3,), sigma))
-    assert_close("denoise_cfg vs matched oracle", got, want, 1e-2)
+    assert_close("denoise_cfg vs matched oracle", got, want, T(1e-2))
     # uncond half sees an all-zero context: its cross-attention must contribute exactly nothing
     got1 = model.model(x.to(dev), t.to(dev), cross_attn_cond=torch.zeros_like(c).to(dev), global_cond=g.to(dev), cfg_scale=1.0)
     want1 = odit.dit_forward(dsd, x, t, torch.zeros_like(c), g, dc["depth"], dc["num_heads"], rnd=_matched())
-    assert_close("zero-context forward", got1, want1, 3e-3)
+    assert_close("zero-context forward", got1, want1, T(3e-3))
 
 
 def test_negative_prompt_vs_reference_golden(dev):
@@ -180,12 +182,12 @@ def test_negative_prompt_vs_reference_golden(dev):
     neg_mask = torch.ones(c.shape[0], c.shape[1])
     neg_mask[1, 40:] = 0
     got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0, negative_cross_attn_cond=c_neg.to(dev))
-    e1 = assert_close("negative prompt vs reference", got, gold["cfg7_negative_T64"], 1.6e-2)          # measured 7.9e-3
+    e1 = assert_close("negative prompt vs reference", got, gold["cfg7_negative_T64"], T(1.6e-2))          # measured 7.9e-3
     got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0, negative_cross_attn_cond=c_neg.to(dev),
               negative_cross_attn_mask=neg_mask.to(dev))
-    e2 = assert_close("masked negative prompt vs reference", got, gold["cfg7_negative_masked_T64"], 1.6e-2)   # measured 8.2e-3
+    e2 = assert_close("masked negative prompt vs reference", got, gold["cfg7_negative_masked_T64"], T(1.6e-2))   # measured 8.2e-3
     want_m = odit.dit_forward(sd, x, t, c, g, 3, 4, cfg_scale=7.0, negative_cross_attn_cond=c_neg, negative_cross_attn_mask=neg_mask, rnd=_matched())
-    assert_close("masked negative prompt vs matched oracle", got, want_m, 1e-2)
+    assert_close("masked negative prompt vs matched oracle", got, want_m, T(1e-2))
     print(f"\n[negative prompt] rel-L2 vs the reference {e1:.2e}, masked {e2:.2e}")
 
 
@@ -218,7 +220,7 @@ def test_generate_with_negative_conditioning(dev, small_dit):
     fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, negative_cross_attn_cond=nc,
                                           negative_cross_attn_mask=ni["negative_cross_attn_mask"].cpu(), rnd=_matched())
     want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), noise * sig[0], sig, lambda i, s, sn: step_noise[i])
-    e = assert_close("trajectory with a negative prompt vs matched oracle", lat, want, 2e-2)
+    e = assert_close("trajectory with a negative prompt vs matched oracle", lat, want, T(2e-2))
     it = iter(step_noise)
     plain = generate_diffusion_cond(model, steps=steps, cfg_scale=7.0, conditioning_tensors=pos, sample_size=t_len * ratio, seed=5,
                                     device=str(dev), sampler_type="dpmpp-3m-sde", sigma_min=0.3, sigma_max=500, return_latents=True, noise=noise,
@@ -248,36 +250,38 @@ def test_dit_adaln_vs_reference_golden(dev):
     for t_len in (64, 77):
         x, t, c, g = cases.dit_inputs(2, t_len, 128, 96, 1)
         got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
-        want_m = odit.dit_forward(sd, x, t, c, g, 3, 4, rnd=bf16_round, adaln=True)
-        e_m = assert_close(f"adaLN T={t_len} vs matched oracle", got, want_m, 3e-3)
-        e_f = assert_close(f"adaLN T={t_len} vs reference", got, gold[f"cfg1_T{t_len}"], 2.5e-3)
+        want_m = odit.dit_forward(sd, x, t, c, g, 3, 4, rnd=SUITE.round, adaln=True)
+        e_m = assert_close(f"adaLN T={t_len} vs matched oracle", got, want_m, T(3e-3))
+        e_f = assert_close(f"adaLN T={t_len} vs reference", got, gold[f"cfg1_T{t_len}"], T(2.5e-3))
         print(f"\n[adaLN T={t_len}] rel-L2 vs matched {e_m:.2e}, vs the reference {e_f:.2e}")
     x, t, c, g = cases.dit_inputs(2, 77, 128, 96, 1)
     got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=7.0)
-    assert_close("adaLN cfg7 vs matched oracle", got, odit.dit_forward(sd, x, t, c, g, 3, 4, cfg_scale=7.0, rnd=bf16_round, adaln=True), 1e-2)
-    e7 = assert_close("adaLN cfg7 vs reference", got, gold["cfg7_T77"], 1.2e-2)
+    assert_close("adaLN cfg7 vs matched oracle", got, odit.dit_forward(sd, x, t, c, g, 3, 4, cfg_scale=7.0, rnd=SUITE.round, adaln=True), T(1e-2))
+    e7 = assert_close("adaLN cfg7 vs reference", got, gold["cfg7_T77"], T(1.2e-2))
     print(f"\n[adaLN cfg7] rel-L2 vs the reference {e7:.2e}")
     got = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), cfg_scale=1.0)
-    assert_close("adaLN without global cond vs reference", got, gold["noglobal_T77"], 2.5e-3)
+    assert_close("adaLN without global cond vs reference", got, gold["noglobal_T77"], T(2.5e-3))
     # adaLN-modulated LayerNorm fused with the e4m3 row quantisation (fp8 GEMM mode)
     for mode, fams in (("fp8", odit.FP8_DEFAULT_FAMILIES), ("fp8-all", odit.FP8_FAMILIES)):
         dit.set_gemm_dtype(mode)
         got8 = dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
         assert_close(f"adaLN {mode} vs matched fp8 oracle", got8, odit.dit_forward(sd, x, t, c, g, 3, 4, rnd=odit.Fp8Rounding(fams), adaln=True), 5e-3)
-    dit.set_gemm_dtype("bf16")
+    dit.set_gemm_dtype(SUITE.gemm_dtype)
     # fused sampler-step entry point
     dit.prepare_generation(c.to(dev), g.to(dev), 7.0)
     sigma = 2.3
     from oracle import sampler as osamp
-    fn = lambda xin, tt: odit.dit_forward(sd, xin, tt, c, g, 3, 4, cfg_scale=7.0, rnd=bf16_round, adaln=True)
+    fn = lambda xin, tt: odit.dit_forward(sd, xin, tt, c, g, 3, 4, cfg_scale=7.0, rnd=SUITE.round, adaln=True)
     assert_close("adaLN denoise_cfg", dit.denoise((x * sigma).to(dev), sigma, cfg_scale=7.0), osamp.vdenoise(fn, x * sigma, torch.full((2,), sigma)), 1e-2)
 
 
-def test_dit_fp16_mode(dev, small_dit):
-    """gemm_dtype "fp16" (round 4): the fp16 build of every block kernel (v_mfma_f32_*_f16, the same rate as bf16 on gfx950) against
-    the oracle with fp16 rounding at the same store points (LnFoldRoundingF16 / plain fp16_round without the LayerNorm fold) and
-    against the fp32 oracle -- 8x less operand rounding than bf16: the gates are the bf16 gates / 4."""
+def test_dit_other_operand_format(dev, small_dit):
+    """The operand format the suite does NOT default to (SAT_TEST_DTYPE, tests/conftest.py; "fp16" = the package default, round 4: the fp16
+    build of every block kernel, v_mfma_f32_*_f16 at the bf16 rate): switched on through set_gemm_dtype, against the oracle with that format's
+    rounding at the same store points (LnFoldRounding[F16] / plain rounding without the LayerNorm fold) and against the fp32 oracle.  fp16
+    carries 8x less operand rounding than bf16: its gates are the bf16 gates / 4."""
     from oracle import dit as odit
+    from util import OperandFormat
     cfg, model, sd = small_dit
     dc = cfg["model"]["diffusion"]["config"]
     dsd = _sub(sd, "model.model.")
@@ -285,27 +289,31 @@ def test_dit_fp16_mode(dev, small_dit):
     x, c, g = _inputs(2, 77, dc["cond_token_dim"])
     t = torch.tensor([0.31, 0.87])
     run = lambda **kw: model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), **kw)
-    bf = run(cfg_scale=1.0)
+    base = run(cfg_scale=1.0)
     want_f = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"])
-    dit.set_gemm_dtype("fp16")
+    other = OperandFormat("bf16" if SUITE.f16 else "f16")
+    TO = other.tol
+    dit.set_gemm_dtype(other.gemm_dtype)
     try:
         got = run(cfg_scale=1.0)
-        e_m = assert_close("fp16 dit vs matched fp16 oracle", got, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=odit.LnFoldRoundingF16()), 7.5e-4)
-        e_f = assert_close("fp16 dit vs fp32 oracle", got, want_f, 6e-4)
-        e_b = rel_l2(got, bf)
-        assert e_b > 1e-4, "fp16 mode must actually change the arithmetic"
+        fold_rnd = odit.LnFoldRoundingF16() if other.f16 else odit.LnFoldRounding()
+        e_m = assert_close(f"{other.gemm_dtype} dit vs its matched oracle", got, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=fold_rnd), TO(3e-3))
+        e_f = assert_close(f"{other.gemm_dtype} dit vs fp32 oracle", got, want_f, TO(2.4e-3))
+        e_b = rel_l2(got, base)
+        assert e_b > 1e-4, "the switch must actually change the arithmetic"
         got7 = run(cfg_scale=7.0)
         want7 = odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], cfg_scale=7.0)
-        e_7 = assert_close("fp16 dit cfg7 vs fp32 oracle", got7, want7, 3e-3)
+        e_7 = assert_close(f"{other.gemm_dtype} dit cfg7 vs fp32 oracle", got7, want7, TO(1.2e-2))
         dit.set_layernorm_fusion(False)
         plain = run(cfg_scale=1.0)
-        e_p = assert_close("fp16 standalone-LayerNorm plan vs matched oracle", plain, odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=odit.fp16_round), 7.5e-4)
-        print(f"\n[dit fp16] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e} (bf16 path vs fp32: {rel_l2(bf, want_f):.2e}), CFG 7 vs fp32 {e_7:.2e}, "
-              f"standalone LayerNorms vs matched {e_p:.2e}, vs the bf16 path {e_b:.2e}")
+        e_p = assert_close(f"{other.gemm_dtype} standalone-LayerNorm plan vs matched oracle", plain,
+                           odit.dit_forward(dsd, x, t, c, g, dc["depth"], dc["num_heads"], rnd=other.round), TO(3e-3))
+        print(f"\n[dit {other.gemm_dtype}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e} ({SUITE.gemm_dtype} path vs fp32: {rel_l2(base, want_f):.2e}), CFG 7 vs fp32 {e_7:.2e}, "
+              f"standalone LayerNorms vs matched {e_p:.2e}, vs the {SUITE.gemm_dtype} path {e_b:.2e}")
     finally:
         dit.set_layernorm_fusion(True)
-        dit.set_gemm_dtype("bf16")
-    assert torch.equal(run(cfg_scale=1.0), bf), "switching back to bf16 must restore the default path bit for bit"
+        dit.set_gemm_dtype(SUITE.gemm_dtype)
+    assert torch.equal(run(cfg_scale=1.0), base), "switching back must restore the default path bit for bit"
 
 
 @pytest.mark.parametrize("mode", ["fp8", "fp8-all"])
@@ -340,9 +348,9 @@ def test_dit_fp8_gemm_mode(dev, small_dit, mode):
         # CFG 7 extrapolates the cond/uncond difference ~7x: 7 x (4e-3, a handful of e4m3 codes flipped by accumulation order) + margin
         assert_close("fp8 dit cfg7 vs matched fp8 oracle", got7, want7, 5e-2)
     finally:
-        dit.set_gemm_dtype("bf16")
+        dit.set_gemm_dtype(SUITE.gemm_dtype)
     again = model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0)
-    assert torch.equal(again, bf), "switching back to bf16 must restore the default path bit for bit"
+    assert torch.equal(again, bf), "switching back must restore the default path bit for bit"
 
 
 @pytest.fixture(scope="module")
@@ -370,7 +378,7 @@ def test_oobleck_decode(dev, small_vae, b, t_len, fmt):
     try:
         got = model.decode(z.to(dev))
     finally:
-        model.set_gemm_dtype("bf16")
+        model.set_gemm_dtype(SUITE.gemm_dtype)
     dsd = _sub(sd, "decoder.")
     want_f = oob.oobleck_decoder(dsd, z, strides=strides)
     want_m = oob.oobleck_decoder(dsd, z, strides=strides, rnd=rnd)
@@ -399,7 +407,7 @@ def test_oobleck_encode_and_vae(dev, small_vae, b, t_len, fmt):
         got = model.encoder(audio.to(dev))
         z = model.encode(audio.to(dev), noise=noise.to(dev))
     finally:
-        model.set_gemm_dtype("bf16")
+        model.set_gemm_dtype(SUITE.gemm_dtype)
     e_f = assert_close("encode vs fp32 oracle", got, want_f, tol_f)
     e_m = assert_close("encode vs matched oracle", got, want_m, tol_m)
     print(f"\n[encode b={b} T={t_len}, {fmt}] rel-L2 vs matched {e_m:.2e}, vs fp32 {e_f:.2e}")
@@ -433,7 +441,7 @@ def test_generate_diffusion_cond_small(dev, small_dit):
     sig = osamp.get_sigmas_polyexponential(steps, 0.3, 500.0, 1.0)
     fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=_matched())
     want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), noise * sig[0], sig, lambda i, s, sn: step_noise[i])
-    e = assert_close("6-step latent trajectory vs matched oracle", lat, want, 2e-2)
+    e = assert_close("6-step latent trajectory vs matched oracle", lat, want, T(2e-2))
     print(f"\n[generate small] latent rel-L2 vs matched oracle {e:.2e}")
     # full call incl. decode; reproducible from the seed
     a1 = generate_diffusion_cond(model, steps=3, cfg_scale=7.0, conditioning_tensors=cond, sample_size=t_len * ratio, seed=9,
@@ -444,7 +452,7 @@ def test_generate_diffusion_cond_small(dev, small_dit):
     assert torch.equal(a1, a2), "same seed must give the same audio"
     vsd = _sub(sd, "pretransform.model.decoder.")
     strides = cfg["model"]["pretransform"]["config"]["decoder"]["config"]["strides"]
-    assert_close("pretransform.decode", model.pretransform.decode(lat), oob.oobleck_decoder(vsd, lat.cpu(), strides=strides, rnd=bf16_round), 1.5e-2)
+    assert_close("pretransform.decode", model.pretransform.decode(lat), oob.oobleck_decoder(vsd, lat.cpu(), strides=strides, rnd=SUITE.round), T(1.5e-2))
 
 
 @pytest.mark.parametrize("sampler_type", ["dpmpp-2m-sde", "dpmpp-3m-sde"])
@@ -476,7 +484,7 @@ def test_sample_k_inpainting_and_2m(dev, small_dit, sampler_type):
     x0, cb = osamp.inpainting_start_and_callback(init, noise * sig[0], mask, steps, lambda i: renoise[i])
     solver = osamp.sample_dpmpp_2m_sde if sampler_type == "dpmpp-2m-sde" else osamp.sample_dpmpp_3m_sde
     want = solver(lambda x, s_: osamp.vdenoise(fn, x, s_), x0.clone(), sig, lambda i, a_, b_: step_noise[i], callback=cb)
-    e = assert_close(f"inpainting trajectory ({sampler_type}) vs matched oracle", got, want, 2e-2)
+    e = assert_close(f"inpainting trajectory ({sampler_type}) vs matched oracle", got, want, T(2e-2))
     print(f"\n[inpaint {sampler_type}] rel-L2 {e:.2e}")
     with pytest.raises(NotImplementedError):
         sample_k(model.model, noise.to(dev), None, None, steps, sampler_type="k-euler-nonexistent", cross_attn_cond=c.to(dev),
@@ -517,7 +525,7 @@ def test_sample_k_single_step_samplers(dev, small_dit, sampler_type):
         want = osamp.sample_dpmpp_2s_ancestral(den, x0, sig, lambda i, a_, b_: step_noise[i])
     else:
         want = osamp.sample_dpm_fast(den, x0, 0.3, 80.0, steps)
-    e = assert_close(f"{sampler_type} trajectory vs matched oracle", got, want, 2e-2)
+    e = assert_close(f"{sampler_type} trajectory vs matched oracle", got, want, T(2e-2))
     assert seen == list(range(len(seen))) and len(seen) >= 2
     print(f"\n[{sampler_type}] rel-L2 {e:.2e}")
 
@@ -546,7 +554,7 @@ def test_sample_k_dpm_adaptive(dev, small_dit):
     print(f"\n[k-dpm-adaptive] product {info}  oracle {winfo}")
     assert info["steps"] >= 3 and info["nfe"] == 3 * info["steps"]
     assert (info["n_accept"], info["n_reject"]) == (winfo["n_accept"], winfo["n_reject"])
-    assert_close("k-dpm-adaptive latents vs matched oracle", got, want, 2e-2)
+    assert_close("k-dpm-adaptive latents vs matched oracle", got, want, T(2e-2))
 
 
 def test_rectified_flow_euler(dev, small_dit):
@@ -567,7 +575,7 @@ def test_rectified_flow_euler(dev, small_dit):
                     cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=3.0, batch_cfg=True, rescale_cfg=True)
     fn = lambda xin, tt: odit.dit_forward(dsd, xin, tt, c, g, dc["depth"], dc["num_heads"], cfg_scale=3.0, rnd=_matched())
     want = osamp.sample_discrete_euler(fn, init * (1 - 0.8) + noise * 0.8, steps, 0.8)
-    assert_close("rectified-flow Euler trajectory", got, want, 1e-2)
+    assert_close("rectified-flow Euler trajectory", got, want, T(1e-2))
 
 
 def _two_layer_full_width(dev, seed=0):
@@ -680,7 +688,7 @@ def test_full_size_dit_vs_reference_golden(dev, full_dit, t_len, gemm_dtype):
     try:
         got = full_dit(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_embed=g.to(dev), cfg_scale=1.0)
     finally:
-        full_dit.set_gemm_dtype("bf16")
+        full_dit.set_gemm_dtype(SUITE.gemm_dtype)
     e = assert_close(f"full-size DiT T={t_len} vs reference [{gemm_dtype}]", got, want, 8e-3 if gemm_dtype == "bf16" else 1e-3)
     print(f"\n[full DiT T={t_len}, {gemm_dtype}] rel-L2 vs the reference's fp32 output {e:.2e} (out std {want.std():.3f})")
 
@@ -742,7 +750,7 @@ def test_full_size_batch8_config3_config5(dev, full_dit, gemm_dtype):
         e_d = assert_close(f"[{gemm_dtype}] denoise_cfg B=8 vs forward + VDenoiser scalings", den, want_den, g_inv7)
         print(f"[config {'5' if gemm_dtype.startswith('fp8') else '3'}, {gemm_dtype}] fused denoise_cfg at B=8 vs forward + scalings: {e_d:.2e}")
     finally:
-        full_dit.set_gemm_dtype("bf16")
+        full_dit.set_gemm_dtype(SUITE.gemm_dtype)
 
 
 @pytest.mark.parametrize("gemm_dtype", ["bf16", "fp8", "fp8-all", "fp16"])
@@ -780,7 +788,7 @@ def test_full_size_trajectory(dev, full_dit, gemm_dtype):
                      device=str(dev), callback=cb, noise_sampler=lambda s, sn: next(it).to(dev), cfg_scale=tj["cfg_scale"],
                      cross_attn_cond=c.to(dev), global_cond=g.to(dev))
     finally:
-        full_dit.set_gemm_dtype("bf16")
+        full_dit.set_gemm_dtype(SUITE.gemm_dtype)
     snaps[tj["steps"]] = x
     # tolerances: (vs the matched-rounding oracle, vs the fp32 oracle) per snapshot
     # Measured on MI355X (round 3), rel-L2 after 4 / 8 / 12 steps:
@@ -809,6 +817,83 @@ def test_full_size_trajectory(dev, full_dit, gemm_dtype):
         assert_close(f"[{gemm_dtype}] latents after {i} steps vs fp32 oracle", snaps[i], gold[f"fp32_step{i}"], tol[i][1])
 
 
+# 100-step gates: ~2x the values measured on MI355X (round 5, printed by the test; profiles/r05_traj100_parity.txt), per format:
+# {snapshot: latents rel-L2 vs the fp32 oracle}, audio rel-L2 (worst of the two windows)
+TRAJ100_GATES = {
+    "fp32x": ({12: 1.0, 25: 1.0, 50: 1.0, 100: 1.0}, 1.0),
+    "fp16": ({12: 1.0, 25: 1.0, 50: 1.0, 100: 1.0}, 1.0),
+    "bf16": ({12: 1.0, 25: 1.0, 50: 1.0, 100: 1.0}, 1.0),
+    "fp8": ({12: 1.0, 25: 1.0, 50: 1.0, 100: 1.0}, 1.0),
+}
+
+
+@pytest.mark.parametrize("gemm_dtype", ["fp32x", "fp16", "bf16", "fp8"])
+def test_full_size_trajectory_100_steps(dev, full_dit, gemm_dtype):
+    """Parity at the HEADLINE's own length: the metric is a 100-step generation (generate.py:27-32,
+    inference/generation.py:95-261).  100 steps of DPM-Solver++(3M) SDE, sigma 500 -> 0.3, batched CFG 7, full-size SA-Open DiT (D = 1536,
+    T = 1024), initial and per-step noise injected, through the product's own `sample_k`, then the full-size Oobleck decode -- against the
+    CPU oracle's fp32 trajectory and audio (tests/golden/traj100_full.npz, generated by tests/golden/make_traj100_golden.py: latents after
+    12 / 25 / 50 / 100 steps, two 65 536-sample windows of the decoded audio).  `fp32x` -- the exact-fp32 verification mode, same plan, other
+    summation order -- is the yardstick: the trajectory amplifies any perturbation, so what the 16-bit formats add has to be read against the
+    distance between two fp32 evaluations.  Also reported: the codec alone (the ORACLE's final latents through the product's decoder)."""
+    import cases
+    import os
+    if os.environ.get("SAT_SKIP_SLOW") == "1":
+        pytest.skip("SAT_SKIP_SLOW=1")
+    from stable_audio_tools import synthetic
+    from stable_audio_tools.inference.sampling import sample_k
+    from stable_audio_tools.models import _init
+    from stable_audio_tools.models.autoencoders import OobleckDecoder
+    from stable_audio_tools.models.diffusion import DiTWrapper
+    gold = cases.load("traj100_full")
+    tj = cases.TRAJ100
+    c, g, noise, step_noise = cases.traj100_inputs()
+    wrap = DiTWrapper.__new__(DiTWrapper)          # sample_k wants the wrapper type; the full-size DiT of the fixture goes inside
+    torch.nn.Module.__init__(wrap)
+    wrap.model = full_dit
+    snaps = {}
+
+    def cb(info):
+        if info["i"] in tj["snapshots"]:           # x at the start of step i = the latents after i steps
+            snaps[info["i"]] = info["x"].clone()
+
+    sn_dev = [n.to(dev) for n in step_noise]
+    it = iter(sn_dev)
+    full_dit.set_gemm_dtype(gemm_dtype)
+    try:
+        x = sample_k(wrap, noise.to(dev), steps=tj["steps"], sampler_type="dpmpp-3m-sde", sigma_min=tj["sigma_min"], sigma_max=tj["sigma_max"],
+                     device=str(dev), callback=cb, noise_sampler=lambda s, sn: next(it), cfg_scale=tj["cfg_scale"],
+                     cross_attn_cond=c.to(dev), global_cond=g.to(dev))
+    finally:
+        full_dit.set_gemm_dtype(SUITE.gemm_dtype)
+    snaps[tj["steps"]] = x
+    assert torch.isfinite(x).all()
+    # the codec build that goes with the DiT's format (bf16 with bf16, fp16 with everything else: the package default)
+    codec_fmt = "bf16" if gemm_dtype == "bf16" else "fp16"
+    with _init.skip_init():
+        dec = OobleckDecoder(**cases.vae_kwargs(cases.FULL_VAE, True))
+    dec.load_state_dict(synthetic.synth_state_dict(dec.state_dict(), 0))
+    dec = dec.to(dev).set_gemm_dtype(codec_fmt)
+    audio = dec(x)
+    audio_codec_only = dec(gold[f"fp32_step{tj['steps']}"].to(dev))
+    assert audio.shape == (1, 2, 1024 * 2048) and torch.isfinite(audio).all()
+    lat_gate, audio_gate = TRAJ100_GATES[gemm_dtype]
+    msg, e_lat = [], {}
+    for i in tj["snapshots"]:
+        e_lat[i] = rel_l2(snaps[i], gold[f"fp32_step{i}"])
+        msg.append(f"latents after {i:3d} steps vs fp32 oracle {e_lat[i]:.2e}")
+    e_audio, e_codec = 0.0, 0.0
+    for name, s0 in tj["audio_windows"].items():
+        w = slice(s0, s0 + tj["audio_window_len"])
+        ea, ec = rel_l2(audio[:, :, w], gold[f"audio_{name}"]), rel_l2(audio_codec_only[:, :, w], gold[f"audio_{name}"])
+        msg.append(f"audio window '{name}': generation {ea:.2e}, codec alone ({codec_fmt}, on the oracle's latents) {ec:.2e}")
+        e_audio, e_codec = max(e_audio, ea), max(e_codec, ec)
+    print(f"\n[100-step full-size trajectory, {gemm_dtype}]\n  " + "\n  ".join(msg))
+    for i in tj["snapshots"]:
+        assert e_lat[i] <= lat_gate[i], f"[{gemm_dtype}] latents after {i} steps: rel-L2 {e_lat[i]:.3e} > {lat_gate[i]:.1e}"
+    assert e_audio <= audio_gate, f"[{gemm_dtype}] decoded audio: rel-L2 {e_audio:.3e} > {audio_gate:.1e}"
+
+
 def test_fp32x_mode_vs_reference_golden(dev, full_dit, small_dit):
     """gemm_dtype="fp32x": the fp32 verification mode (csrc/f32_ref.hip: exact fp32 MFMA, fp32 LayerNorm output, fp32 q / k / v / P)
     through the SAME plan, workspace layout, RoPE table, prepend token, null-context skip and CFG batching as the bf16 path.
@@ -831,7 +916,7 @@ def test_fp32x_mode_vs_reference_golden(dev, full_dit, small_dit):
             e = assert_close(f"fp32x reduced DiT cfg {cfg_scale} vs fp32 oracle", got, want, tol)
             print(f"\n[fp32x reduced, cfg {cfg_scale}] rel-L2 vs fp32 oracle {e:.2e}")
     finally:
-        dit.set_gemm_dtype("bf16")
+        dit.set_gemm_dtype(SUITE.gemm_dtype)
     full_dit.set_gemm_dtype("fp32x")
     try:
         gold = cases.load("dit_full_T1024")
@@ -848,7 +933,7 @@ def test_fp32x_mode_vs_reference_golden(dev, full_dit, small_dit):
             e6 = assert_close("fp32x full-size DiT T=6144 vs reference", got, cases.load("dit_full_T6144")["out"], 1e-3)
         print(f"\n[fp32x full size] rel-L2 vs the reference: T=1024 {e1:.2e}, T=1024 CFG 7 {e7:.2e}, T=6144 {e6:.2e}  (north_star: 1e-3)")
     finally:
-        full_dit.set_gemm_dtype("bf16")
+        full_dit.set_gemm_dtype(SUITE.gemm_dtype)
 
 
 @pytest.mark.parametrize("mode", ["fp8", "fp8-all"])
@@ -910,13 +995,13 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
     ratio = cfg["model"]["downsampling_ratio"]
     strides = cfg["model"]["decoder"]["config"]["strides"]
     dsd, esd = _sub(sd, "decoder."), _sub(sd, "encoder.")
-    dec = lambda z: oob.oobleck_decoder(dsd, z, strides=strides, rnd=bf16_round)
+    dec = lambda z: oob.oobleck_decoder(dsd, z, strides=strides, rnd=SUITE.round)
     # chunked decode == oracle chunked decode; and agrees with the un-chunked decode away from the seams
     z = synthetic.synth_input("zc", (2, 64, 23), 51)
     got = vae.decode_audio(z.to(dev), chunked=True, chunk_size=8, overlap=2, max_batch_size=3)
     want = oob.decode_audio_chunked(dec, z, 8, 2, ratio)
     assert got.shape == want.shape == (2, 2, 23 * ratio)
-    assert_close("decode_audio chunked", got, want, 1e-2)
+    assert_close("decode_audio chunked", got, want, T(1e-2))
     # chunked encode with injected VAE noise: patch the bottleneck's draw through the `noise=` hook per call
     audio = synthetic.synth_input("ac", (1, 2, 19 * ratio), 52, 0.3)
     noises = [synthetic.synth_input(f"vn{i}", (2, 64, 8), 60 + i) for i in range(4)]
@@ -943,7 +1028,7 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
         outs = []
         for i in range(0, len(chunks), 2):
             grp = torch.cat(chunks[i:i + 2], dim=0)
-            ms = oob.oobleck_encoder(esd, grp, strides=cfg["model"]["encoder"]["config"]["strides"], rnd=bf16_round)
+            ms = oob.oobleck_encoder(esd, grp, strides=cfg["model"]["encoder"]["config"]["strides"], rnd=SUITE.round)
             outs += list(oob.vae_sample(ms, noises[it["i"]][: grp.shape[0]]).split(1, dim=0))
             it["i"] += 1
         return outs
@@ -956,7 +1041,7 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
     zs = iter(enc_chunks([padded[..., i * hop: i * hop + cs] for i in range(n_chunk)]))
     want = oob.encode_audio_chunked(lambda c: next(zs), audio, 8, 2, ratio, 64)
     assert n_calls == it["i"]
-    assert_close("encode_audio chunked", got, want, 1.5e-2)
+    assert_close("encode_audio chunked", got, want, T(1.5e-2))
     it["i"] = 0
     n_chunk_r = n_chunk                      # reconstruct pads with hop * n_chunk (reference quirk) but slices n_chunk chunks
     padded = F.pad(audio, (0, cs + hop * n_chunk_r - audio.shape[-1]))
@@ -964,7 +1049,7 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
     outs = iter([dec(zz) for zz in zs2])
     want = oob.reconstruct_audio_chunked(lambda c, i: next(outs), audio, 8, 2, ratio)
     assert rec.shape == audio.shape
-    assert_close("reconstruct_audio chunked", rec, want, 2e-2)
+    assert_close("reconstruct_audio chunked", rec, want, T(2e-2))
 
     # audio-to-audio (init_audio, init_noise_level): encode -> x = init + noise*sigma_max' -> sample -> latents
     from stable_audio_tools.inference.generation import generate_diffusion_cond
@@ -994,7 +1079,7 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
         bn.encode = orig
     padded = F.pad(init, (0, 100)).unsqueeze(0)
     esd2 = _sub(sdd, "pretransform.model.encoder.")
-    ms = oob.oobleck_encoder(esd2, padded, strides=pr["encoder"]["config"]["strides"], rnd=bf16_round)
+    ms = oob.oobleck_encoder(esd2, padded, strides=pr["encoder"]["config"]["strides"], rnd=SUITE.round)
     z0 = oob.vae_sample(ms, vnoise).repeat(b, 1, 1)
     ci = model.get_conditioning_inputs(cond)
     cac, gc = ci["cross_attn_cond"].cpu().float(), ci["global_cond"].cpu().float()
@@ -1002,7 +1087,7 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
     dsd2 = _sub(sdd, "model.model.")
     fn = lambda xin, tt: odit.dit_forward(dsd2, xin, tt, cac, gc, dc["depth"], dc["num_heads"], cfg_scale=7.0, rnd=_matched())
     want = osamp.sample_dpmpp_3m_sde(lambda x, s: osamp.vdenoise(fn, x, s), z0 + noise * sig[0], sig, lambda i, s, sn: step_noise[i])
-    assert_close("audio-to-audio latents", lat, want, 2e-2)
+    assert_close("audio-to-audio latents", lat, want, T(2e-2))
 
     # inpainting through the public entry point (generation.py:195-213): cut & paste of the init latents + soft mask; the
     # region the last step's binary mask keeps (mask <= 1: everything) must come out as init + renoise * sigma_last
@@ -1024,4 +1109,4 @@ def test_chunked_codec_and_audio_to_audio(dev, small_dit, small_vae):
     sig_in = osamp.get_sigmas_polyexponential(steps, 0.3, 50.0, 1.0)
     x0, cb = osamp.inpainting_start_and_callback(cut, noise * sig_in[0], build_mask(t_len, margs), steps, lambda i: renoise[i])
     want_in = osamp.sample_dpmpp_2m_sde(lambda x, s: osamp.vdenoise(fn, x, s), x0.clone(), sig_in, lambda i, s, sn: step_noise[i], callback=cb)
-    assert_close("inpainting latents (generate_diffusion_cond)", lat_in, want_in, 2e-2)
+    assert_close("inpainting latents (generate_diffusion_cond)", lat_in, want_in, T(2e-2))

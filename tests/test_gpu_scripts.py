@@ -22,8 +22,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def package_default(request):
-    """The operand format a freshly built model starts with: the suite pins "bf16" (conftest.py); "fp16" is what a user of the scripts
-    gets (stable_audio_tools/_config.py).  The scripts and the direct calls they are compared with are built under the same default."""
+    """The operand format a freshly built model starts with: "fp16" is what a user of the scripts gets
+    (stable_audio_tools/_config.py) and what the suite runs on by default (conftest.py), "bf16" the other build.  The scripts and the direct calls they are compared with are built under the same default."""
     from stable_audio_tools import _config
     prev = _config.set_default_gemm_dtype(request.param)
     yield request.param
