@@ -278,8 +278,7 @@ def main():
     dit.set_gemm_dtype(args.dtype)
     model.pretransform.model.set_gemm_dtype("fp16" if args.dtype == "fp16" else "bf16")        # the codec follows (fp16 = the reference's model_half)
     dit.set_layernorm_fusion(args.layernorm == "fused")
-    from stable_audio_tools import _hip
-    _hip.check(_hip.lib().sat_set_cross_attention_fusion(1 if args.cross_attention == "fused" else 0))
+    dit.set_cross_attention_fusion(args.cross_attention == "fused")
 
     from stable_audio_tools import _hip
     lib = _hip.lib()

@@ -67,14 +67,7 @@ int sat_device_cus() {
     }
     return c;
 }
-extern "C" int sat_version(void) { return 4; }
-
-// to_q + cross-attention in one launch where it applies (A/B switch; process-wide like sat_gemm_set_wide_tile)
-static int g_cross_fusion = 1;
-extern "C" int sat_set_cross_attention_fusion(int32_t on) {
-    g_cross_fusion = on ? 1 : 0;
-    return 0;
-}
+extern "C" int sat_version(void) { return 5; }
 
 // ------------------------------------------------------------------------------ plan
 namespace {
@@ -115,6 +108,8 @@ struct sat_dit_plan {
     float *win_eff, *wout_eff;
     float *rope_cos, *rope_sin, *inv_freq;
     int f16 = 0;                    // cfg.gemm_dtype == 3: every 16-bit operand buffer holds IEEE fp16 and the fp16 build of the kernels runs
+    bool cross_fusion = true;       // cfg.cross_attention == 0: to_q + cross-attention core in one launch where it applies
+    int tile_bits = 0;              // cfg.tile_policy as GemmArgs::variant bits (sat_tile_policy_bits)
     bool ln_fold = false;           // cfg.ln_fold, bf16 / fp16 operands, "prepend" conditioning: LayerNorms run inside the GEMM epilogues
     int fp8_mode = 2;               // 2: v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, 2x rate); 1: v_mfma_f32_32x32x16_fp8_fp8
     // gemm_dtype == 1: which GEMM families take e4m3 operands (sat_dit_cfg.fp8_families; SAT_FP8_* bits); 0 in every other mode
@@ -441,7 +436,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         };
         if (p->f8_qkv) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.pre_g, L.pre_b, w.A, w.As, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
         else if (!L.fold_qkv) SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s, f16));
-        g = GemmArgs{}; g.f16 = f16;
+        g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
         g.A = w.A; g.W = L.w_qkv; g.M = M; g.N = 3 * D; g.K = D;
         if (L.fold_qkv) fold_in(g, L.c1_qkv, L.c2_qkv);
         if (p->f8_qkv) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_qkv; }
@@ -451,7 +446,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
         SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
         SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, p->f8_o ? w.AOs : nullptr, 1.0f, f16));
-        g = GemmArgs{}; g.f16 = f16;
+        g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
@@ -467,7 +462,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             if (bc > 0) {
                 if (p->f8_cq) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.cross_g, L.cross_b, w.A, w.As, Mc, D, nullptr, nullptr, 1, 0, s));
                 else if (!lf) SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s, f16));
-                g = GemmArgs{}; g.f16 = f16;
+                g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
                 g.A = w.A; g.W = L.w_cq; g.M = Mc; g.N = D; g.K = D;
                 if (lf) fold_in(g, L.c1_cq, L.c2_cq);
                 if (p->f8_cq) { g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_cq; }
@@ -477,7 +472,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 // One launch for to_q + softmax(q k^T) v where the 128 x 64 tile is the choice anyway and its workgroups fit one round
                 // (one prompt: 9 x 24 = 216): the projection's epilogue keeps Q in registers and attends to the <= 189 context keys
                 // staged in LDS (gemm_bf16.hip, XA_OK).  Saves the attention launch and the Q round trip.
-                const bool fuse = g_cross_fusion && !p->f8_cq && !p->f8_o && D >= 192 && p->ctx_lc + 3 <= 192 && cdiv(Mc, 128) * (D / 64) <= 256;
+                const bool fuse = p->cross_fusion && !p->f8_cq && !p->f8_o && D >= 192 && p->ctx_lc + 3 <= 192 && cdiv(Mc, 128) * (D / 64) <= 256;
                 if (fuse) {
                     g.heads.xa_k = p->kc + l * per_layer; g.heads.xa_vt = p->vct + l * per_layer; g.heads.xa_out = w.AO;
                     g.heads.xa_kvh = p->kvh_cross; g.heads.xa_sk = p->ctx_lc; g.heads.xa_sk_pad = p->ctx_lcpad;
@@ -486,7 +481,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 if (!fuse)
                     SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
                                                  p->ctx_lc, Spad, p->ctx_lcpad, s, p->f8_o ? w.AOs : nullptr, 1.0f, f16));
-                g = GemmArgs{}; g.f16 = f16;
+                g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
                 if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
                 fold_out(g);
@@ -498,7 +493,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                                                        S, ssg_ld, s));
         else if (!lf) SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
                                                        ssg_ld, s, f16));
-        g = GemmArgs{}; g.f16 = f16;
+        g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
         g.A = w.A; g.W = L.w_ff1; g.bias = L.b_ff1; g.M = M; g.N = 2 * p->inner; g.K = D; g.H = w.Hh;
         if (lf) { g.bias = nullptr; fold_in(g, L.c1_ff1, L.c2_ff1); }
         if (p->f8_ff1) {
@@ -522,7 +517,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             p->prof_n++;
             p->prof_m = g.M; p->prof_nn = g.N; p->prof_k = g.K;
         }
-        g = GemmArgs{}; g.f16 = f16;
+        g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (p->f8_ff2) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.Hs; g.w_scale = L.s_ff2; }
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
@@ -559,6 +554,11 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
     SAT_CHECK_ARG(cfg->gemm_dtype >= 0 && cfg->gemm_dtype <= 3, SAT_E_INVALID,
                   "dit_plan_create: gemm_dtype must be 0 (bf16), 1 (e4m3), 2 (fp32 verification) or 3 (fp16)");
     SAT_CHECK_ARG(cfg->gemm_dtype != 1 || cfg->embed_dim % 256 == 0, SAT_E_UNSUPPORTED, "dit_plan_create: gemm_dtype needs embed_dim %% 256 == 0");
+    SAT_CHECK_ARG(cfg->gemm_dtype == 1 || cfg->fp8_families == 0, SAT_E_INVALID,
+                  "dit_plan_create: fp8_families = 0x%x with gemm_dtype %d (a caller built against an older sat_dit_cfg layout?)", cfg->fp8_families, cfg->gemm_dtype);
+    SAT_CHECK_ARG(cfg->cross_attention == 0 || cfg->cross_attention == 1, SAT_E_INVALID, "dit_plan_create: cross_attention must be 0 (fused where it applies) or 1 (two kernels)");
+    SAT_CHECK_ARG(cfg->tile_policy == 0 || cfg->tile_policy == 22 || cfg->tile_policy == 80 || cfg->tile_policy == 81 || cfg->tile_policy == 82, SAT_E_INVALID,
+                  "dit_plan_create: tile_policy must be 0 / 80 (default), 22, 81 or 82");
     const int fam = cfg->fp8_families ? cfg->fp8_families : SAT_FP8_DEFAULT;
     if (cfg->gemm_dtype == 1) {
         SAT_CHECK_ARG((fam & ~SAT_FP8_ALL) == 0, SAT_E_INVALID, "dit_plan_create: unknown bits in fp8_families 0x%x", fam);
@@ -576,6 +576,8 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
         p->f8_qkv = fam & SAT_FP8_QKV; p->f8_cq = fam & SAT_FP8_CROSS_Q; p->f8_ff1 = fam & SAT_FP8_FF_IN; p->f8_ff2 = fam & SAT_FP8_FF_OUT;
         p->f8_o = fam & SAT_FP8_TO_OUT;
     }
+    p->cross_fusion = cfg->cross_attention == 0;
+    p->tile_bits = sat_tile_policy_bits(cfg->tile_policy);
     p->ln_fold = cfg->ln_fold != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
     return 0;

@@ -1531,7 +1531,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             }
         } else if (a.fp8 == 2) {      // block-scaled MFMA with unit scales: 2x the MFMA rate
             const int fv = a.variant & 0xff;
-            if ((fv == 80 || (fv == 0 && v == 22 && sat_g_wide_tile >= 80)) && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
+            if ((fv == 80 || (fv == 0 && v == 22 && sat_wide_tile_of(a.variant) >= 80)) && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
             switch (v) {
                 case 15: return launch_pipe<128, 128, 64, 4, 2, 3, EPI, 2>(a, stream);
                 case 16: return launch_pipe<128, 64, 64, 4, 1, 3, EPI, 2>(a, stream);
@@ -1558,7 +1558,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             // (profiles/r03_ph8_streamk.txt): SwiGLU 1.26, heads 1.07, fp32 output with a long reduction 1.02 -- and with the K-split of the
             // remainder round (sat_gemm_ph8_splits) the last round costs ~0.35 of a round instead of 1.
             double s256 = score(256, 256, 1.0);
-            if (sat_g_wide_tile >= 80 && sat_gemm_ph8_supports(EPI, a)) {
+            if (sat_wide_tile_of(a.variant) >= 80 && sat_gemm_ph8_supports(EPI, a)) {
                 const double rate = EPI == EPI_SWIGLU ? 1.26 : EPI == EPI_HEADS ? 1.07 : 1.02;
                 const long t = (long)cdiv(a.M, 256) * (a.N / 256);
                 const double rounds = sat_gemm_ph8_splits(EPI, a) ? (double)(t / cus) + 0.35 : (double)((t + cus - 1) / cus);
@@ -1576,15 +1576,15 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             // one round of 128 x 128 tiles (to_out / FF-out at one prompt: 204 workgroups on 256 CUs): the two-K-group build puts 8 waves of
             // 64 x 64 on every CU instead of 8 waves of 32 x 64 -- FF-out 56.5 us against 60.7, to_out 20.6 against 21.4 (tools/ph8_probe.py narrow)
             if ((v == 15 || v == 44) && EPI == EPI_F32 && !a.fp8 && a.K % 128 == 0 && a.K >= 256 && (long)cdiv(a.M, 128) * (a.N / 128) <= cus &&
-                !(a.variant & 0x800000) && sat_g_wide_tile != 82)
+                !(a.variant & 0x800000) && sat_wide_tile_of(a.variant) != 82)
                 v = 49;
         } else {
             v = 5;
         }
     }
     // the 256x256 tile is the 8-wave / 8-phase kernel of gemm_ph8.hip wherever it applies (bf16 operands, K % 128 == 0);
-    // sat_gemm_set_wide_tile(22) brings the 16-wave 2-stage tile back for A/B measurements
-    if (v == 22 && !(a.variant & 0xff) && sat_g_wide_tile >= 80 && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
+    // tile policy 22 (sat_dit_cfg.tile_policy) brings the 16-wave 2-stage tile back for A/B measurements
+    if (v == 22 && !(a.variant & 0xff) && sat_wide_tile_of(a.variant) >= 80 && sat_gemm_ph8_supports(EPI, a)) return sat_launch_gemm_ph8(EPI, a, stream);
     switch (v) {
         case 1: return launch_cfg<128, 128, 2, 2, EPI>(a, stream);
         case 5: return launch_cfg<128, 128, 2, 2, EPI, true>(a, stream);
@@ -1630,16 +1630,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-#ifndef SAT_OPERAND_F16
-int sat_g_wide_tile = 80;
-extern "C" int sat_gemm_set_wide_tile(int32_t tile) {
-    SAT_CHECK_ARG(tile == 22 || tile == 80 || tile == 81 || tile == 82, SAT_E_INVALID,
-                  "sat_gemm_set_wide_tile: 22 (16 waves, 2-stage ring), 80 (8 waves, 8-phase), 81 (80, also for the fp32-output GEMMs with K < 4096: A/B) or "
-                  "82 (80 without the two-K-group 128 x 128 tile: A/B)");
-    sat_g_wide_tile = tile;
-    return 0;
-}
-#else
+#ifdef SAT_OPERAND_F16
 // entry of the fp16 build for the bf16 build's dispatcher (GemmArgs differs only in the pointer element type)
 int sat_launch_gemm_f16(int epi, const void* gemm_args, hipStream_t stream) {
     return f16::sat_launch_gemm(epi, *static_cast<const f16::GemmArgs*>(gemm_args), stream);

@@ -1286,7 +1286,7 @@ bool SAT_OPNS::sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
     // fp32-output GEMMs with a short reduction (to_out, cross to_out: K = 1536) spend a third of their time in the residual
     // read-modify-write at HBM speed; persistent workgroups run those epilogues in lockstep, the 16-wave tile's independent workgroups
     // drift apart and overlap them with other tiles' main loops: measured 111 us against 122 at 8 prompts (profiles/r03_ph8_streamk.txt)
-    if ((epi == EPI_F32 || epi == EPI_RESID) && a.K < 4096 && sat_g_wide_tile != 81) return false;          // (81: sat_gemm_set_wide_tile, A/B)
+    if ((epi == EPI_F32 || epi == EPI_RESID) && a.K < 4096 && sat_wide_tile_of(a.variant) != 81) return false;          // (81: sat_dit_cfg.tile_policy, A/B)
     if (epi == EPI_HEADS) return (a.heads.heads * 64) % 256 == 0;
     return true;
 }

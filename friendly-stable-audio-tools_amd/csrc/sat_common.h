@@ -351,7 +351,16 @@ using namespace SAT_OPNS;
 int sat_launch_gemm_f16(int epi, const void* gemm_args, hipStream_t stream);
 int sat_launch_attention_f16(const void* q, const void* k, const void* vt, void* out, int b, int h, int kvh, int sq, int sk, int sq_pad,
                              int sk_pad, hipStream_t s, unsigned char* out_scales, float q_scale);
-extern int sat_g_wide_tile;          // sat_gemm_set_wide_tile (gemm_bf16.hip, bf16 build)
+// Tile policy of a launch: bits 24-26 of GemmArgs::variant (sat_dit_cfg.tile_policy puts them there for every GEMM of a plan; the
+// unit-level entry points leave them 0).  0 = the default (80); the others are A/B measurement switches:
+//   22: the 16-wave 2-stage 256 x 256 tile of rounds 1-2 instead of the 8-phase kernel
+//   81: the 8-phase kernel also for the fp32-output GEMMs with K < 4096        82: no two-K-group 128 x 128 tile
+#define SAT_TILE_POLICY_SHIFT 24
+static inline int sat_tile_policy_bits(int policy) { return (policy == 22 ? 1 : policy == 81 ? 2 : policy == 82 ? 3 : 0) << SAT_TILE_POLICY_SHIFT; }
+static inline int sat_wide_tile_of(int variant) {
+    const int p = (variant >> SAT_TILE_POLICY_SHIFT) & 7;
+    return p == 1 ? 22 : p == 2 ? 81 : p == 3 ? 82 : 80;
+}
 
 // f16 (last argument of the launchers below): the 16-bit output is IEEE fp16 (saturating) instead of bf16
 int sat_launch_layernorm(const float* x, const float* gamma, const float* beta, op_t* y, int m, int d, hipStream_t s, int f16 = 0);

@@ -18,10 +18,14 @@ class SatError(RuntimeError):
     pass
 
 
+ABI_VERSION = 5          # include/sat_hip.h: sat_version()
+
+
 class SatDitCfg(Structure):
     _fields_ = [("io_channels", c_int32), ("embed_dim", c_int32), ("depth", c_int32), ("num_heads", c_int32),
                 ("cond_token_dim", c_int32), ("cond_embed_dim", c_int32), ("global_cond_dim", c_int32),
-                ("max_seq_len", c_int32), ("adaln", c_int32), ("gemm_dtype", c_int32), ("fp8_families", c_int32), ("ln_fold", c_int32)]
+                ("max_seq_len", c_int32), ("adaln", c_int32), ("gemm_dtype", c_int32), ("fp8_families", c_int32), ("ln_fold", c_int32),
+                ("cross_attention", c_int32), ("tile_policy", c_int32)]
 
 
 class SatT5Cfg(Structure):
@@ -76,8 +80,6 @@ _SIGNATURES = {
     "sat_float_to_int16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "sat_layernorm_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sat_cast_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
-    "sat_gemm_set_wide_tile": (c_int32, [c_int32]),
-    "sat_set_cross_attention_fusion": (c_int32, [c_int32]),
     "sat_cross_attention_fused_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                                  c_int32, c_int32, c_void_p]),
     "sat_resample_sinc": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
@@ -135,6 +137,9 @@ def lib():
             fn = getattr(handle, name)   # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
+        if handle.sat_version() != ABI_VERSION:          # the cfg structs below mirror exactly one version of include/sat_hip.h
+            raise SatError(f"{LIB_PATH} reports ABI version {handle.sat_version()}, this package binds version {ABI_VERSION}: rebuild "
+                           "(python __graft_entry__.py build)")
         _lib = handle
     return _lib
 

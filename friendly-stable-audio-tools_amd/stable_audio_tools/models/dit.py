@@ -76,6 +76,26 @@ class DiffusionTransformer(nn.Module):
         self._ctx_key = None
         self.gemm_dtype = _config.default_gemm_dtype()
         self.layernorm_fusion = True
+        self.cross_attention_fusion = True
+        self.tile_policy = 0
+
+    def set_cross_attention_fusion(self, on: bool):
+        """Build extension, A/B switch: the to_q projection + cross-attention core as ONE launch where it applies (one prompt; the default) or
+        always as two kernels (``sat_dit_cfg.cross_attention``).  Per model; rebuilds the plan on next use."""
+        if bool(on) != self.cross_attention_fusion:
+            self.cross_attention_fusion = bool(on)
+            self._plan_version = None
+        return self
+
+    def set_tile_policy(self, policy: int):
+        """Build extension, A/B measurement switch (``sat_dit_cfg.tile_policy``): 0 / 80 the measured tile choice, 22 the 16-wave 256 x 256 tile
+        of rounds 1-2, 81 the 8-phase kernel for every fp32-output GEMM, 82 no two-K-group 128 x 128 tile.  Per model; rebuilds the plan."""
+        if policy not in (0, 22, 80, 81, 82):
+            raise ValueError("tile_policy must be 0, 22, 80, 81 or 82")
+        if policy != self.tile_policy:
+            self.tile_policy = policy
+            self._plan_version = None
+        return self
 
     def set_layernorm_fusion(self, on: bool):
         """Build extension: run the LayerNorms of the blocks (transformer.py:692-700) inside the epilogues of the GEMMs either side of
@@ -124,7 +144,7 @@ class DiffusionTransformer(nn.Module):
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
                              self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
                              1 if self.global_cond_type == "adaLN" else 0, GEMM_DTYPES[self.gemm_dtype], FP8_FAMILIES.get(self.gemm_dtype, 0),
-                             1 if self.layernorm_fusion else 0)
+                             1 if self.layernorm_fusion else 0, 0 if self.cross_attention_fusion else 1, self.tile_policy)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)))
         keep = []

@@ -31,6 +31,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported (tests/test_cabi.py). */
+#pragma GCC visibility push(default)
 
 #define SAT_OK 0
 #define SAT_E_INVALID (-1)      /* bad argument (NULL, shape, size) */
@@ -41,6 +43,8 @@ extern "C" {
 
 typedef void* sat_stream_t;     /* hipStream_t */
 
+/* ABI version: 5.  A loader MUST check it (stable_audio_tools/_hip.py does): the cfg structs grow at the END between versions, and an older
+ * caller's struct would leave the new fields uninitialised. */
 int sat_version(void);
 const char* sat_last_error(void);
 
@@ -111,6 +115,13 @@ typedef struct sat_dit_cfg {
                                   bf16(gamma.W) and finishes the normalisation on its fp32 accumulators.  Same arithmetic up to WHERE
                                   the one bf16 rounding of the activation happens (before instead of after the normalisation);
                                   0: three LayerNorm kernels per block */
+    /* ---- version 5: the two A/B switches that used to be process-wide setters (sat_set_cross_attention_fusion, sat_gemm_set_wide_tile) are
+     * per plan -- "distinct plans are independent" now also holds for them.  Appended at the END of the struct; sat_version() == 5. */
+    int32_t cross_attention;   /* 0 (default): to_q projection + cross-attention core in ONE launch where the projection's 128 x 64 tiles fit one
+                                  round of workgroups (one prompt; transformer.py:430-437 + 496-536), two kernels otherwise; 1: always two kernels */
+    int32_t tile_policy;       /* 0 / 80 (default): the measured tile choice; A/B measurement switches: 22 = the 16-wave 256 x 256 tile of rounds
+                                  1-2 instead of the 8-phase kernel, 81 = the 8-phase kernel also for fp32-output GEMMs with K < 4096, 82 = no
+                                  two-K-group 128 x 128 tile */
 } sat_dit_cfg;
 
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
@@ -291,12 +302,6 @@ int sat_gemm_f32_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t varian
 int sat_gemm_bf16_f32_ws(const void* a_bf16_dev, const void* w_bf16_dev, const float* bias_dev, float* c_dev,
                          int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t variant, void* ws_dev, size_t ws_bytes,
                          sat_stream_t stream);
-/* Which kernel serves the 256 x 256 tile of the bf16 GEMMs: 80 (default) = 8 waves, 128 x 64 per wave, 8-phase schedule with a
- * counted-vmcnt LDS-DMA ring of half-tiles (csrc/gemm_ph8.hip); 22 = the 16-wave 2-stage tile of rounds 1-2 (A/B measurements); 81 = 80, also for
- * the fp32-output GEMMs with K < 4096 that the default keeps on the 16-wave tile (A/B: 34.27 vs 34.42 ms per CFG step at 8 prompts); 82 = 80
- * without the two-K-group 128 x 128 tile of the one-round fp32-output GEMMs (A/B).  e4m3
- * operands: the LayerNorm-fed GEMMs (heads / SwiGLU epilogues) follow this switch too, the MXFP8-operand GEMMs always run tile 22.  Process-wide; not a per-call argument because the tile is chosen inside the plan. */
-int sat_gemm_set_wide_tile(int32_t tile);
 /* SwiGLU GEMM (models/transformer.py:211-235): h[m,n/2] (bf16) = (A W_v^T + b_v) * silu(A W_g^T + b_g)
  * with W [n,k] in the REFERENCE row order (value rows then gate rows); re-packed internally
  * into wpack_dev [n,k] bf16 and bpack_dev [n] fp32 scratch. */
@@ -327,8 +332,6 @@ int sat_attention_prescaled_bf16(const void* q_dev, const void* k_dev, const voi
  * sat_attention_bf16 with sk + 3 <= 192 keys (they are staged in LDS as a whole); GQA d/64 over kvh.  Q never reaches memory. */
 int sat_cross_attention_fused_bf16(const void* a_bf16_dev, const void* wq_bf16_dev, const void* k_dev, const void* vt_dev, void* out_dev,
                                    int32_t b, int32_t s, int32_t d, int32_t kvh, int32_t sk, int32_t sk_pad, sat_stream_t stream);
-/* A/B switch of that fusion inside the plans (default on); process-wide like sat_gemm_set_wide_tile. */
-int sat_set_cross_attention_fusion(int32_t on);
 /* Fused QKV projection + partial RoPE + head split (models/transformer.py:430-452):
  * a [b*s, d] bf16, w_qkv [3d, d] bf16 -> q,k [b,h,s_pad,64], vt [b,h,64,s_pad] bf16 (k / vt in the key-side
  * layout of sat_attention_bf16; s_pad % 128 == 0, s_pad >= s + 3).
@@ -463,6 +466,7 @@ int sat_number_embed(const float* values_dev, int32_t count, float min_val, floa
                      int32_t half_dim, const float* linear_w_dev, const float* linear_b_dev, int32_t features, float* out_dev,
                      sat_stream_t stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

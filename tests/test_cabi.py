@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libsat_hip.so does not export {name}"
     assert sorted(_hip.exported_symbols()) == declared, "ctypes signature table and header disagree"
-    assert lib.sat_version() >= 1
+    assert lib.sat_version() == _hip.ABI_VERSION == 5
 
 
 def test_library_has_no_torch_dependency():
@@ -55,10 +55,31 @@ def test_argument_validation_without_gpu():
     ocfg.is_decoder, ocfg.io_channels, ocfg.channels, ocfg.latent_dim, ocfg.n_blocks = 1, 2, 100, 64, 2
     assert lib.sat_oobleck_plan_create(ctypes.byref(ocfg), ctypes.byref(plan)) == -2
     assert lib.sat_dpmpp3m_update(None, None, None, None, None, 0.0, 1.0, 0.0, 0.0, 0.0, 10, None) == -1
-    # the A/B switches of the tile policy take their documented values only (and leave the default behind)
-    for tile in (22, 81, 82, 80):
-        assert lib.sat_gemm_set_wide_tile(tile) == 0
-    assert lib.sat_gemm_set_wide_tile(7) == -1 and b"sat_gemm_set_wide_tile" in lib.sat_last_error()
+    # the A/B switches are per plan (sat_dit_cfg, ABI version 5) and take their documented values only
+    for tile, want in ((22, 0), (81, 0), (82, 0), (80, 0), (0, 0), (7, -1)):
+        cfg = _hip.SatDitCfg(64, 256, 2, 4, 128, 128, 64, 128, 0, 0, 0, 1, 0, tile)
+        rc = lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan))
+        assert rc == want, (tile, rc, lib.sat_last_error())
+        if rc == 0:
+            lib.sat_dit_plan_destroy(plan)
+    assert b"tile_policy" in lib.sat_last_error()
+    cfg = _hip.SatDitCfg(64, 256, 2, 4, 128, 128, 64, 128, 0, 0, 0, 1, 2, 0)
+    assert lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)) == -1 and b"cross_attention" in lib.sat_last_error()
+    # a struct laid out for an older header (fp8_families where ln_fold used to be) fails loudly instead of silently mis-reading it
+    cfg = _hip.SatDitCfg(64, 256, 2, 4, 128, 128, 64, 128, 0, 0, 1, 0)
+    assert lib.sat_dit_plan_create(ctypes.byref(cfg), ctypes.byref(plan)) == -1 and b"fp8_families" in lib.sat_last_error()
+
+
+def test_library_exports_nothing_but_the_header():
+    """built with -fvisibility=hidden, the dynamic symbol table holds the sat_* functions of include/sat_hip.h and nothing
+    else of ours -- no mangled launchers, kernel stubs or template instantiations (106 of them in round 4)."""
+    from stable_audio_tools import _hip
+    out = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    ours = sorted(n for n in names if n.startswith("sat_"))
+    assert ours == _declared_symbols(), sorted(set(ours) ^ set(_declared_symbols()))
+    other = [n for n in names if not n.startswith("sat_") and n not in ("_init", "_fini", "__bss_start", "_edata", "_end")]
+    assert not other, f"{len(other)} non-sat_ dynamic symbols exported, e.g. {other[:5]}"
 
 
 def test_product_has_no_cpu_path():

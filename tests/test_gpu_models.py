@@ -61,7 +61,7 @@ def _inputs(b, t_len, cond_dim, seed=1):
 
 def test_cross_attention_fusion_on_off(dev, small_dit):
     """to_q + cross-attention as ONE launch (the plan's default where the projection's 128 x 64 tiles fit one round) against the same plan
-    with two kernels (sat_set_cross_attention_fusion(0)).  Both keep Q pre-scaled with one bf16 rounding and run the same per-wave step on
+    with two kernels (sat_dit_cfg.cross_attention = 1, per plan).  Both keep Q pre-scaled with one bf16 rounding and run the same per-wave step on
     the same K / V^T tiles (attn_core.h).  One sequence: a wave holds the same 32 queries either way, so the outputs are bit-identical.
     Three sequences of 78 rows: the fused tiles straddle sequences (second pass on the next sequence's keys) and group the queries
     into waves differently -- the wave-wide "redo this block" decision may differ, the results agree to rounding."""
@@ -74,10 +74,10 @@ def test_cross_attention_fusion_on_off(dev, small_dit):
         run = lambda: model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0).cpu()
         fused = run()
         try:
-            _hip.check(_hip.lib().sat_set_cross_attention_fusion(0))
+            model.model.model.set_cross_attention_fusion(False)
             separate = run()
         finally:
-            _hip.check(_hip.lib().sat_set_cross_attention_fusion(1))
+            model.model.model.set_cross_attention_fusion(True)
         assert torch.isfinite(fused).all()
         assert torch.equal(fused, run()), "the fused path is not repeatable"
         if b == 1:

@@ -458,9 +458,11 @@ def full_model():
         res = {t: [] for t in tiles}
         for _ in range(4):
             for t in tiles:
-                _hip.check(_hip.lib().sat_gemm_set_wide_tile(t))
+                dit.set_tile_policy(t)          # (per plan since ABI version 5: the plan is rebuilt and the context re-prepared)
+                dit.prepare_generation(c, g, 7.0)
                 res[t].append(timeit(lambda: dit.denoise(x, 3.0, cfg_scale=7.0, out=out), iters=6, warm=2))
-        _hip.check(_hip.lib().sat_gemm_set_wide_tile(80))
+        dit.set_tile_policy(80)
+        dit.prepare_generation(c, g, 7.0)
         print("wide-tile A/B, DiT CFG step ms: " + " | ".join(f"{t}: {statistics.median(v):.3f} (min {min(v):.3f})" for t, v in res.items()), flush=True)
     print("denoise finite:", torch.isfinite(out).all().item(), "std", out.std().item())
     z = torch.randn(b, 64, 1024, device=dev)
