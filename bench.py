@@ -276,7 +276,9 @@ def main():
     cond = conditioning(model, prompt_ids, dev)
     dit = model.model.model
     dit.set_gemm_dtype(args.dtype)
-    model.pretransform.model.set_gemm_dtype("fp16" if args.dtype == "fp16" else "bf16")        # the codec follows (fp16 = the reference's model_half)
+    from stable_audio_tools import _config
+    codec_dtype = _config.codec_gemm_dtype(args.dtype)        # one rule, shared with generate.py (fp16 = the reference's model_half)
+    model.pretransform.model.set_gemm_dtype(codec_dtype)
     dit.set_layernorm_fusion(args.layernorm == "fused")
     dit.set_cross_attention_fusion(args.cross_attention == "fused")
 
@@ -330,7 +332,7 @@ def main():
                                     f"{args.batch} prompt(s)/GPU x 47.55 s, 100 DPM-Solver++(3M) SDE steps") if args.workload == "sa_open" else
                                    ("Stable Audio 2.0 shape (24 layers, D=1536, S=6145, CFG 7) audio-to-audio: Oobleck encode of 285.3 s init audio + "
                                     f"100 DPM-Solver++(3M) SDE steps from sigma 7 + decode, {args.batch} prompt(s)/GPU"), "prompts_per_gpu": args.batch,
-                       "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "layernorm": args.layernorm, "cross_attention": args.cross_attention, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
+                       "codec_dtype": codec_dtype, "sampler_steps": DIT_STEPS, "cfg_scale": CFG_SCALE, "layernorm": args.layernorm, "cross_attention": args.cross_attention, "sample_size": SAMPLE_SIZE, "parallelism": f"dp{world} (rank-strided prompts, one all-gather)"},
             "roofline": {"bound": "mfma", "kernel": f"FFN-in SwiGLU GEMM M={m.value} N={n.value} K={k.value} ({args.dtype} MFMA, fp32 acc)", "achieved": achieved,
                          "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak, "traffic": traffic,
                          "traffic_source": traffic_source, "avg_launch_us": avg_ms * 1e3, "launches_timed": cnt.value},

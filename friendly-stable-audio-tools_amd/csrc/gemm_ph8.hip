@@ -659,35 +659,45 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         if constexpr (FP8 != 0) return fmaf(a * rstd, c1, c2);
         else return rstd * (a - mean * c1) + c2;
     };
-    // everything a K-range needs before its main loop: LayerNorm loads, DMA addresses, half-tiles 0..6 in flight, LayerNorm constants
-    auto prepare = [&](const Seg& s, int lb) {
+    // Everything a K-range needs before its main loop, in two steps.  ISSUE: the loads of the LayerNorm partial sums / channel constants, the
+    // DMA addresses, half-tiles 0..6 in flight.  FINISH: (mean, 1 / std) and the constants into LDS.  For the FIRST range of a workgroup the
+    // two run back to back; inside the persistent loop ISSUE runs in front of the current range's epilogue and -- LN_DEFER -- FINISH behind it,
+    // at the top of the next range: the round trip of the partial-sum loads (1.2-1.5 us of the 1.7 us "prepare-next" that was left after the
+    // LDS accesses went out of the compiler's sight, profiles/r05_ph8_timeline.txt) then hides behind the epilogue instead of in front of it.
+    // The loaded values (28 registers) stay live across the epilogue: affordable next to the SwiGLU epilogue, not next to the heads one.
+    struct LnPre {
+        float2 lnp[12];
+        f32x4_t lncst;
+        float a_sc;
+    };
+    constexpr bool LN_DEFER = LN_CONS && EPI == EPI_SWIGLU;
+    auto prepare_issue = [&](const Seg& s, [[maybe_unused]] LnPre& st) {
         int tid = tid_;
         asm volatile("" : "+v"(tid));            // (keeps this block's address arithmetic inside the persistent loop, see the epilogue)
-        [[maybe_unused]] float2 lnp[12];         // local: nothing of this is live across the main loop
-        [[maybe_unused]] f32x4_t lncst = {0.f, 0.f, 0.f, 0.f};
-        [[maybe_unused]] float a_sc = 1.f;
         [[maybe_unused]] const int ct = NT - 1 - tid;        // the last BN / 2 threads bring in the channel constants, 16 bytes each
         if constexpr (LN_CONS) {
+            st.lncst = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            st.a_sc = 1.f;
             if (ln_fast) {
                 int m = s.m0 + (tid >> 1);
                 m = m < M ? m : M - 1;
                 const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)m * np + (tid & 1);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) lnp[i] = pp[2 * i];
+                for (int i = 0; i < 12; ++i) st.lnp[i] = pp[2 * i];
             } else {
 #pragma unroll
-                for (int i = 0; i < 12; ++i) lnp[i] = make_float2(0.f, 0.f);
+                for (int i = 0; i < 12; ++i) st.lnp[i] = make_float2(0.f, 0.f);
             }
             if (ct < BN / 2) {
                 const bool first = ct < BN / 4;
                 const float* src = ln_fold ? (first ? g.ln_c1 + s.n0 + ct * 4 : g.ln_c2 + s.n0 + (ct - BN / 4) * 4)
                                            : (first ? (FP8 != 0 ? g.w_scale + s.n0 + ct * 4 : nullptr)
                                                     : (g.bias ? g.bias + s.n0 + (ct - BN / 4) * 4 : nullptr));
-                if (src) lncst = *reinterpret_cast<const f32x4_t*>(src);
+                if (src) st.lncst = *reinterpret_cast<const f32x4_t*>(src);
             }
             if constexpr (FP8 != 0) {
                 const int m = s.m0 + (tid >> 1);
-                a_sc = g.a_scale[m < M ? m : M - 1];
+                st.a_sc = g.a_scale[m < M ? m : M - 1];
             }
         }
         setup_dma(s);
@@ -697,15 +707,20 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 #pragma unroll
         for (int j = 0; j < ((PH2 && PH2V != 2) ? 2 : 3); ++j) issue(j, 1, s.kt0 + 1);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    auto prepare_finish = [&](const Seg& s, int lb, [[maybe_unused]] LnPre& st) {
         if constexpr (LN_CONS) {
+            int tid = tid_;
+            asm volatile("" : "+v"(tid));
+            const int ct = NT - 1 - tid;
             float2* lnst = reinterpret_cast<float2*>(smem + RING_BYTES + lb * LN_BYTES);
             float* lnc = reinterpret_cast<float*>(smem + RING_BYTES + lb * LN_BYTES + BM * 8);
             const int r = tid >> 1, sub = tid & 1;           // two threads per row
             float sum = 0.f, sq = 0.f;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
-                sum += lnp[i].x;
-                sq += lnp[i].y;
+                sum += st.lnp[i].x;
+                sq += st.lnp[i].y;
             }
             if (ln_fold && !ln_fast) {                       // any other K: plain loop (behind the DMA pieces in the memory queue)
                 int m = s.m0 + r;
@@ -723,9 +738,9 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                 const float inv_k = 1.0f / (float)K;
                 const float mean = sum * inv_k;
                 const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
-                lds_st64(lnst + r, ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, a_sc));
+                lds_st64(lnst + r, ln_fold ? make_float2(mean, rsqrtf(var + g.ln_eps)) : make_float2(0.f, st.a_sc));
             }
-            if (ct < BN / 2) lds_st128(lnc + ct * 4, lncst);
+            if (ct < BN / 2) lds_st128(lnc + ct * 4, st.lncst);
         }
     };
 
@@ -1026,7 +1041,9 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     // same moment, only adds the delay: profiles/r03_ph8_stagger_negative.txt -- the 17-us epilogue of a 256 x 256 fp32 tile is bound
     // per CU, not by the sum.)
     int lb = 0;
-    prepare(cur, lb);
+    LnPre lnpre;
+    prepare_issue(cur, lnpre);
+    prepare_finish(cur, lb, lnpre);
     while (true) {
         {
             // fp32 output: the accumulators of a WHOLE tile start from the bias (lane (l15, q4) owns channels 16 nb + 4 q4 .. + 3 of every
@@ -1072,7 +1089,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         if constexpr (EPI == EPI_HEADS) {
             if (rows_valid && cur.tr && (g.heads.kind[cur.n0 / (g.heads.heads * 64)] & 2)) rope_prefetch(cur, rp);
         }
-        if (more) prepare(nxt, lb ^ 1);       // the ring is free: the next range's DMA latency hides behind this epilogue
+        if (more) {                           // the ring is free: the next range's DMA latency hides behind this epilogue
+            prepare_issue(nxt, lnpre);
+            if constexpr (!LN_DEFER) prepare_finish(nxt, lb ^ 1, lnpre);
+        }
         bool fin = true;
         if (EPI == EPI_F32 && !cur.whole) {           // a part of a K-split tile (fp32 output only): plain stores of the raw accumulators, the kernel
             int lane_l = lane;                            // boundary publishes them to ph8_reduce_f32_kernel
@@ -1097,6 +1117,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         if (!more) break;
         cur = nxt;
         lb ^= 1;
+        if constexpr (LN_DEFER) prepare_finish(cur, lb, lnpre);          // (published by the barrier at the top of the loop)
     }
 }
 
@@ -1158,7 +1179,9 @@ bool ph8_auto_split(const GemmArgs& a, bool epi_f32, int cus) {
 int ph8_schedule(const GemmArgs& a, int split, bool epi_f32, int bm, int bn, int wgs_per_cu, Ph8Sched& out) {
     int cus = 0;
     SAT_TRY(ph8_cus(cus));
-    const bool have_slab = a.slab != nullptr;
+    // the automatic policy only splits when the caller's slab holds one accumulator image per workgroup -- the same condition the tile score
+    // assumes (sat_gemm_ph8_splits); an undersized workspace runs the unsplit schedule.  A FORCED split (variant bit 16) keeps the hard error.
+    const bool have_slab = a.slab != nullptr && (split >= 0 || a.slab_bytes >= (size_t)cus * 65536 * sizeof(float));
     if (split < 0) split = (bm == 256 && epi_f32 && have_slab && ph8_auto_split(a, epi_f32, cus)) ? 1 : 0;
     if (bm != 256 || !epi_f32) split = 0;          // the K-split machinery (slabs, reduce kernel) is built for the 256 x 256 fp32-output tile
     Ph8Sched s{};
@@ -1356,14 +1379,18 @@ int SAT_OPNS::sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream
             if (dbg == 0 && (a.variant & 0x40000)) return launch_ph8<EPI_SWIGLU, 0, false>(a, stream);
             if (dbg == 0 && (a.variant & 0x80000)) return launch_ph8<EPI_SWIGLU, 0, true, 2>(a, stream);
 #endif
+#ifndef SAT_OPERAND_F16          // (e4m3 operands ride in the bf16 build: sat_launch_gemm rejects f16 && fp8)
             if (dbg == 0 && a.fp8) return launch_ph8<EPI_SWIGLU, 0, true, 1, 4, 4, 2>(a, stream);
+#endif
             if (dbg == 0) return launch_ph8<EPI_SWIGLU>(a, stream);
 #ifdef SAT_GEMM_EXPERIMENTS
             if (dbg == 9) return launch_ph8<EPI_SWIGLU, 9>(a, stream);
 #endif
             break;
         case EPI_HEADS:
+#ifndef SAT_OPERAND_F16
             if (dbg == 0 && a.fp8) return launch_ph8<EPI_HEADS, 0, true, 1, 4, 4, 2>(a, stream);
+#endif
             if (dbg == 0) return launch_ph8<EPI_HEADS>(a, stream);
 #ifdef SAT_GEMM_EXPERIMENTS
             if (dbg == 9) return launch_ph8<EPI_HEADS, 9>(a, stream);

@@ -133,9 +133,10 @@ def main():
     sample_rate, sample_size = model_config["sample_rate"], model_config["sample_size"]
     model = model.to(device).eval()
     if args.gemm_dtype is not None:
+        from stable_audio_tools import _config
         model.model.model.set_gemm_dtype(args.gemm_dtype)
-        if args.gemm_dtype in ("fp16", "bf16") and model.pretransform is not None:
-            model.pretransform.model.set_gemm_dtype(args.gemm_dtype)
+        if model.pretransform is not None:          # the codec follows by ONE rule (same in bench.py): fp16 with fp16, bf16 with bf16 and the e4m3 modes
+            model.pretransform.model.set_gemm_dtype(_config.codec_gemm_dtype(args.gemm_dtype))
     cond_dim = model_config["model"]["conditioning"]["cond_dim"]
     if model.conditioner is not None:
         model.conditioner.set_device(str(device))      # what generate_diffusion_cond does first (generation.py:125); needed by encoders here

@@ -27,3 +27,10 @@ def set_default_gemm_dtype(dtype: str) -> str:
         raise ValueError(f"default gemm dtype must be one of {_CHOICES}")
     prev, _default = _default, dtype
     return prev
+
+
+def codec_gemm_dtype(dit_gemm_dtype: str) -> str:
+    """The operand format the Oobleck codec runs in next to a DiT in ``dit_gemm_dtype`` -- ONE rule for generate.py, bench.py and the tests:
+    "fp16" -> "fp16" (the reference's ``model_half``), "bf16" -> "bf16", the e4m3 modes -> "bf16" (what their description promises: everything
+    that is not e4m3 stays bf16), "fp32x" -> "fp16" (there is no fp32 codec build; the verification mode is about the DiT)."""
+    return {"fp16": "fp16", "bf16": "bf16", "fp8": "bf16", "fp8-all": "bf16", "fp32x": "fp16"}[dit_gemm_dtype]

@@ -27,7 +27,13 @@ class Pretransform(nn.Module):
 
 class AutoencoderPretransform(Pretransform):
     """Wraps an ``AudioAutoencoder``.  ``scale`` divides the latents on the way in and multiplies them on the way out
-    (pretransforms.py:62, :65); ``chunked`` / ``iterate_batch`` are forwarded to the codec's ``encode_audio`` / ``decode_audio``."""
+    (pretransforms.py:62, :65); ``chunked`` / ``iterate_batch`` are forwarded to the codec's ``encode_audio`` / ``decode_audio``.
+
+    Deviation from the reference, stated: there ``model_half=False`` runs the codec in fp32 (pretransforms.py:39-59).  This build has no fp32
+    codec kernels -- the convolutions always take 16-bit operands with fp32 accumulation (0.7e-3 of the reference's fp32 output in fp16, 6-8e-3
+    in bf16, tests/test_gpu_models.py) -- so ``model_half`` only PINS fp16; with ``model_half=False`` the codec runs in the package default
+    (fp16 unless SAT_GEMM_DTYPE / set_default_gemm_dtype / set_gemm_dtype say bf16).  fp16 conversions saturate at +-65504 instead of
+    producing inf as the reference's fp16 path would: with a checkpoint whose activations leave that range use ``set_gemm_dtype("bf16")``."""
 
     def __init__(self, model, scale=1.0, model_half=False, iterate_batch=False, chunked=False):
         bottleneck = model.bottleneck

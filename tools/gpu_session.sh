@@ -5,23 +5,30 @@
 #   stats [bench.py args]   rocprofv3 --kernel-trace --stats of bench.py     -> gpurun_out/${TAG}_kernel_stats.csv + _summary.md
 #   pmc                     FETCH_SIZE / WRITE_SIZE / SQ counter passes of tools/gpu_probe.py full (separate passes, no traces)
 #   probe <sections...>     tools/ph8_probe.py sections with the experiments build
-# TAG (default r04) names the outputs.
+#   both                    the -m gpu suite under BOTH operand formats (SAT_TEST_DTYPE=fp16 = the package default, then bf16), prints shown (-s)
+# TAG (default r05) names the outputs.
 cd "$(dirname "$0")/.."
 R=$PWD
 mkdir -p gpurun_out
 export PYTHONPATH=$R/friendly-stable-audio-tools_amd:$PYTHONPATH
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 stage=$1; shift
 case $stage in
   pytest)
     timeout 2400 python -m pytest tests -m gpu -q -rf --no-header -p no:cacheprovider "$@" > gpurun_out/${TAG}_pytest.log 2>&1
     echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -5 gpurun_out/${TAG}_pytest.log ;;
+  both)
+    for fmt in fp16 bf16; do
+      SAT_TEST_DTYPE=$fmt timeout 2400 python -m pytest tests -m gpu -q -s -rf --no-header -p no:cacheprovider "$@" > gpurun_out/${TAG}_pytest_$fmt.log 2>&1
+      echo "pytest[$fmt] rc=$?" >> gpurun_out/${TAG}_pytest_$fmt.log; tail -3 gpurun_out/${TAG}_pytest_$fmt.log
+    done ;;
   bench)
     timeout 900 python bench.py "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cut -c1-400 gpurun_out/${TAG}_bench.json ;;
   stats)
     cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$TAG
     timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_stats_bench.json 2> $R/gpurun_out/${TAG}_stats.err
     f=$(find /tmp/prof_$TAG -name '*kernel_stats.csv' | head -1); cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv
+    t=$(find /tmp/prof_$TAG -name '*kernel_trace.csv' | head -1); python $R/tools/trace_blocks.py "$t" > $R/gpurun_out/${TAG}_block_trace.txt 2>&1
     python $R/tools/stats_summary.py $R/gpurun_out/${TAG}_kernel_stats.csv 2 "$TAG: bench.py $*" > $R/gpurun_out/${TAG}_kernel_stats_summary.md; head -16 $R/gpurun_out/${TAG}_kernel_stats_summary.md | cut -c1-180 ;;
   pmc)
     cd /tmp; export TMPDIR=/tmp
