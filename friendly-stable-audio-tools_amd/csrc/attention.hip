@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const op_t* __restric
 static unsigned long long* g_attn_dbg = nullptr;
 #endif
 #if defined(SAT_GEMM_EXPERIMENTS) && !defined(SAT_OPERAND_F16)
-extern "C" int sat_attention_dbg_read(unsigned long long* out4) {
+extern "C" __attribute__((visibility("default"))) int sat_attention_dbg_read(unsigned long long* out4) {
     SAT_CHECK_ARG(g_attn_dbg, SAT_E_INVALID, "no attention counters");
     SAT_HIP(hipDeviceSynchronize());
     SAT_HIP(hipMemcpy(out4, g_attn_dbg, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -1315,7 +1315,7 @@ bool SAT_OPNS::sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
 }
 
 #if defined(SAT_GEMM_EXPERIMENTS) && !defined(SAT_OPERAND_F16)
-extern "C" int sat_gemm_ph8_timestamps(unsigned long long* out_host) {
+extern "C" __attribute__((visibility("default"))) int sat_gemm_ph8_timestamps(unsigned long long* out_host) {
     SAT_CHECK_ARG(g_ts_buf, SAT_E_INVALID, "no timestamps recorded");
     SAT_HIP(hipDeviceSynchronize());
     SAT_HIP(hipMemcpy(out_host, g_ts_buf, 256 * 4 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));

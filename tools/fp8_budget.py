@@ -1,7 +1,9 @@
 """Developer experiment (CPU, oracle only): the error budget of BASELINE config 5.  The full-size 12-step CFG-7
 trajectory of tests/golden/traj_full.npz is re-run with e4m3 operands in ONE subset of the block's GEMM families at a time
 (oracle.dit.Fp8Rounding(families=...)) and compared with the fp32 trajectory of the fixture after 4 / 8 / 12 steps.
-usage: python tools/fp8_budget.py qkv cq ff1 ff2 o qkv+ff1 qkv+cq+ff1 ...      (one run per argument, ~7 min each on 8 cores)"""
+usage: python tools/fp8_budget.py qkv cq ff1 ff2 o qkv+ff1 qkv+cq+ff1 ...      (one run per argument, ~7 min each on 8 cores)
+Round 5: a family name with the suffix "@mx" quantises its LayerNorm-fed ACTIVATION with MX block scales (one power-of-two
+scale per 32 channels, oracle.dit.mxfp8_blocks) instead of one scale per token, "@mxw" the weights as well: `qkv@mx`, `qkv@mxw`, `qkv@mx+cq+ff1+ff2`."""
 import os
 import sys
 import time
@@ -30,8 +32,19 @@ def main():
     gold = cases.load("traj_full")
     sig = osamp.get_sigmas_polyexponential(tj["steps"], tj["sigma_min"], tj["sigma_max"], 1.0)
     for arg in sys.argv[1:]:
-        fams = tuple(arg.split("+"))
-        rnd = odit.Fp8Rounding(families=fams)
+        spec = arg.split("+")
+        fams = tuple(f.split("@")[0] for f in spec)
+        mx_act = {f.split("@")[0] for f in spec if "@mx" in f}
+        mx_w = {f.split("@")[0] for f in spec if f.endswith("@mxw")}
+
+        class Rnd(odit.Fp8Rounding):
+            def act(self, x, fam="qkv"):
+                return odit.mxfp8_blocks(x) if fam in mx_act else super().act(x, fam)
+
+            def weight(self, w, fam="qkv"):
+                return odit.mxfp8_blocks(w) if fam in mx_w else super().weight(w, fam)
+
+        rnd = Rnd(families=fams)
         snaps = {}
 
         def cb(info, snaps=snaps):
