@@ -305,8 +305,9 @@ def main():
         # HBM traffic of the dominant kernel cannot be measured inside a timed run (PMC passes serialise the kernels): it is the
         # figure of the latest committed rocprofv3 --pmc pass of this same command (FETCH_SIZE x2 + WRITE_SIZE, separate passes)
         traffic, traffic_source = None, None
-        for tname in ("r04_ffn_traffic.json", "r03_ffn_traffic.json", "r02_ffn_traffic.json", "r01_ffn_traffic.json"):
-            tpath = os.path.join(ROOT, "profiles", tname)
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_ffn_traffic.json")), reverse=True):          # newest round first
+            tname = os.path.basename(tpath)
             if os.path.exists(tpath) and args.batch == 1 and args.dtype in ("bf16", "fp16") and args.workload == "sa_open":
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 traffic_source = f"profiles/{tname} (rocprofv3 --pmc passes of this command, not measured in this run)"

@@ -1063,6 +1063,15 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = b0[j];
         }
+        // (materialised HERE: left to itself the compiler turns the initialisation into 64 register moves behind the barrier, in front of the
+        // first fragment reads of the main loop; in front of the wait they overlap with the landing of the range's first tiles and the previous
+        // epilogue's stores)
+        if constexpr (EPI != EPI_HEADS) {          // (the heads kernel has no registers to spare for it: it spills)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+        }
         // the range's first tiles have landed (and the previous epilogue's stores are out); LayerNorm constants are visible
         wait_vmcnt<0>();
         wait_lgkmcnt<0>();
