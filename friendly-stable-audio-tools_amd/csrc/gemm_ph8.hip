@@ -839,7 +839,11 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             lds_wait(c1v[0], c1v[1], c1g[0], c1g[1], c2v[0], c2v[1], c2g[0], c2g[1]);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) lds_tie(stv[mb]);
-            op_t* __restrict__ hbase = g.H + (ncol0 >> 1) + q4 * 8;
+            // The 16-bit output goes through a buffer descriptor whose range ends at row M: rows beyond it are dropped by the hardware, the
+            // store is UNCONDITIONAL -- so a wave issues exactly MB vector-memory operations behind the next range's DMA prologue, and the
+            // wait at the top of that range can be counted (EPI_STORES): it no longer waits for these stores to be acknowledged.
+            const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)g.H, 0, (int)((unsigned)M * (unsigned)ldh * 2u), 0x00020000);
+            const int hcol = (ncol0 >> 1) + q4 * 8;
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int m = mrow0 + mb * 16;
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         continue;
                     }
                 }
-                if (m < M) *reinterpret_cast<u32x4*>(hbase + (size_t)m * ldh) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(ph8_u32x4{pk[0], pk[1], pk[2], pk[3]}, rsH, (m * ldh + hcol) * 2, 0, 0);
             }
         } else {   // EPI_HEADS: split into heads, LayerNorm fold, partial RoPE on d < 32 (transformer.py:158-183, 438-452)
             const HeadsEpi& he = g.heads;
@@ -1041,6 +1045,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     // same moment, only adds the delay: profiles/r03_ph8_stagger_negative.txt -- the 17-us epilogue of a 256 x 256 fp32 tile is bound
     // per CU, not by the sum.)
     int lb = 0;
+    // vector-memory operations a wave issues between a range's DMA prologue and the top of that range, when they are a constant: the MB
+    // unconditional stores of the SwiGLU epilogue (16-bit output; the e4m3 build writes a data-dependent mix).  -1: not a constant.
+    constexpr int EPI_STORES = (EPI == EPI_SWIGLU && FP8 == 0 && DBG == 0 && PH2 && PH2V == 1) ? MB : -1;
+    [[maybe_unused]] bool stores_behind = false;
     LnPre lnpre;
     prepare_issue(cur, lnpre);
     prepare_finish(cur, lb, lnpre);
@@ -1072,8 +1080,17 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
         }
-        // the range's first tiles have landed (and the previous epilogue's stores are out); LayerNorm constants are visible
-        wait_vmcnt<0>();
+        // This wave's pieces of W-lo, A-lo, W-hi of the range's first K-tile have landed (the barrier covers the other waves'); LayerNorm
+        // constants are visible.  The prologue is 12 LDS-DMA instructions per wave and phase A's own vmcnt(8) covers the rest of it, so the
+        // six youngest may stay in flight -- and where the epilogue in between issued a KNOWN number of stores (EPI_STORES) those stay in
+        // flight too: the wait used to be vmcnt(0), i.e. every store of the previous epilogue acknowledged before the next main loop starts
+        // (the 1.9 us between two ranges in profiles/r05_ph8_timeline.txt).
+        if constexpr (EPI_STORES >= 0) {
+            if (stores_behind) wait_vmcnt<6 + (EPI_STORES >= 0 ? EPI_STORES : 0)>();
+            else wait_vmcnt<6>();
+        } else {
+            wait_vmcnt<0>();
+        }
         wait_lgkmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if constexpr (DBG == 2) {       // ablation: fragments are read once
@@ -1115,6 +1132,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         }
         if constexpr (DBG == 9) t2 = __builtin_amdgcn_s_memrealtime();
         if (fin && rows_valid) epilogue(cur, lb, rp, more);
+        stores_behind = fin && rows_valid;
         if constexpr (DBG == 9) {
             if (tid_ == 0 && ts_n < 4) {
                 unsigned long long* o = ts + ((size_t)blockIdx.x * 4 + ts_n) * 8;
@@ -1275,6 +1293,8 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
     SAT_CHECK_ARG((uint64_t)a.M * (uint64_t)a.K * 2u < (1ull << 31), SAT_E_UNSUPPORTED, "gemm(8-phase): A larger than 2 GiB");
     if constexpr (EPI == EPI_F32)         // the epilogue addresses C / xb / ln_part through buffer descriptors with 32-bit byte offsets
         SAT_CHECK_ARG(((uint64_t)a.M + 256) * (uint64_t)a.ldc * 4u < (1ull << 31) && a.ldc >= a.N, SAT_E_UNSUPPORTED, "gemm(8-phase): C larger than 2 GiB");
+    if constexpr (EPI == EPI_SWIGLU)      // the 16-bit output is addressed through a buffer descriptor with 32-bit byte offsets
+        SAT_CHECK_ARG(((uint64_t)a.M + 256) * (uint64_t)(a.N / 2) * 2u < (1ull << 31), SAT_E_UNSUPPORTED, "gemm(8-phase): H larger than 2 GiB");
     constexpr bool LN_CONS = EPI == EPI_SWIGLU || EPI == EPI_HEADS;
     SAT_CHECK_ARG(LN_CONS || !a.ln_part, SAT_E_UNSUPPORTED, "gemm(8-phase): the LayerNorm fold is finished by the SwiGLU / heads epilogues");
     SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (EPI == EPI_F32 && a.xb && a.ln_part_out), SAT_E_UNSUPPORTED,
