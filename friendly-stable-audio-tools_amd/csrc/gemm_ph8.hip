@@ -749,8 +749,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     // against 2.8 for SwiGLU (profiles/r04_ph8_heads_swiglu_timeline.txt).  Now a lane fetches the (cos, sin) of its FIRST row block and of
     // position 16 right after the main loop, in FRONT of the next range's LDS-DMA prologue (oldest entries of the in-order vector-memory
     // queue; inline assembly, so the compiler's conservative wait insertion neither sees nor serialises them), waits for them with ONE counted
-    // wait behind it, and walks to the next row block -- 16 positions on -- by the angle-addition rotation (16 FMAs; 5e-7 absolute after seven
-    // steps, three orders below the 16-bit rounding of q / k).  A row block in which some lane crosses into the next sequence re-reads the table.
+    // wait behind it, and walks to the next row block -- 16 positions on -- by the angle-addition rotation (16 FMAs).  Against exact arithmetic the
+    // walked values are as accurate as the table (1.5e-5 vs 2.7e-5 at S = 1025); they differ from the TABLE -- the reference's fp32 pos * inv_freq --
+    // by its own angle rounding: <= 4e-5 (rms 3e-6) at S = 1025, <= 2.4e-4 (rms 1.5e-5) at S = 6145, against 16-bit rounding of q / k of 1.4e-4 rms
+    // (tests/test_host_logic.py::test_rope_angle_addition_recurrence_error).  A row block in which some lane crosses into the next sequence re-reads the table.
     // The (cos, sin) of position 16 -- 32 floats, the same for every tile -- sit in LDS behind the LayerNorm constants, written once per workgroup.
     struct RopePre {
         f32x4_t cs, sn;

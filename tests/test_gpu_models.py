@@ -753,7 +753,7 @@ def test_full_size_batch8_config3_config5(dev, full_dit, gemm_dtype):
         full_dit.set_gemm_dtype(SUITE.gemm_dtype)
 
 
-@pytest.mark.parametrize("gemm_dtype", ["bf16", "fp8", "fp8-all", "fp16"])
+@pytest.mark.parametrize("gemm_dtype", ["bf16", "fp8", "fp16"])
 def test_full_size_trajectory(dev, full_dit, gemm_dtype):
     """Multi-step parity at FULL size: 12 steps of DPM-Solver++(3M) SDE, sigma 500 -> 0.3, batched CFG 7, on the
     SA-Open DiT (D = 1536, T = 1024) through the product's own `sample_k`, initial and per-step noise injected, against the CPU
@@ -795,12 +795,13 @@ def test_full_size_trajectory(dev, full_dit, gemm_dtype):
     #   bf16: vs matched oracle 2.9e-4 / 6.5e-3 / 9.4e-3, vs fp32 oracle 3.6e-4 / 5.2e-3 / 8.1e-3 (the matched ORACLE itself is 3.7e-4 / 4.6e-3 /
     #         7.9e-3 away from the fp32 oracle: the trajectory amplifies rounding noise chaotically, two bf16 evaluations with the same
     #         rounding points but different summation order drift apart as fast as either drifts from fp32);
-    #   fp8-all (every block GEMM e4m3, round 3's config 5): vs matched 8.7e-3 / 1.8e-1 / 3.7e-1, vs fp32 6.6e-3 / 1.2e-1 / 2.9e-1 (matched oracle
-    #         vs fp32: 8.1e-3 / 1.1e-1 / 2.3e-1) -- the to_out projections on MXFP8 attention outputs alone cost 3.3e-1 (tools/fp8_budget.py);
+    #   fp8-all (every block GEMM e4m3, round 3's config 5) drifted 8.7e-3 / 1.8e-1 / 3.7e-1 from its matched oracle and 2.9e-1 from fp32 -- the to_out
+    #         projections on MXFP8 attention outputs alone cost 3.3e-1 (tools/fp8_budget.py).  Its trajectory case was dropped in round 5: a gate of
+    #         7.4e-1 gates nothing; the mode stays covered per forward at full size (test_full_size_batch8_config3_config5[fp8-all]) and
+    #         against its matched oracle (test_dit_fp8_gemm_mode[fp8-all], test_fp8_full_width_slice_vs_matched_oracle);
     #   fp8 (round 4's config 5: cross to_q + FF-in + FF-out): vs matched 3.4e-4 / 7.1e-3 / 1.3e-2, vs fp32 4.1e-4 / 5.7e-3 / 1.4e-2 -- bf16-class.
     #   fp16 (round 4): see the printed lines; gates = 2x measured
     tol = {"bf16": {4: (6e-4, 8e-4), 8: (1.3e-2, 1.1e-2), 12: (1.9e-2, 1.7e-2)},
-           "fp8-all": {4: (1.8e-2, 1.4e-2), 8: (3.6e-1, 2.5e-1), 12: (7.4e-1, 5.7e-1)},
            "fp8": {4: (7e-4, 9e-4), 8: (1.5e-2, 1.2e-2), 12: (2.6e-2, 2.9e-2)},
            "fp16": {4: (2e-4, 2e-4), 8: (3e-3, 3e-3), 12: (5e-3, 5e-3)}}[gemm_dtype]
     msg = []

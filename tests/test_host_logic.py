@@ -208,6 +208,43 @@ def test_scripts_host_side(tmp_path):
     assert sr == 8000 and torch.allclose(b, torch.tensor([[0.5, -1.0, 1.0]]), atol=1e-4)
 
 
+def test_rope_angle_addition_recurrence_error():
+    """The 8-phase heads epilogue (csrc/gemm_ph8.hip, round 5) fetches (cos, sin) of a lane's first row block and walks to the next -- 16
+    positions on -- by the angle-addition rotation with the table row of position 16, in fp32, up to seven times.  The claims in the kernel's
+    comment, for every start position and every frequency of rotary_freqs (transformer.py:158-183): against EXACT arithmetic the walked values
+    are as accurate as the table; they differ from the table (= the reference's fp32 pos * inv_freq) by no more than its own angle rounding --
+    <= 5e-5 at the SA-Open length, <= 3e-4 at the SA-2.0 length, rms an order below -- against a 16-bit rounding of q / k of 1.4e-4 rms."""
+    import numpy as np
+    for s_len, bound in ((1025, 5e-5), (6145, 3e-4)):
+        inv_freq = (1.0 / (10000 ** (np.arange(0, 32, 2, dtype=np.float32) / np.float32(32)))).astype(np.float32)
+        ang = (np.arange(s_len, dtype=np.float32)[:, None] * inv_freq[None, :]).astype(np.float32)          # fp32 product, as the table is built
+        cos_t, sin_t = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+        pos64 = np.arange(s_len, dtype=np.float64)[:, None] * inv_freq[None, :].astype(np.float64)
+        table_vs_exact = max(float(np.abs(cos_t - np.cos(pos64)).max()), float(np.abs(sin_t - np.sin(pos64)).max()))
+        c16, s16 = cos_t[16], sin_t[16]
+        start = np.arange(0, s_len - 7 * 16)
+        c, s = cos_t[start].copy(), sin_t[start].copy()
+        vs_table = vs_exact = 0.0
+        for step in range(1, 8):
+            c, s = (c * c16 - s * s16).astype(np.float32), (s * c16 + c * s16).astype(np.float32)
+            idx = start + 16 * step
+            vs_table = max(vs_table, float(np.abs(c - cos_t[idx]).max()), float(np.abs(s - sin_t[idx]).max()))
+            vs_exact = max(vs_exact, float(np.abs(c - np.cos(pos64[idx])).max()), float(np.abs(s - np.sin(pos64[idx])).max()))
+            rms = float(np.sqrt(np.mean((c - cos_t[idx]) ** 2)))
+        assert vs_table <= bound and rms <= bound / 10, (s_len, vs_table, rms)
+        assert vs_exact <= 1.05 * table_vs_exact + 1e-6, (s_len, vs_exact, table_vs_exact)
+
+
+def test_codec_format_follows_the_dit_by_one_rule():
+    """generate.py and bench.py picked the codec's operand format differently for the e4m3 modes.  One rule now
+    (stable_audio_tools/_config.py: codec_gemm_dtype), used by both scripts and by the 100-step parity test."""
+    from stable_audio_tools import _config
+    assert [_config.codec_gemm_dtype(d) for d in ("fp16", "bf16", "fp8", "fp8-all", "fp32x")] == ["fp16", "bf16", "bf16", "bf16", "fp16"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script in ("bench.py", os.path.join("friendly-stable-audio-tools_amd", "generate.py")):
+        assert "codec_gemm_dtype" in open(os.path.join(root, script)).read(), script
+
+
 def test_package_default_is_fp16():
     """What a user gets without touching any switch: fp16 operands (the reference's own GPU arithmetic).  The suite runs on that default
     unless SAT_TEST_DTYPE=bf16 (conftest.py); the switch is per model and process-wide."""

@@ -5,6 +5,8 @@
 #   stats [bench.py args]   rocprofv3 --kernel-trace --stats of bench.py     -> gpurun_out/${TAG}_kernel_stats.csv + _summary.md
 #   pmc                     FETCH_SIZE / WRITE_SIZE / SQ counter passes of tools/gpu_probe.py full (separate passes, no traces)
 #   probe <sections...>     tools/ph8_probe.py sections with the experiments build
+#   ab                      same-box interleaved A/B of the DiT step against the round-4 library (tools/ab_r04.py; needs tools/ab/*.so)
+#   power [bench.py args]   rocm-smi power / clock samples while bench.py runs (tools/power_probe.py)
 #   both                    the -m gpu suite under BOTH operand formats (SAT_TEST_DTYPE=fp16 = the package default, then bf16), prints shown (-s)
 # TAG (default r05) names the outputs.
 cd "$(dirname "$0")/.."
@@ -40,6 +42,10 @@ case $stage in
       rm -rf $R/gpurun_out/${TAG}_pmc_$tag
     done
     head -4 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE_per_kernel.csv | cut -c1-200 ;;
+  ab)
+    timeout 900 python tools/ab_r04.py "$@" > gpurun_out/${TAG}_ab_r04.log 2>&1; tail -6 gpurun_out/${TAG}_ab_r04.log ;;
+  power)
+    timeout 900 python tools/power_probe.py "bench.py $*" -- python bench.py --no-cpu-baseline "$@" > gpurun_out/${TAG}_power.txt 2>&1; grep "Socket\|sclk clock speed" gpurun_out/${TAG}_power.txt ;;
   probe)
     SAT_HIP_EXP=1 timeout 900 python tools/ph8_probe.py "$@" > gpurun_out/${TAG}_probe.log 2>&1; tail -40 gpurun_out/${TAG}_probe.log ;;
   *) echo "unknown stage $stage"; exit 2 ;;
