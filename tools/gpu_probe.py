@@ -16,6 +16,9 @@ from stable_audio_tools import _hip
 dev = torch.device("cuda:0")
 if os.environ.get("SAT_HIP_EXP"):       # developer build with the experimental tiles / ablation modes (make -C csrc exp)
     _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libsat_hip_exp.so")
+if os.environ.get("SAT_HIP_LIB"):       # another build of the library (tools/ab/*.so: same-box comparisons against an earlier round)
+    _hip.LIB_PATH = os.path.join(ROOT, os.environ["SAT_HIP_LIB"])
+    _hip.ABI_VERSION = int(os.environ.get("SAT_HIP_ABI", _hip.ABI_VERSION))
 lib = _hip.lib()
 
 
