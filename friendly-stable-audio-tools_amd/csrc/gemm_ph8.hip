@@ -1049,7 +1049,8 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     int lb = 0;
     // vector-memory operations a wave issues between a range's DMA prologue and the top of that range, when they are a constant: the MB
     // unconditional stores of the SwiGLU epilogue (16-bit output; the e4m3 build writes a data-dependent mix).  -1: not a constant.
-    constexpr int EPI_STORES = (EPI == EPI_SWIGLU && FP8 == 0 && DBG == 0 && PH2 && PH2V == 1) ? MB : -1;
+    // (DBG 9, the timeline build: wave 0 issues its timestamp stores on top -- more operations behind the prologue, so the counted wait only gets stricter)
+    constexpr int EPI_STORES = (EPI == EPI_SWIGLU && FP8 == 0 && (DBG == 0 || DBG == 9) && PH2 && PH2V == 1) ? MB : -1;
     [[maybe_unused]] bool stores_behind = false;
     LnPre lnpre;
     prepare_issue(cur, lnpre);
