@@ -45,3 +45,19 @@ def test_attention_kernels_fit_four_waves_per_simd(defines, tmp_path):
     for name, m in att.items():
         assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{name}: {m}"
         assert m["vgpr_count"] <= 128, f"{name}: {m}"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("defines", [[], ["-DSAT_OPERAND_F16"]], ids=["bf16", "f16"])
+def test_one_prompt_gemm_tiles_keep_their_occupancy(defines, tmp_path):
+    """The one-prompt tiles of gemm_bf16.hip and the register budgets their occupancy rests on: the 12-wave 256 x 192 heads tile (to_qkv; three
+    waves per SIMD = 168 VGPRs -- round 5 fetches the rotation table of both row blocks up front, which took it from 142 to 158) and the
+    two-K-group 128 x 128 tile (FF-out / to_out; 8 waves of 256 registers), both without scratch."""
+    meta = _kernels("gemm_bf16.hip", defines, str(tmp_path))
+    qkv = {k: v for k, v in meta.items() if "gemm_pipe_kernelILi256ELi192ELi64ELi4ELi3ELi2ELi3ELi0ELi1ELb0E" in k}
+    kgroup = {k: v for k, v in meta.items() if "gemm_pipe_kernelILi128ELi128ELi64ELi2ELi2ELi2ELi0ELi0ELi2ELb0E" in k}
+    assert len(qkv) == 1 and len(kgroup) == 1, sorted(meta)[:5]
+    for name, m in list(qkv.items()) + list(kgroup.items()):
+        assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{name}: {m}"
+    assert next(iter(qkv.values()))["vgpr_count"] <= 168
+    assert next(iter(kgroup.values()))["vgpr_count"] <= 256
