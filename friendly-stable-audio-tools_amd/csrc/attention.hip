@@ -314,17 +314,20 @@ int SAT_OPNS::sat_launch_attention(const op_t* q, const op_t* k, const op_t* vt,
     SAT_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)out) & 15) == 0, SAT_E_INVALID, "attention: pointers must be 16-byte aligned");
     const float scale_log2 = q_scale;       // SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e), or 1 for a pre-scaled Q
     dim3 grid(cdiv(sq, Q_BLOCK), h, b);
-    // One KV group (256 queries per workgroup, every wave walks all the KV tiles) when the grid still gives every CU its two workgroups
-    // twice over, or when there are too few keys to split (cross-attention: 130 keys = 3 tiles).  Measured (profiles/
-    // r03_attention_groups.txt): SA-2.0 self-attention 650 -> 617 us, 8 prompts 214 -> 205, cross 10.8 -> 9.8; at one prompt (240
-    // workgroups of 256 queries for 512 slots) the split stays: 31.1 vs 32.6 us.  SAT_ATTN_GROUPS = 1 | 2 forces a layout (A/B).
+    // One KV group (256 queries per workgroup, every wave walks all the KV tiles of one shared ring: half the LDS-DMA and K / V^T traffic per
+    // query, no merge) or two (128 queries x 2 key ranges merged through LDS: twice the waves in flight, half the tile chain per wave)?
+    // Round 3's rule -- one group only from 1024 workgroups on, or for <= 512 keys -- predates MODE 2 (the softmax reference carried through the
+    // matrix pipe), which only the one-group layout can afford in registers.  Re-measured in round 5 for a pre-scaled Q
+    // (profiles/r05_attention_layout_sweep.txt, S = 1025, 24 heads): 2 sequences (one prompt with CFG, 240 workgroups) 23.7 us against 25.9 with
+    // two groups, 4 / 6 / 8 / 16 sequences 38.8 / 56.1 / 72.8 / 137 against 46.0 / 65.3 / 78.7 / 154; ONE sequence (120 workgroups for 256 CUs)
+    // 21.5 against 15.8 -- there the split stays.  A plain Q (MODE 1 in both layouts) keeps round 3's rule.  SAT_ATTN_GROUPS = 1 | 2 forces a layout (A/B).
 #ifdef SAT_GEMM_EXPERIMENTS
     const int force_grp = [] { const char* e = getenv("SAT_ATTN_GROUPS"); return e ? atoi(e) : 0; }();      // re-read per launch (A/B in one process)
 #else
     static const int force_grp = [] { const char* e = getenv("SAT_ATTN_GROUPS"); return e ? atoi(e) : 0; }();
 #endif
     const long wg1 = (long)cdiv(sq, 256) * h * b;
-    const bool one_group = force_grp ? force_grp == 1 : (wg1 >= 1024 || sk <= 512);
+    const bool one_group = force_grp ? force_grp == 1 : (wg1 >= 1024 || sk <= 512 || (q_scale == 1.0f && !out_scales && wg1 >= 200));
 #ifdef SAT_GEMM_EXPERIMENTS
     if (one_group && !out_scales && getenv("SAT_ATTN_DBG") && atoi(getenv("SAT_ATTN_DBG")) == 9) {
         if (!g_attn_dbg) {

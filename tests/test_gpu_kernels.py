@@ -153,7 +153,8 @@ def _pad_heads(x, s_pad, key_side=False):
 
 @pytest.mark.parametrize("fmt", FORMATS, ids=repr)
 @pytest.mark.parametrize("prescaled", [False, True])
-@pytest.mark.parametrize("b,h,kvh,sq,sk", [(2, 4, 4, 1025, 1025), (1, 4, 2, 300, 130), (2, 2, 2, 64, 64), (1, 2, 1, 129, 7), (8, 64, 8, 300, 700)])
+@pytest.mark.parametrize("b,h,kvh,sq,sk", [(2, 4, 4, 1025, 1025), (1, 4, 2, 300, 130), (2, 2, 2, 64, 64), (1, 2, 1, 129, 7), (8, 64, 8, 300, 700),
+                                          (2, 24, 24, 1025, 1025)])          # the last: one prompt with CFG at full size = 240 single-range workgroups (round 5's layout rule)
 def test_attention(dev, b, h, kvh, sq, sk, prescaled, fmt):
     """prescaled: the layout the DiT plan runs -- Q carries log2(e)/8 (written so by the QKV epilogue); every shape with <= 512 keys or
     >= 1024 workgroups of 256 queries then takes the single-KV-group kernel whose softmax reference rides in the matrix pipe."""

@@ -36,5 +36,11 @@ for dt, fn_name in ((torch.float16, "sat_attention_prescaled_f16"), (torch.bfloa
             else: os.environ.pop("SAT_ATTN_DBG", None)
             res[mode] = statistics.median([timeit(f) for _ in range(3)])
         os.environ.pop("SAT_ATTN_DBG", None)
+        os.environ["SAT_ATTN_GROUPS"] = "1"          # the single-range layout (256 queries per workgroup, MODE 2) forced: 240 workgroups at one prompt
+        one_range = statistics.median([timeit(f) for _ in range(3)])
+        os.environ["SAT_ATTN_GROUPS"] = "2"
+        two_range = statistics.median([timeit(f) for _ in range(3)])
+        os.environ.pop("SAT_ATTN_GROUPS", None)
+        print(f"{str(dt):15s} {name:14s}: forced single-range layout {one_range:6.1f} us, forced two-range layout {two_range:6.1f} us", flush=True)
         print(f"{str(dt):15s} {name:14s}: shipped {res[0]:6.1f} us | no softmax arithmetic {res[1]:6.1f} | no LDS-DMA {res[2]:6.1f} | no MFMA {res[3]:6.1f} | "
               f"no DMA + no barrier {res[4]:6.1f} | + fragments read once {res[5]:6.1f}", flush=True)
