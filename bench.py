@@ -79,10 +79,12 @@ def one_generation(model, cond, seed, dev, world):
     if world > 1 or FORCE_DIST:
         from stable_audio_tools.inference.distributed import gather_sharded
         out = gather_sharded(out, world * b)           # the single RCCL collective (xGMI)
-    # the reference's float_to_int16_audio ends in .cpu() (utils/audio_utils.py:21-26): the int16 audio leaves the device inside the
-    # timed step (8.4 MB per prompt; rank 0 takes the gathered batch, the other ranks their own prompts)
+    # the reference's float_to_int16_audio ends in .cpu() (utils/audio_utils.py:21-26) and every rank writes its OWN prompts' files
+    # (generate.py:119-120, 142-151): each rank takes its own shard off the device inside the timed step (8.4 MB per prompt); the gathered
+    # batch stays in HBM on every rank.  (Until round 5 rank 0 copied the whole gathered batch -- 537 MB of pageable D2H per step on
+    # config 3 -- while the others copied 1/8 of that: a built-in scaling loss under the MAX-over-ranks clock.)
     rank = int(os.environ.get("RANK", "0"))
-    return (out if rank == 0 else out[rank::world]).cpu()
+    return (out[rank::world] if world > 1 else out).cpu()
 
 
 def cpu_baseline(sd):

@@ -824,7 +824,13 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
     const int M = g.M, N = g.N, K = g.K;
     const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = N / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // the workgroups behind the tiles prefetch the next launches' weights into the memory-side cache and exit (GemmArgs::pf_*)
+    const int n_tiles = (int)gridDim.x - g.pf_wgs;
+    if ((int)blockIdx.x >= n_tiles) {
+        sat_prefetch_wg(g, (int)blockIdx.x - n_tiles, tid, NT);
+        return;
+    }
+    const int bid = xcd_remap(blockIdx.x, n_tiles);
     int tm, tn;
     if (tiles_m <= tiles_n) {
         tn = bid / tiles_m;
@@ -1453,7 +1459,8 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG(b.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", b.N, BN);
     SAT_CHECK_ARG(b.K % (BK * KG) == 0 && b.K / (BK * KG) >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
     int tiles = cdiv(b.M, BM) * (b.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), xa ? XA_LDS : LDS, stream, b);
+    b.pf_wgs = sat_pf_extra_wgs(a, tiles, std::max(1, sat_device_cus()));
+    hipLaunchKernelGGL(kern, dim3(tiles + b.pf_wgs), dim3(NT), xa ? XA_LDS : LDS, stream, b);
     SAT_LAUNCH_CHECK();
     return 0;
 }

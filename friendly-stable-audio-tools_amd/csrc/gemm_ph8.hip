@@ -331,6 +331,12 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     const int wr = wave / WN, wc = wave % WN;
     const int l15_ = lane & 15, q4_ = lane >> 4;
     const int M = g.M, N = g.N, K = g.K;
+    // the workgroups behind the persistent ones prefetch the next launches' weights into the memory-side cache and exit (GemmArgs::pf_*):
+    // a balanced one-prompt launch (2 x 216, 2 x 192) leaves 40-64 compute units idle, hardware dispatch puts them there
+    if ((int)blockIdx.x >= sc.G) {
+        sat_prefetch_wg(g, (int)blockIdx.x - sc.G, tid_, NT);
+        return;
+    }
     const int wgi = xcd_remap(blockIdx.x, sc.G);          // consecutive logical workgroups share an XCD (and so the tiles they split)
 
     // ---- the walk over this workgroup's K-ranges
@@ -1324,7 +1330,10 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
         ts = g_ts_buf;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(sc.G), dim3(NT), LDS, stream, a, sc, ts);
+    int cus = 0;
+    SAT_TRY(ph8_cus(cus));
+    a.pf_wgs = (BM == 256 && DBG == 0) ? sat_pf_extra_wgs(a0, sc.G, cus) : 0;
+    hipLaunchKernelGGL(kern, dim3(sc.G + a.pf_wgs), dim3(NT), LDS, stream, a, sc, ts);
     if (sc.split) hipLaunchKernelGGL(ph8_reduce_f32_kernel, dim3(sc.sk_tiles * 8), dim3(512), 0, stream, a, sc);
     SAT_LAUNCH_CHECK();
     return 0;

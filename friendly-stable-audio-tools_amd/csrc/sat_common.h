@@ -230,6 +230,43 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Body of a prefetch workgroup (GemmArgs::pf_*): workgroup `part` of `nparts` touches every nparts-th group of lines of the regions,
+// 8 loads in flight per lane, results discarded.  Plain loads: the line is fetched from HBM through the memory-side cache into this
+// XCD's L2 -- whichever XCD the consumer's workgroups run on finds it in the MALL.
+template <bool NT>
+__device__ __forceinline__ unsigned sat_pf_load(const char* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
+    else return *reinterpret_cast<const volatile unsigned*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void sat_prefetch_lines(const void* base, unsigned bytes, int part, int nparts, int tid, int nthreads) {
+    const unsigned lines = bytes >> 7;
+    const char* p = reinterpret_cast<const char*>(base);
+    unsigned acc = 0;
+    const unsigned stride = (unsigned)nparts * (unsigned)nthreads;
+    unsigned i = (unsigned)part * (unsigned)nthreads + (unsigned)tid;
+    for (; i + 7u * stride < lines; i += 8u * stride) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sat_pf_load<NT>(p + ((size_t)(i + u * stride) << 7));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u];
+    }
+    for (; i < lines; i += stride) acc ^= sat_pf_load<NT>(p + ((size_t)i << 7));
+    asm volatile("" ::"v"(acc));          // keep the loads
+}
+
+// what a kernel runs for blockIdx.x >= its own workgroup count (`part` = blockIdx.x - that count)
+template <typename Args>
+__device__ __forceinline__ void sat_prefetch_wg(const Args& g, int part, int tid, int nthreads) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (!g.pf_bytes[r]) continue;
+        if (g.pf_nt) sat_prefetch_lines<true>(g.pf_ptr[r], g.pf_bytes[r], part, g.pf_wgs, tid, nthreads);
+        else sat_prefetch_lines<false>(g.pf_ptr[r], g.pf_bytes[r], part, g.pf_wgs, tid, nthreads);
+    }
+}
+
 // LDS tile layout used by the MFMA kernels: rows of 64 bf16 (128 B = eight 16-B chunks);
 // chunk c of row r lives at chunk (c ^ ((r >> 1) & 7)).  With this XOR every 16-lane group
 // of a ds_read_b128 fragment read (16 distinct rows, same logical chunk) covers all 16
@@ -327,7 +364,27 @@ struct GemmArgs {
     // workspace), used by this launch only; nullptr = the remainder round's tiles stay whole.
     float* slab;
     size_t slab_bytes;
+    // ---- next-launch operand prefetch (round 6).  In the model every layer's weights were last touched one sampler step (2.15 GB of
+    // weight traffic) ago: they come from HBM, where a stand-alone loop on one operand set finds them in the 256-MiB memory-side cache
+    // (MALL).  A launch that leaves compute units idle (one prompt: 192-216 workgroups on 256 CUs) therefore carries up to `pf_wgs`
+    // EXTRA workgroups behind its tiles (blockIdx >= the tile / persistent-workgroup count, so hardware dispatch puts them on the
+    // idle CUs) that touch one dword of every 128-byte line of up to two regions -- the weights of the launches that follow -- and
+    // exit: HBM is idle under these compute-bound launches, and the lines are in the MALL when the next launch's LDS-DMA asks for them.
+    // Set by the DiT plan (sat_dit_cfg.prefetch); 0 extra workgroups = off.  Reads only; never changes a result.
+    const void* pf_ptr[2];
+    unsigned pf_bytes[2];
+    int pf_wgs;
+    int pf_nt;                 // 1: non-temporal loads (A/B switch, sat_dit_cfg.prefetch = 2)
 };
+
+// cap on the extra prefetch workgroups of one launch
+#define SAT_PF_MAX_WGS 48
+// extra workgroups the launcher may append behind `main_wgs` resident workgroups (one per CU)
+static inline int sat_pf_extra_wgs(const GemmArgs& a, int main_wgs, int cus) {
+    if (!(a.pf_bytes[0] | a.pf_bytes[1]) || main_wgs >= cus) return 0;
+    const int idle = cus - main_wgs;
+    return idle < SAT_PF_MAX_WGS ? idle : SAT_PF_MAX_WGS;
+}
 
 // bf16 build: checks a.f16 and forwards fp16 work to sat_launch_gemm_f16 (the fp16 build of the same file)
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream);

@@ -18,14 +18,14 @@ class SatError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5          # include/sat_hip.h: sat_version()
+ABI_VERSION = 6          # include/sat_hip.h: sat_version()
 
 
 class SatDitCfg(Structure):
     _fields_ = [("io_channels", c_int32), ("embed_dim", c_int32), ("depth", c_int32), ("num_heads", c_int32),
                 ("cond_token_dim", c_int32), ("cond_embed_dim", c_int32), ("global_cond_dim", c_int32),
                 ("max_seq_len", c_int32), ("adaln", c_int32), ("gemm_dtype", c_int32), ("fp8_families", c_int32), ("ln_fold", c_int32),
-                ("cross_attention", c_int32), ("tile_policy", c_int32)]
+                ("cross_attention", c_int32), ("tile_policy", c_int32), ("prefetch", c_int32)]
 
 
 class SatT5Cfg(Structure):
@@ -43,6 +43,7 @@ _SIGNATURES = {
     "sat_version": (c_int32, []),
     "sat_last_error": (c_char_p, []),
     "sat_dit_plan_create": (c_int32, [POINTER(SatDitCfg), POINTER(c_void_p)]),
+    "sat_dit_plan_create_sized": (c_int32, [POINTER(SatDitCfg), c_size_t, POINTER(c_void_p)]),
     "sat_dit_plan_destroy": (None, [c_void_p]),
     "sat_dit_plan_set_tensor": (c_int32, [c_void_p, c_char_p, c_void_p, c_int64]),
     "sat_dit_plan_finalize": (c_int32, [c_void_p, c_void_p]),

@@ -43,8 +43,9 @@ extern "C" {
 
 typedef void* sat_stream_t;     /* hipStream_t */
 
-/* ABI version: 5.  A loader MUST check it (stable_audio_tools/_hip.py does): the cfg structs grow at the END between versions, and an older
- * caller's struct would leave the new fields uninitialised. */
+/* ABI version: 6.  A loader MUST check it (stable_audio_tools/_hip.py does): the cfg structs grow at the END between versions.  Since version 6
+ * the size of the caller's sat_dit_cfg travels with the call (sat_dit_plan_create_sized), so a struct laid out for another version is rejected
+ * deterministically instead of being read past its end; sat_dit_plan_create keeps reading exactly the version-5 layout (14 int32 fields). */
 int sat_version(void);
 const char* sat_last_error(void);
 
@@ -122,8 +123,17 @@ typedef struct sat_dit_cfg {
     int32_t tile_policy;       /* 0 / 80 (default): the measured tile choice; A/B measurement switches: 22 = the 16-wave 256 x 256 tile of rounds
                                   1-2 instead of the 8-phase kernel, 81 = the 8-phase kernel also for fp32-output GEMMs with K < 4096, 82 = no
                                   two-K-group 128 x 128 tile */
+    /* ---- version 6 (read by sat_dit_plan_create_sized only) */
+    int32_t prefetch;          /* next-launch operand prefetch: a block GEMM that leaves compute units idle (one prompt: 192-216 workgroups on 256
+                                  CUs) carries extra workgroups that pull the weights of the launches behind it from HBM into the 256-MiB
+                                  memory-side cache while the matrix pipes work (reads only; results are bit-identical).  0 (default): on;
+                                  1: off; 2: on, with non-temporal loads (A/B measurement switch) */
 } sat_dit_cfg;
+#define SAT_DIT_CFG_BYTES_V5 56          /* the layout sat_dit_plan_create reads: everything up to and including tile_policy */
 
+/* cfg_bytes = sizeof(sat_dit_cfg) of the header the CALLER was built against: the current size or SAT_DIT_CFG_BYTES_V5 (fields behind it take
+ * their defaults); anything else is SAT_E_INVALID.  sat_dit_plan_create(cfg, out) == sat_dit_plan_create_sized(cfg, SAT_DIT_CFG_BYTES_V5, out). */
+int sat_dit_plan_create_sized(const sat_dit_cfg* cfg, size_t cfg_bytes, sat_dit_plan** out_plan);
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
 void sat_dit_plan_destroy(sat_dit_plan* plan);
 

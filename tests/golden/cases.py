@@ -65,11 +65,20 @@ TRAJ100 = dict(steps=100, sigma_min=0.3, sigma_max=500.0, cfg_scale=7.0, snapsho
                audio_windows={"start": 0, "middle": 1048576}, audio_window_len=65536)
 
 
-def traj100_inputs():
-    """(cross_attn_cond, global_cond, unit initial noise, per-step unit noise) of the 100-step full-size fixture"""
-    _, _, c, g = dit_inputs(1, 1024, 768, 1536, 1)
-    noise = synthetic.synth_input("traj100_noise", (1, 64, 1024), 700)
-    step_noise = [synthetic.synth_input(f"traj100_sn{i}", (1, 64, 1024), 710 + i) for i in range(TRAJ100["steps"])]
+# further (prompt, seed) pairs of the same 100-step fixture: variant v has its own conditioning and its own noise
+# draws; stored as traj100_full_v{v}.npz with the latents after 50 / 100 steps only (no audio windows)
+TRAJ100_VARIANTS = (0, 1, 2)
+TRAJ100_VARIANT_SNAPSHOTS = (50, 100)
+
+
+def traj100_inputs(variant=0):
+    """(cross_attn_cond, global_cond, unit initial noise, per-step unit noise) of the 100-step full-size fixture; `variant` > 0 =
+    another (prompt, seed) pair"""
+    _, _, c, g = dit_inputs(1, 1024, 768, 1536, 1 + 10 * variant)
+    base = 700 + 1000 * variant
+    tag = "" if variant == 0 else f"_v{variant}"
+    noise = synthetic.synth_input(f"traj100_noise{tag}", (1, 64, 1024), base)
+    step_noise = [synthetic.synth_input(f"traj100_sn{i}{tag}", (1, 64, 1024), base + 10 + i) for i in range(TRAJ100["steps"])]
     return c, g, noise, step_noise
 
 

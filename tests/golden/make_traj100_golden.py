@@ -7,7 +7,12 @@ by the full-size Oobleck decode of the final latents (synthetic weights seed 0).
 two 65 536-sample windows (start, middle) of the decoded stereo audio.  One CFG evaluation takes 20-45 s on 8 cores, the whole job
 about an hour, which is why this is a committed fixture; partial results are checkpointed next to the output after every snapshot.
 
-    python tests/golden/make_traj100_golden.py [threads]        (any machine with the repo; no GPU, no reference needed)
+    python tests/golden/make_traj100_golden.py [threads] [variant]     (any machine with the repo; no GPU, no reference needed)
+
+`variant` 1, 2, ... = another (prompt, seed) pair (the <= 1e-3 claim on more than one trajectory): other conditioning
+tensors, other initial and per-step noise (cases.traj100_inputs(variant)); written to traj100_full_v{variant}.npz with the latents after
+50 / 100 steps only (no decode).  NOTE: these fixtures are outputs of the repo's CPU ORACLE (pinned against the reference by the
+short-run goldens of make_golden.py), not of the reference itself.
 """
 import os
 import sys
@@ -30,19 +35,21 @@ T100 = cases.TRAJ100
 @torch.no_grad()
 def main():
     torch.set_num_threads(int(sys.argv[1]) if len(sys.argv) > 1 else os.cpu_count())
+    variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    snapshots = T100["snapshots"] if variant == 0 else cases.TRAJ100_VARIANT_SNAPSHOTS
     with _init.skip_init():
         dit = DiffusionTransformer(**cases.FULL_DIT)
     sd = synthetic.synth_state_dict(dit.state_dict(), 0)
     del dit
-    c, g, noise, step_noise = cases.traj100_inputs()
+    c, g, noise, step_noise = cases.traj100_inputs(variant)
     sig = osamp.get_sigmas_polyexponential(T100["steps"], T100["sigma_min"], T100["sigma_max"], 1.0)
-    path = os.path.join(cases.GOLDEN_DIR, "traj100_full.npz")
+    path = os.path.join(cases.GOLDEN_DIR, "traj100_full.npz" if variant == 0 else f"traj100_full_v{variant}.npz")
     out = {}
     t0 = time.time()
 
     def cb(info):
         i = info["i"]
-        if i in T100["snapshots"]:          # x at the start of step i = the latents after i steps
+        if i in snapshots:          # x at the start of step i = the latents after i steps
             out[f"fp32_step{i}"] = info["x"].numpy().astype(np.float32).copy()
             np.savez_compressed(path + ".partial.npz", **out)
         print(f"step {i:3d} sigma {float(info['sigma']):9.4f}  |x| {float(info['x'].std()):.4f}  {time.time() - t0:6.0f} s", flush=True)
@@ -53,6 +60,11 @@ def main():
     np.savez_compressed(path + ".partial.npz", **out)
     print(f"trajectory: {time.time() - t0:.0f} s, final std {x.std():.4f}", flush=True)
     del sd
+    if variant != 0:
+        np.savez_compressed(path, **out)
+        os.remove(path + ".partial.npz")
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+        return
     with _init.skip_init():
         dec = OobleckDecoder(**cases.vae_kwargs(cases.FULL_VAE, True))
     vsd = synthetic.synth_state_dict(dec.state_dict(), 0)

@@ -399,103 +399,6 @@ def test_ln_fold_swiglu(dev, prod, cons, m, fmt):
     assert_close("ln-fold swiglu vs fp32 LayerNorm + Linear", out, val * F.silu(gate), fmt.tol(1e-2))
 
 
-@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
-@pytest.mark.parametrize("s,s_pad", [(197, 256), (385, 512)])
-@pytest.mark.parametrize("variant", [0] + GEMM_VARIANTS)
-def test_qkv_rope(dev, variant, s, s_pad, fmt):
-    from oracle import dit as odit
-    _hip, lib = _lib()
-    b, d = 2, 256
-    _skip_tile(variant, 3 * d, d)
-    h = d // 64
-    a = _rand((b * s, d), 15).to(fmt.dtype)
-    w = (_rand((3 * d, d), 16) * 0.1).to(fmt.dtype)
-    inv_freq = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
-    qkv = (a.float() @ w.float().T).view(b, s, 3 * d)
-    q, k, v = (odit._heads(t, h) for t in qkv.chunk(3, dim=-1))
-    freqs = odit.rotary_freqs(inv_freq, s)
-    q, k = odit.apply_rotary(q, freqs), odit.apply_rotary(k, freqs)
-    ad, wd, fd = a.to(dev), w.to(dev), inv_freq.to(dev)
-    qd = torch.full((b, h, s_pad, 64), float("nan"), dtype=fmt.dtype, device=dev)
-    kd = torch.full_like(qd, float("nan"))
-    vtd = torch.full((b, h, 64, s_pad), float("nan"), dtype=fmt.dtype, device=dev)
-    scratch = torch.empty((2 * s * 16,), dtype=torch.float32, device=dev)
-    _hip.check(fmt.fn(lib, "sat_qkv_rope_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(fd), _hip.ptr(qd), _hip.ptr(kd), _hip.ptr(vtd),
-                                                _hip.ptr(scratch), b, s, s_pad, d, variant, _hip.stream()))
-    assert_close("rope q", qd[:, :, :s], q, fmt.tol(4e-3))
-    vtd = vtd[..., _vt_perm(s_pad).to(vtd.device)]      # undo the key permutation of the V^T layout
-    for i in range(b):     # key-side tensors of sequence i start at row/column (i*s) & 3
-        ob = (i * s) & 3
-        assert_close("rope k", kd[i, :, ob:ob + s], k[i], fmt.tol(4e-3))
-        assert_close("v^T", vtd[i, :, :, ob:ob + s], v[i].transpose(1, 2), fmt.tol(4e-3))
-        assert (kd[i, :, :ob] == 0).all() and (kd[i, :, ob + s:] == 0).all(), "K pads must be zero"
-        assert (vtd[i, :, :, :ob] == 0).all() and (vtd[i, :, :, ob + s:] == 0).all(), "V^T pads must be zero"
-    assert (qd[:, :, s:] == 0).all(), "Q pads must be zero"
-
-
-def _ln_fold_producer(dev, m, d, k, variant, seed=40, fmt=FORMATS[0], x_scale=2.0):
-    """x0 + a w^T + bias through the producer entry; returns (c fp32, xb bf16 / fp16, ln_part) on the device after checking them."""
-    _hip, lib = _lib()
-    a = _rand((m, k), seed).to(fmt.dtype)
-    w = (_rand((d, k), seed + 1) * 0.05 + torch.linspace(-0.02, 0.03, d)[:, None]).to(fmt.dtype)
-    bias = _rand((d,), seed + 2)
-    x0 = _rand((m, d), seed + 3, x_scale) + 0.3       # rows with a mean: the fold has to subtract it
-    want = a.float() @ w.float().T + bias + x0
-    ad, wd, bd, cd = a.to(dev), w.to(dev), bias.to(dev), x0.to(dev)
-    xb = torch.full((m, d), float("nan"), dtype=fmt.dtype, device=dev)
-    part = torch.full((m, d // 64, 2), float("nan"), dtype=torch.float32, device=dev)
-    if variant & 0x10000:
-        ws, ws_bytes = _split_ws(dev, m, d, k, variant)
-        _hip.check(fmt.fn(lib, "sat_gemm_resid_ln_bf16_ws")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), _hip.ptr(xb), _hip.ptr(part), m, d, k,
-                                                            variant, _hip.ptr(ws), ws_bytes, _hip.stream()))
-    else:
-        _hip.check(fmt.fn(lib, "sat_gemm_resid_ln_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), _hip.ptr(xb), _hip.ptr(part), m, d, k,
-                                                         variant, _hip.stream()))
-    assert_close(f"ln-fold producer v{variant}", cd, want, 1e-3)
-    assert torch.equal(xb, cd.clamp(-65504.0, 65504.0).to(fmt.dtype)), "xb must be the 16-bit rounding (fp16: saturating) of the fp32 rows just written"
-    blocks = xb.float().view(m, d // 64, 64).double()
-    assert_close("ln-fold partial sums", part[..., 0], blocks.sum(-1), 1e-5)
-    assert_close("ln-fold partial squares", part[..., 1], (blocks * blocks).sum(-1), 1e-5)
-    return cd, xb, part
-
-
-def _ln_fold_reference(xb, w, gamma, beta, bias, fmt=FORMATS[0]):
-    """What the consumer computes, in fp64 on the same rounded operands: rstd (xb (gamma.w)^T - mean c1) + c2."""
-    x = xb.double().cpu()
-    mean = x.mean(-1, keepdim=True)
-    var = (x * x).mean(-1, keepdim=True) - mean * mean
-    rstd = 1.0 / torch.sqrt(var + 1e-5)
-    wp = fmt.round(gamma * w).double()
-    c2 = (w.double() * beta.double()).sum(-1) + (bias.double() if bias is not None else 0.0)
-    return (rstd * (x @ wp.T - mean * wp.sum(-1)) + c2).float()
-
-
-@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
-@pytest.mark.parametrize("m", [300, 770])
-@pytest.mark.parametrize("prod,cons", [(15, 22), (16, 30), (22, 15), (30, 16), (44, 22), (49, 15), (0, 0), (80, 80), (15, 80), (80, 30), (SPLIT, 80)])
-def test_ln_fold_swiglu(dev, prod, cons, m, fmt):
-    """LayerNorm folded into FF-in (sat_dit_cfg.ln_fold): producer epilogue -> bf16 rows + partial sums -> SwiGLU GEMM that finishes
-    the normalisation.  Gates: 4e-3 against the same arithmetic in fp64 (one bf16 rounding of the output), 1e-2 against the plain fp32
-    LayerNorm -> Linear -> SwiGLU of the reference (transformer.py:700, 222, 232-235; adds the bf16 rounding of the operands)."""
-    _hip, lib = _lib()
-    d, inner = 768, 768
-    cd, xb, part = _ln_fold_producer(dev, m, d, 256, prod, fmt=fmt)
-    w = _rand((2 * inner, d), 50) * 0.08
-    gamma = 0.8 + 0.2 * _rand((d,), 51)
-    beta = 0.1 * _rand((d,), 52)
-    bias = 0.1 * _rand((2 * inner,), 53)
-    wd, gd, bd, bbd = w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev)
-    wp = torch.empty((2 * inner, d), dtype=fmt.dtype, device=dev)
-    c12 = torch.empty((4 * inner,), dtype=torch.float32, device=dev)
-    out = torch.full((m, inner), float("nan"), dtype=fmt.dtype, device=dev)
-    _hip.check(fmt.fn(lib, "sat_gemm_swiglu_ln_bf16")(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(bbd),
-                                                      _hip.ptr(wp), _hip.ptr(c12), _hip.ptr(out), m, 2 * inner, d, cons, _hip.stream()))
-    val, gate = _ln_fold_reference(xb, w, gamma, beta, bias, fmt).chunk(2, dim=-1)
-    assert_close("ln-fold swiglu vs same arithmetic", out, val * F.silu(gate), fmt.tol(4e-3))
-    val, gate = F.linear(F.layer_norm(cd.cpu(), (d,), gamma, beta, eps=1e-5), w, bias).chunk(2, dim=-1)
-    assert_close("ln-fold swiglu vs fp32 LayerNorm + Linear", out, val * F.silu(gate), fmt.tol(1e-2))
-
-
 @pytest.mark.parametrize("row_mean,outlier", [(0.0, 0.0), (8.0, 0.0), (30.0, 0.0), (0.0, 60.0)])
 def test_ln_fold_rows_with_common_mode(dev, row_mean, outlier):
     """the fold feeds un-normalised bf16(x) to the MFMA and subtracts mean * c1 afterwards, so its rounding error scales with

@@ -5,15 +5,15 @@
 #   stats [bench.py args]   rocprofv3 --kernel-trace --stats of bench.py     -> gpurun_out/${TAG}_kernel_stats.csv + _summary.md
 #   pmc                     FETCH_SIZE / WRITE_SIZE / SQ counter passes of tools/gpu_probe.py full (separate passes, no traces)
 #   probe <sections...>     tools/ph8_probe.py sections with the experiments build
-#   ab                      same-box interleaved A/B of the DiT step against the round-4 library (tools/ab_r04.py; needs tools/ab/*.so)
+#   ab                      same-box interleaved A/B of the DiT step against the round-5 library (tools/ab_r05.py; needs tools/ab/libsat_hip_r05.so)
 #   power [bench.py args]   rocm-smi power / clock samples while bench.py runs (tools/power_probe.py)
 #   both                    the -m gpu suite under BOTH operand formats (SAT_TEST_DTYPE=fp16 = the package default, then bf16), prints shown (-s)
-# TAG (default r05) names the outputs.
+# TAG (default r06) names the outputs.
 cd "$(dirname "$0")/.."
 R=$PWD
 mkdir -p gpurun_out
 export PYTHONPATH=$R/friendly-stable-audio-tools_amd:$PYTHONPATH
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 stage=$1; shift
 case $stage in
   pytest)
@@ -43,6 +43,8 @@ case $stage in
     done
     head -4 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE_per_kernel.csv | cut -c1-200 ;;
   ab)
+    timeout 1200 python tools/ab_r05.py "$@" > gpurun_out/${TAG}_ab_r05.log 2>&1; tail -6 gpurun_out/${TAG}_ab_r05.log ;;
+  ab4)
     timeout 900 python tools/ab_r04.py "$@" > gpurun_out/${TAG}_ab_r04.log 2>&1; tail -6 gpurun_out/${TAG}_ab_r04.log ;;
   power)
     timeout 900 python tools/power_probe.py "bench.py $*" -- python bench.py --no-cpu-baseline "$@" > gpurun_out/${TAG}_power.txt 2>&1; grep "Socket\|sclk clock speed" gpurun_out/${TAG}_power.txt ;;
