@@ -266,7 +266,7 @@ __device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t (&v)
         }
         const f32x4_t o = old[nb];
         x += e.accumulate ? o : f32x4_t{0.f, 0.f, 0.f, 0.f};          // (a select on the loaded value, not a branch around the load)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ph8_u32x4, x), e.rsC, off + nb * 64, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ph8_u32x4, x), e.rsC, off + nb * 64, 0, SAT_OUT_AUX);
         if (prod) {
             opx4 xr;
 #pragma unroll
@@ -276,7 +276,7 @@ __device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t (&v)
                 sum += f;
                 sq += f * f;
             }
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ph8_u32x2, xr), e.rsXb, (m * e.N + ncol0 + 4 * q4 + nb * 16) * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ph8_u32x2, xr), e.rsXb, (m * e.N + ncol0 + 4 * q4 + nb * 16) * 2, 0, SAT_OUT_AUX);
         }
     }
     if (prod) {       // add the four lanes (q4 = 0..3) that share the token row
@@ -288,7 +288,7 @@ __device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t (&v)
         sq = __uint_as_float(b[0]) + __uint_as_float(b[1]);
         // lanes q4 != 0 aim beyond the descriptor's range: their store is dropped (no branch)
         const int poff = q4 == 0 ? (m * (e.N >> 6) + (ncol0 >> 6)) * 8 : 0x7ffffff0;
-        __builtin_amdgcn_raw_buffer_store_b64(ph8_u32x2{__float_as_uint(sum), __float_as_uint(sq)}, e.rsPart, poff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(ph8_u32x2{__float_as_uint(sum), __float_as_uint(sq)}, e.rsPart, poff, 0, SAT_OUT_AUX);
     }
 }
 
@@ -891,13 +891,13 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         unsigned q1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv8[4] * inv, hv8[5] * inv, 0u, false);
                         q1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv8[6] * inv, hv8[7] * inv, q1, true);
                         if (m < M) {
-                            *reinterpret_cast<u32x2*>(g.H8 + (size_t)m * ldh + (ncol0 >> 1) + q4 * 8) = u32x2{q0, q1};
+                            st_out(reinterpret_cast<u32x2*>(g.H8 + (size_t)m * ldh + (ncol0 >> 1) + q4 * 8), u32x2(u32x2{q0, q1}));
                             if (q4 == 0) g.Hs[(size_t)m * (ldh >> 5) + (ncol0 >> 6)] = (unsigned char)(e + 127);
                         }
                         continue;
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(ph8_u32x4{pk[0], pk[1], pk[2], pk[3]}, rsH, (m * ldh + hcol) * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ph8_u32x4{pk[0], pk[1], pk[2], pk[3]}, rsH, (m * ldh + hcol) * 2, 0, SAT_OUT_AUX);
             }
         } else {   // EPI_HEADS: split into heads, LayerNorm fold, partial RoPE on d < 32 (transformer.py:158-183, 438-452)
             const HeadsEpi& he = g.heads;
@@ -961,10 +961,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                     }
                     if (m < M) {
                         op_t* row = dst + ((size_t)(b * he.heads + head) * Spad + sq_ + ob) * 64;
-                        *reinterpret_cast<u32x2*>(row + 4 * q4) = u32x2{pack_op2(x[0][0], x[0][1]), pack_op2(x[0][2], x[0][3])};
-                        *reinterpret_cast<u32x2*>(row + 16 + 4 * q4) = u32x2{pack_op2(x[1][0], x[1][1]), pack_op2(x[1][2], x[1][3])};
-                        *reinterpret_cast<u32x4*>(row + 32 + 8 * q4) = u32x4{pack_op2(x[2][0], x[2][1]), pack_op2(x[2][2], x[2][3]),
-                                                                             pack_op2(x[3][0], x[3][1]), pack_op2(x[3][2], x[3][3])};
+                        st_out(reinterpret_cast<u32x2*>(row + 4 * q4), u32x2(u32x2{pack_op2(x[0][0], x[0][1]), pack_op2(x[0][2], x[0][3])}));
+                        st_out(reinterpret_cast<u32x2*>(row + 16 + 4 * q4), u32x2(u32x2{pack_op2(x[1][0], x[1][1]), pack_op2(x[1][2], x[1][3])}));
+                        st_out(reinterpret_cast<u32x4*>(row + 32 + 8 * q4), u32x4{pack_op2(x[2][0], x[2][1]), pack_op2(x[2][2], x[2][3]),
+                                                                           pack_op2(x[3][0], x[3][1]), pack_op2(x[3][2], x[3][3])});
                     }
                     sq_ += 16;
                     while (sq_ >= S) {
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         }
                         const size_t drow = (size_t)(nb * 16 + l15) * Spad;
                         if (whole4 && shift) {         // aligned: (ss[0] + ob) % 4 == mbase % 4 == 0
-                            *reinterpret_cast<u32x2*>(dst + hb0 + vt_pos(ss[0] + ob0) + drow) = u32x2{pack_op2(v[0], v[1]), pack_op2(v[2], v[3])};
+                            st_out(reinterpret_cast<u32x2*>(dst + hb0 + vt_pos(ss[0] + ob0) + drow), u32x2(u32x2{pack_op2(v[0], v[1]), pack_op2(v[2], v[3])}));
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)

@@ -219,6 +219,35 @@ __device__ __forceinline__ void gather_channel_runs(const f32x16& a, float (&v)[
         }
 }
 
+// Cache policy of the bulk OUTPUT stores of the block kernels (activations the NEXT launch reads: q / k / v, attention output, SwiGLU hidden
+// state, the residual stream and its 16-bit image).  The L2s of the 8 XCDs are not coherent with each other, so a dependent launch on the same
+// stream waits for the write-back of every line the previous one left dirty (in-image guide, "boundary": + bytes / 6 TB/s -- 2.8-3.8 us behind
+// 13-17 MB; one block at one prompt leaves 115 MB behind its seven launches).  SAT_OUT_POLICY (build-time, A/B'd in round 6):
+//   0  default write-back stores        1  write-through (sc0 sc1): the line leaves for the memory side while the epilogue still runs
+//   2  non-temporal (nt)                3  write-through + non-temporal
+#ifndef SAT_OUT_POLICY
+#define SAT_OUT_POLICY 0
+#endif
+// aux operand of the raw_buffer_store builtins on gfx94x / gfx950: bit 0 = sc0, bit 1 = nt, bit 4 = sc1
+#define SAT_OUT_AUX (SAT_OUT_POLICY == 1 ? 17 : SAT_OUT_POLICY == 2 ? 2 : SAT_OUT_POLICY == 3 ? 19 : 0)
+// (inline assembly: the compiler does not count these stores in its vmcnt bookkeeping -- loads return in order among themselves, so an
+// uncounted older store can only make a counted wait stricter, never let it pass early)
+template <typename T>
+__device__ __forceinline__ void st_out(T* p, T v) {
+    static_assert(sizeof(T) == 8 || sizeof(T) == 16, "st_out: 8- or 16-byte pieces");
+    if constexpr (SAT_OUT_POLICY == 0) {
+        *p = v;
+    } else if constexpr (sizeof(T) == 16) {
+        if constexpr (SAT_OUT_POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (SAT_OUT_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    } else {
+        if constexpr (SAT_OUT_POLICY == 1) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        else if constexpr (SAT_OUT_POLICY == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    }
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids
 // land on the same XCD (hardware places block b on XCD b % 8), so neighbouring tiles share
 // one L2.  Speed only -- never correctness.

@@ -2,8 +2,8 @@
 to the library round 5 shipped; git-ignored like every .so, it travels to the GPU box) against this tree's library under named settings of its
 per-plan switches, all timed INTERLEAVED in one process on one box (box-to-box spread of the bench line is +-3 %): one full-size model per
 entry, `dit.denoise` = one CFG-7 denoiser step (2 sequences per prompt), what generate_diffusion_cond calls 100 times.
-Entries: AB_SET="name:key=value;key=value,name:..." with keys prefetch / tile_policy (default: r05 library, this tree with prefetch off / on /
-non-temporal).  Developer tool; not part of the product or the tests.     usage: python tools/ab_r05.py [batch ...]      (default: 1 8)"""
+Entries: AB_SET="name:key=value;key=value,name:..." with keys prefetch / tile_policy / old=1 (a second instance of the round-5 library:
+instance-to-instance noise) / lib=path (another build of this tree).  Developer tool; not part of the product or the tests.     usage: python tools/ab_r05.py [batch ...]      (default: 1 8)"""
 import ctypes
 import os
 import statistics
@@ -53,7 +53,17 @@ def main():
     spec = os.environ.get("AB_SET", "off:prefetch=1,on:prefetch=0,nt:prefetch=2")
     for item in filter(None, spec.split(",")):
         name, _, kv = item.partition(":")
-        entries[name] = (new, {k: int(v) for k, v in (p.split("=") for p in filter(None, kv.split(";")))})
+        raw = dict(p.split("=") for p in filter(None, kv.split(";")))
+        libpath = raw.pop("lib", None)          # lib=tools/ab/x.so: another build of THIS tree (same ABI); old=1: a further instance of the round-5 library
+        opts = {k: int(v) for k, v in raw.items()}
+        if libpath:
+            h = ctypes.CDLL(os.path.join(ROOT, libpath))
+            for fname, (res, args) in _hip._SIGNATURES.items():
+                fn = getattr(h, fname)
+                fn.restype, fn.argtypes = res, args
+            entries[name] = (h, opts)
+        else:
+            entries[name] = (entries["r05"][0] if opts.pop("old", 0) else new, opts)
     print(torch.cuda.get_device_name(0), {k: (v[0].sat_version(), v[1]) for k, v in entries.items()}, flush=True)
     dits = {}
     for name, (h, opts) in entries.items():

@@ -128,6 +128,23 @@ def libcal():
     arms_bench("libcal 8192^3", 8192, 8192, 8192, [80], rounds=3, iters=3)
 
 
+def quant6():
+    """Round 6, pricing the M-tail BEFORE building anything: what would every block GEMM cost if M were a whole number of
+    tiles -- M = 2048 / 16384 (the tokens without the 2 / 16 rows that spill into a ninth / 65th row of tiles) against the model's M = 2050 /
+    16400 -- with the shipped tile choice (v0), the 8-phase tile (80), the 12-wave 256 x 192 (30), the 256 x 128 8-wave tile (12, experiments
+    build: 768 tiles = 3.0 rounds at M = 16384) and the vendor library, all interleaved; plain fp32 output (the epilogue is the same on both M)."""
+    for name, n, k, vs1, vs8 in (("ff_in", 12288, 1536, [0], [0]), ("qkv", 4608, 1536, [0, 80 | 0x20000], [0]),
+                                 ("to_out", 1536, 1536, [0, 15], [0, 22, 80 | 0x20000, 12]), ("ff_out", 1536, 6144, [0, 44], [0, 22, 12])):
+        for m in (2050, 2048):
+            arms_bench(f"quant6 {name} B1", m, n, k, vs1, rounds=4, iters=10)
+        for m in (16400, 16384):
+            arms_bench(f"quant6 {name} B8", m, n, k, vs8, rounds=3, iters=6)
+    for m in (1025, 1024):
+        arms_bench("quant6 cross B1", m, 1536, 1536, [0, 15], rounds=4, iters=10)
+    for m in (8200, 8192):
+        arms_bench("quant6 cross B8", m, 1536, 1536, [0, 22, 12], rounds=3, iters=6)
+
+
 def balance(bit=0x200000):
     """schedule A/B on the real epilogues: every CU a workgroup (256 + remainder) vs balanced rounds on fewer workgroups (variant bit 21)"""
     def ab(label, mk, flops, arms, rounds=5):
