@@ -243,8 +243,8 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const op_t* __restric
             swap_halves(q8[2], q8[3]);
             if (qi < Sq) {
                 unsigned char* op = reinterpret_cast<unsigned char*>(out) + ((size_t)b * Sq + qi) * ((size_t)H * 64) + h * 64 + db * 32 + 8 * half;
-                st_out(reinterpret_cast<u32x2*>(op), u32x2(u32x2{q8[0], q8[1]}));
-                st_out(reinterpret_cast<u32x2*>(op + 16), u32x2(u32x2{q8[2], q8[3]}));
+                *reinterpret_cast<u32x2*>(op) = u32x2{q8[0], q8[1]};
+                *reinterpret_cast<u32x2*>(op + 16) = u32x2{q8[2], q8[3]};
                 if (half == 0) out_scales[((size_t)b * Sq + qi) * ((size_t)H * 2) + h * 2 + db] = (unsigned char)(e + 127);
             }
         }
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const op_t* __restric
             swap_halves(pk[4], pk[6]);
             swap_halves(pk[5], pk[7]);
             if (qi < Sq) {
-                st_out(reinterpret_cast<u32x4*>(op + db * 32), u32x4(u32x4{pk[0], pk[1], pk[2], pk[3]}));
-                st_out(reinterpret_cast<u32x4*>(op + db * 32 + 16), u32x4(u32x4{pk[4], pk[5], pk[6], pk[7]}));
+                *reinterpret_cast<u32x4*>(op + db * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                *reinterpret_cast<u32x4*>(op + db * 32 + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
             }
         }
     }

@@ -112,7 +112,6 @@ struct sat_dit_plan {
     int f16 = 0;                    // cfg.gemm_dtype == 3: every 16-bit operand buffer holds IEEE fp16 and the fp16 build of the kernels runs
     bool cross_fusion = true;       // cfg.cross_attention == 0: to_q + cross-attention core in one launch where it applies
     int tile_bits = 0;              // cfg.tile_policy as GemmArgs::variant bits (sat_tile_policy_bits)
-    int pf_mode = 0;                // cfg.prefetch: 0 next-launch weight prefetch on (16-bit operand modes), 1 off, 2 on with non-temporal loads
     bool ln_fold = false;           // cfg.ln_fold, bf16 / fp16 operands, "prepend" conditioning: LayerNorms run inside the GEMM epilogues
     int fp8_mode = 2;               // 2: v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, 2x rate); 1: v_mfma_f32_32x32x16_fp8_fp8
     // gemm_dtype == 1: which GEMM families take e4m3 operands (sat_dit_cfg.fp8_families; SAT_FP8_* bits); 0 in every other mode
@@ -437,20 +436,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         auto fold_out = [&](GemmArgs& ga) {
             if (lf) { ga.xb = w.A; ga.ln_part_out = w.ln_part; }
         };
-        // Next-launch operand prefetch (GemmArgs::pf_*, sat_dit_cfg.prefetch): every launch names the weights of the launches behind it --
-        // the launcher appends prefetch workgroups only where the launch leaves compute units idle.  Who pulls what (bytes per layer at
-        // D = 1536: to_qkv 14.2 MB, to_out / to_q / cross to_out 4.7 MB each, FF-in 37.7 MB, FF-out 18.9 MB): to_qkv -> to_out + to_q;
-        // to_out -> cross to_out + the first third of FF-in; to_q -> the second third; cross to_out -> the last third; FF-in -> FF-out;
-        // FF-out -> the next block's to_qkv (the last block: the first block's, for the next sampler step).  16-bit operand modes only.
-        const bool pf_on = p->pf_mode != 1 && (c.gemm_dtype == 0 || c.gemm_dtype == 3);
-        auto pf = [&](GemmArgs& ga, int slot, const void* ptr, size_t bytes) {
-            if (!pf_on || !ptr || bytes < 128) return;
-            ga.pf_ptr[slot] = ptr; ga.pf_bytes[slot] = (unsigned)bytes; ga.pf_nt = p->pf_mode == 2;
-        };
-        const size_t wDD = (size_t)D * D * 2, wff1 = (size_t)2 * p->inner * D * 2, wff2 = (size_t)D * p->inner * 2;
-        const size_t ff1_third = (wff1 / 3) & ~(size_t)127;
-        const int bc_pf = cross ? ((p->ctx_null_from >= 0 && p->ctx_null_from < bf) ? p->ctx_null_from : bf) : 0;
-        const char* ff1_bytes = (const char*)L.w_ff1;
         if (p->f8_qkv) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.pre_g, L.pre_b, w.A, w.As, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
         else if (!L.fold_qkv) SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s, f16));
         g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
@@ -461,8 +446,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.heads.kind[0] = 2 | 8; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4; g.heads.qscale = SAT_ATTN_QSCALE;
         g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
         g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
-        pf(g, 0, L.w_o, wDD);
-        if (bc_pf > 0) pf(g, 1, L.w_cq, wDD); else pf(g, 1, ff1_bytes, ff1_third);
         SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
         SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, p->f8_o ? w.AOs : nullptr, 1.0f, f16));
         g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
@@ -470,8 +453,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         fold_out(g);
-        if (bc_pf > 0) { pf(g, 0, L.w_co, wDD); pf(g, 1, ff1_bytes, ff1_third); }
-        else pf(g, 0, ff1_bytes + ff1_third, wff1 - ff1_third);
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
         // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
         // unconditional CFG half, dit.py:294-300) get k = v = 0 from the bias-free to_cond_embed / to_kv, hence an
@@ -498,7 +479,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                     g.heads.xa_k = p->kc + l * per_layer; g.heads.xa_vt = p->vct + l * per_layer; g.heads.xa_out = w.AO;
                     g.heads.xa_kvh = p->kvh_cross; g.heads.xa_sk = p->ctx_lc; g.heads.xa_sk_pad = p->ctx_lcpad;
                 }
-                pf(g, 0, ff1_bytes + ff1_third, ff1_third);
                 SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
                 if (!fuse)
                     SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
@@ -507,7 +487,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
                 if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
                 fold_out(g);
-                pf(g, 0, ff1_bytes + 2 * ff1_third, wff1 - 2 * ff1_third);
                 SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
             }
         }
@@ -523,7 +502,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             g.fp8 = p->fp8_mode; g.a_scale = w.As; g.w_scale = L.s_ff1;
             if (p->f8_ff2) { g.H8 = (unsigned char*)w.Hh; g.Hs = w.Hs; }          // FF-out's MXFP8 operand; otherwise the e4m3 GEMM writes a bf16 hidden state
         }
-        pf(g, 0, L.w_ff2, wff2);
         const bool prof = p->prof_on && l == c.depth / 2 && p->prof_n < kProfMaxPairs;
         if (prof) {
             if ((int)p->prof_ev.size() < 2 * (p->prof_n + 1)) {
@@ -547,7 +525,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         if (l + 1 < c.depth) fold_out(g);       // nobody normalises the output of the last block
-        pf(g, 0, p->layers[(l + 1) % c.depth].w_qkv, 3 * wDD);
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
     }
     // project_out + drop prepend + postprocess_conv + residual (transformer.py:807, dit.py:219-224)
@@ -564,13 +541,13 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
 
 extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_bytes, sat_dit_plan** out_plan) {
     SAT_CHECK_ARG(cfg_in && out_plan, SAT_E_INVALID, "dit_plan_create: null argument");
-    static_assert(sizeof(sat_dit_cfg) == SAT_DIT_CFG_BYTES_V5 + 4 && offsetof(sat_dit_cfg, prefetch) == SAT_DIT_CFG_BYTES_V5, "sat_dit_cfg layout");
-    SAT_CHECK_ARG(cfg_bytes == sizeof(sat_dit_cfg) || cfg_bytes == SAT_DIT_CFG_BYTES_V5, SAT_E_INVALID,
-                  "dit_plan_create: sat_dit_cfg of %zu bytes; this library knows %zu (version 6) and %d (version 5)", cfg_bytes, sizeof(sat_dit_cfg), SAT_DIT_CFG_BYTES_V5);
-    sat_dit_cfg cfg_local{};              // fields behind the caller's struct keep their defaults (0)
+    static_assert(sizeof(sat_dit_cfg) == SAT_DIT_CFG_BYTES_V5, "sat_dit_cfg layout");
+    // (the one layout this library knows; when the struct grows again, the older sizes are accepted here and the fields behind them defaulted)
+    SAT_CHECK_ARG(cfg_bytes == sizeof(sat_dit_cfg), SAT_E_INVALID, "dit_plan_create: sat_dit_cfg of %zu bytes; this library (ABI version %d) knows %zu",
+                  cfg_bytes, sat_version(), sizeof(sat_dit_cfg));
+    sat_dit_cfg cfg_local{};
     memcpy(&cfg_local, cfg_in, cfg_bytes);
     const sat_dit_cfg* cfg = &cfg_local;
-    SAT_CHECK_ARG(cfg->prefetch >= 0 && cfg->prefetch <= 2, SAT_E_INVALID, "dit_plan_create: prefetch must be 0 (on), 1 (off) or 2 (on, non-temporal loads)");
     SAT_CHECK_ARG(cfg->embed_dim > 0 && cfg->num_heads > 0 && cfg->embed_dim == cfg->num_heads * 64, SAT_E_UNSUPPORTED,
                   "dit_plan_create: dim_heads must be 64 (embed_dim %d, heads %d)", cfg->embed_dim, cfg->num_heads);
     SAT_CHECK_ARG(cfg->embed_dim % 128 == 0 && cfg->embed_dim <= 2048, SAT_E_UNSUPPORTED,
@@ -614,7 +591,6 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
     }
     p->cross_fusion = cfg->cross_attention == 0;
     p->tile_bits = sat_tile_policy_bits(cfg->tile_policy);
-    p->pf_mode = cfg->prefetch;
     p->ln_fold = cfg->ln_fold != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
     return 0;

@@ -172,8 +172,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                             p1[e] = f32_to_op(v1[e]);
                         }
                         if (shift) {     // aligned: (ss[0] + ob) % 4 == mb % 4 == 0
-                            st_out(reinterpret_cast<opx4*>(dst + base + (size_t)l31 * Spad), opx4(p0));
-                            st_out(reinterpret_cast<opx4*>(dst + base + (size_t)(32 + l31) * Spad), opx4(p1));
+                            *reinterpret_cast<opx4*>(dst + base + (size_t)l31 * Spad) = p0;
+                            *reinterpret_cast<opx4*>(dst + base + (size_t)(32 + l31) * Spad) = p1;
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -250,7 +250,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                     if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + c0 + j * 32 + q * 8);
                     if (grow) v *= *reinterpret_cast<const f32x4*>(grow + j * 32 + q * 8);      // adaLN gate (transformer.py:674, 688)
                     v += old[j][q];
-                    if (m < M) st_out(reinterpret_cast<f32x4*>(crow + j * 32 + q * 8), f32x4(v));
+                    if (m < M) *reinterpret_cast<f32x4*>(crow + j * 32 + q * 8) = v;
                 }
         }
     } else if constexpr (EPI == EPI_SWIGLU) {
@@ -316,8 +316,8 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                 half_swap(q8[2], q8[3]);
                 if (m < M) {
                     unsigned char* hrow = g.H8 + (size_t)m * ldh + hc0 + 8 * half;
-                    st_out(reinterpret_cast<u32x2*>(hrow), u32x2(u32x2{q8[0], q8[1]}));
-                    st_out(reinterpret_cast<u32x2*>(hrow + 16), u32x2(u32x2{q8[2], q8[3]}));
+                    *reinterpret_cast<u32x2*>(hrow) = u32x2{q8[0], q8[1]};
+                    *reinterpret_cast<u32x2*>(hrow + 16) = u32x2{q8[2], q8[3]};
                     if (half == 0) g.Hs[(size_t)m * (ldh >> 5) + (hc0 >> 5)] = (unsigned char)(e + 127);
                 }
             } else {
@@ -333,8 +333,8 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                 half_swap(pk[5], pk[7]);
                 if (m < M) {
                     op_t* hrow = g.H + (size_t)m * ldh + hc0 + 8 * half;
-                    st_out(reinterpret_cast<u32x4*>(hrow), u32x4(u32x4{pk[0], pk[1], pk[2], pk[3]}));
-                    st_out(reinterpret_cast<u32x4*>(hrow + 16), u32x4(u32x4{pk[4], pk[5], pk[6], pk[7]}));
+                    *reinterpret_cast<u32x4*>(hrow) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    *reinterpret_cast<u32x4*>(hrow + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
                 }
             }
         }
@@ -423,8 +423,8 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
                     continue;
                 }
                 if (m < M) {
-                    st_out(reinterpret_cast<u32x4*>(row + j * 32), u32x4(u32x4{pk[0], pk[1], pk[2], pk[3]}));
-                    st_out(reinterpret_cast<u32x4*>(row + j * 32 + 16), u32x4(u32x4{pk[4], pk[5], pk[6], pk[7]}));
+                    *reinterpret_cast<u32x4*>(row + j * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    *reinterpret_cast<u32x4*>(row + j * 32 + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
                 }
             }
         }
@@ -471,7 +471,7 @@ __device__ __forceinline__ void gemm_epilogue_f32_staged(const GemmArgs& g, f32x
                 f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * 64 + c4) + bia;
                 if (m < M && g.gate) v *= *reinterpret_cast<const f32x4*>(g.gate + (size_t)(m / g.gate_rows) * g.gate_ld + nw + c4);
                 v += old[p4];
-                if (m < M) st_out(reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + nw + c4), f32x4(v));
+                if (m < M) *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + nw + c4) = v;
                 if (g.xb) {
                     // LayerNorm fold, producer side (wave-uniform test): bf16 image of the updated row piece + the statistics of the
                     // ROUNDED values over this wave's 64-column block (the 16 lanes of a DPP row hold one row of the pass)
@@ -487,9 +487,9 @@ __device__ __forceinline__ void gemm_epilogue_f32_staged(const GemmArgs& g, f32x
                     sum = row16_sum(sum);
                     sq = row16_sum(sq);
                     if (m < M) {
-                        st_out(reinterpret_cast<opx4*>(g.xb + (size_t)m * g.N + nw + c4), opx4(xr));
+                        *reinterpret_cast<opx4*>(g.xb + (size_t)m * g.N + nw + c4) = xr;
                         if ((lane & 15) == 0)
-                            st_out(reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (g.N >> 6) + (nw >> 6)) * 2), float2(make_float2(sum, sq)));
+                            *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (g.N >> 6) + (nw >> 6)) * 2) = make_float2(sum, sq);
                     }
                 }
             }
@@ -824,13 +824,7 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
     const int M = g.M, N = g.N, K = g.K;
     const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = N / BN;
-    // the workgroups behind the tiles prefetch the next launches' weights into the memory-side cache and exit (GemmArgs::pf_*)
-    const int n_tiles = (int)gridDim.x - g.pf_wgs;
-    if ((int)blockIdx.x >= n_tiles) {
-        sat_prefetch_wg(g, (int)blockIdx.x - n_tiles, tid, NT);
-        return;
-    }
-    const int bid = xcd_remap(blockIdx.x, n_tiles);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
     if (tiles_m <= tiles_n) {
         tn = bid / tiles_m;
@@ -1336,8 +1330,8 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
                     half_swap(pk[4], pk[6]);
                     half_swap(pk[5], pk[7]);
                     if (m < M && b_me == bb) {
-                        st_out(reinterpret_cast<u32x4*>(op + db * 32), u32x4(u32x4{pk[0], pk[1], pk[2], pk[3]}));
-                        st_out(reinterpret_cast<u32x4*>(op + db * 32 + 16), u32x4(u32x4{pk[4], pk[5], pk[6], pk[7]}));
+                        *reinterpret_cast<u32x4*>(op + db * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                        *reinterpret_cast<u32x4*>(op + db * 32 + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
                     }
                 }
             }
@@ -1459,8 +1453,7 @@ int launch_pipe(const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG(b.N % BN == 0, SAT_E_UNSUPPORTED, "gemm: N=%d not a multiple of the %d-column tile", b.N, BN);
     SAT_CHECK_ARG(b.K % (BK * KG) == 0 && b.K / (BK * KG) >= NS, SAT_E_UNSUPPORTED, "gemm: K=%d too small for the %d-stage pipeline", a.K, NS);
     int tiles = cdiv(b.M, BM) * (b.N / BN);
-    b.pf_wgs = sat_pf_extra_wgs(a, tiles, std::max(1, sat_device_cus()));
-    hipLaunchKernelGGL(kern, dim3(tiles + b.pf_wgs), dim3(NT), xa ? XA_LDS : LDS, stream, b);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), xa ? XA_LDS : LDS, stream, b);
     SAT_LAUNCH_CHECK();
     return 0;
 }

@@ -266,7 +266,7 @@ __device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t (&v)
         }
         const f32x4_t o = old[nb];
         x += e.accumulate ? o : f32x4_t{0.f, 0.f, 0.f, 0.f};          // (a select on the loaded value, not a branch around the load)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ph8_u32x4, x), e.rsC, off + nb * 64, 0, SAT_OUT_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ph8_u32x4, x), e.rsC, off + nb * 64, 0, 0);
         if (prod) {
             opx4 xr;
 #pragma unroll
@@ -276,7 +276,7 @@ __device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t (&v)
                 sum += f;
                 sq += f * f;
             }
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ph8_u32x2, xr), e.rsXb, (m * e.N + ncol0 + 4 * q4 + nb * 16) * 2, 0, SAT_OUT_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ph8_u32x2, xr), e.rsXb, (m * e.N + ncol0 + 4 * q4 + nb * 16) * 2, 0, 0);
         }
     }
     if (prod) {       // add the four lanes (q4 = 0..3) that share the token row
@@ -288,7 +288,7 @@ __device__ __forceinline__ void ph8_epi_f32_row(const Ph8F32Epi& e, f32x4_t (&v)
         sq = __uint_as_float(b[0]) + __uint_as_float(b[1]);
         // lanes q4 != 0 aim beyond the descriptor's range: their store is dropped (no branch)
         const int poff = q4 == 0 ? (m * (e.N >> 6) + (ncol0 >> 6)) * 8 : 0x7ffffff0;
-        __builtin_amdgcn_raw_buffer_store_b64(ph8_u32x2{__float_as_uint(sum), __float_as_uint(sq)}, e.rsPart, poff, 0, SAT_OUT_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(ph8_u32x2{__float_as_uint(sum), __float_as_uint(sq)}, e.rsPart, poff, 0, 0);
     }
 }
 
@@ -331,12 +331,6 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     const int wr = wave / WN, wc = wave % WN;
     const int l15_ = lane & 15, q4_ = lane >> 4;
     const int M = g.M, N = g.N, K = g.K;
-    // the workgroups behind the persistent ones prefetch the next launches' weights into the memory-side cache and exit (GemmArgs::pf_*):
-    // a balanced one-prompt launch (2 x 216, 2 x 192) leaves 40-64 compute units idle, hardware dispatch puts them there
-    if ((int)blockIdx.x >= sc.G) {
-        sat_prefetch_wg(g, (int)blockIdx.x - sc.G, tid_, NT);
-        return;
-    }
     const int wgi = xcd_remap(blockIdx.x, sc.G);          // consecutive logical workgroups share an XCD (and so the tiles they split)
 
     // ---- the walk over this workgroup's K-ranges
@@ -891,13 +885,13 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         unsigned q1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv8[4] * inv, hv8[5] * inv, 0u, false);
                         q1 = __builtin_amdgcn_cvt_pk_fp8_f32(hv8[6] * inv, hv8[7] * inv, q1, true);
                         if (m < M) {
-                            st_out(reinterpret_cast<u32x2*>(g.H8 + (size_t)m * ldh + (ncol0 >> 1) + q4 * 8), u32x2(u32x2{q0, q1}));
+                            *reinterpret_cast<u32x2*>(g.H8 + (size_t)m * ldh + (ncol0 >> 1) + q4 * 8) = u32x2{q0, q1};
                             if (q4 == 0) g.Hs[(size_t)m * (ldh >> 5) + (ncol0 >> 6)] = (unsigned char)(e + 127);
                         }
                         continue;
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(ph8_u32x4{pk[0], pk[1], pk[2], pk[3]}, rsH, (m * ldh + hcol) * 2, 0, SAT_OUT_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(ph8_u32x4{pk[0], pk[1], pk[2], pk[3]}, rsH, (m * ldh + hcol) * 2, 0, 0);
             }
         } else {   // EPI_HEADS: split into heads, LayerNorm fold, partial RoPE on d < 32 (transformer.py:158-183, 438-452)
             const HeadsEpi& he = g.heads;
@@ -961,10 +955,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                     }
                     if (m < M) {
                         op_t* row = dst + ((size_t)(b * he.heads + head) * Spad + sq_ + ob) * 64;
-                        st_out(reinterpret_cast<u32x2*>(row + 4 * q4), u32x2(u32x2{pack_op2(x[0][0], x[0][1]), pack_op2(x[0][2], x[0][3])}));
-                        st_out(reinterpret_cast<u32x2*>(row + 16 + 4 * q4), u32x2(u32x2{pack_op2(x[1][0], x[1][1]), pack_op2(x[1][2], x[1][3])}));
-                        st_out(reinterpret_cast<u32x4*>(row + 32 + 8 * q4), u32x4{pack_op2(x[2][0], x[2][1]), pack_op2(x[2][2], x[2][3]),
-                                                                           pack_op2(x[3][0], x[3][1]), pack_op2(x[3][2], x[3][3])});
+                        *reinterpret_cast<u32x2*>(row + 4 * q4) = u32x2{pack_op2(x[0][0], x[0][1]), pack_op2(x[0][2], x[0][3])};
+                        *reinterpret_cast<u32x2*>(row + 16 + 4 * q4) = u32x2{pack_op2(x[1][0], x[1][1]), pack_op2(x[1][2], x[1][3])};
+                        *reinterpret_cast<u32x4*>(row + 32 + 8 * q4) = u32x4{pack_op2(x[2][0], x[2][1]), pack_op2(x[2][2], x[2][3]),
+                                                                             pack_op2(x[3][0], x[3][1]), pack_op2(x[3][2], x[3][3])};
                     }
                     sq_ += 16;
                     while (sq_ >= S) {
@@ -1031,7 +1025,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
                         }
                         const size_t drow = (size_t)(nb * 16 + l15) * Spad;
                         if (whole4 && shift) {         // aligned: (ss[0] + ob) % 4 == mbase % 4 == 0
-                            st_out(reinterpret_cast<u32x2*>(dst + hb0 + vt_pos(ss[0] + ob0) + drow), u32x2(u32x2{pack_op2(v[0], v[1]), pack_op2(v[2], v[3])}));
+                            *reinterpret_cast<u32x2*>(dst + hb0 + vt_pos(ss[0] + ob0) + drow) = u32x2{pack_op2(v[0], v[1]), pack_op2(v[2], v[3])};
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -1330,10 +1324,7 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
         ts = g_ts_buf;
     }
 #endif
-    int cus = 0;
-    SAT_TRY(ph8_cus(cus));
-    a.pf_wgs = (BM == 256 && DBG == 0) ? sat_pf_extra_wgs(a0, sc.G, cus) : 0;
-    hipLaunchKernelGGL(kern, dim3(sc.G + a.pf_wgs), dim3(NT), LDS, stream, a, sc, ts);
+    hipLaunchKernelGGL(kern, dim3(sc.G), dim3(NT), LDS, stream, a, sc, ts);
     if (sc.split) hipLaunchKernelGGL(ph8_reduce_f32_kernel, dim3(sc.sk_tiles * 8), dim3(512), 0, stream, a, sc);
     SAT_LAUNCH_CHECK();
     return 0;

@@ -219,35 +219,6 @@ __device__ __forceinline__ void gather_channel_runs(const f32x16& a, float (&v)[
         }
 }
 
-// Cache policy of the bulk OUTPUT stores of the block kernels (activations the NEXT launch reads: q / k / v, attention output, SwiGLU hidden
-// state, the residual stream and its 16-bit image).  The L2s of the 8 XCDs are not coherent with each other, so a dependent launch on the same
-// stream waits for the write-back of every line the previous one left dirty (in-image guide, "boundary": + bytes / 6 TB/s -- 2.8-3.8 us behind
-// 13-17 MB; one block at one prompt leaves 115 MB behind its seven launches).  SAT_OUT_POLICY (build-time, A/B'd in round 6):
-//   0  default write-back stores        1  write-through (sc0 sc1): the line leaves for the memory side while the epilogue still runs
-//   2  non-temporal (nt)                3  write-through + non-temporal
-#ifndef SAT_OUT_POLICY
-#define SAT_OUT_POLICY 0
-#endif
-// aux operand of the raw_buffer_store builtins on gfx94x / gfx950: bit 0 = sc0, bit 1 = nt, bit 4 = sc1
-#define SAT_OUT_AUX (SAT_OUT_POLICY == 1 ? 17 : SAT_OUT_POLICY == 2 ? 2 : SAT_OUT_POLICY == 3 ? 19 : 0)
-// (inline assembly: the compiler does not count these stores in its vmcnt bookkeeping -- loads return in order among themselves, so an
-// uncounted older store can only make a counted wait stricter, never let it pass early)
-template <typename T>
-__device__ __forceinline__ void st_out(T* p, T v) {
-    static_assert(sizeof(T) == 8 || sizeof(T) == 16, "st_out: 8- or 16-byte pieces");
-    if constexpr (SAT_OUT_POLICY == 0) {
-        *p = v;
-    } else if constexpr (sizeof(T) == 16) {
-        if constexpr (SAT_OUT_POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        else if constexpr (SAT_OUT_POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
-    } else {
-        if constexpr (SAT_OUT_POLICY == 1) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-        else if constexpr (SAT_OUT_POLICY == 2) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
-        else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
-    }
-}
-
 // XCD-aware bijective remap of a linear workgroup id (guide T1): consecutive logical ids
 // land on the same XCD (hardware places block b on XCD b % 8), so neighbouring tiles share
 // one L2.  Speed only -- never correctness.
@@ -257,43 +228,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int q = nwg / NX, r = nwg % NX;
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
-}
-
-// Body of a prefetch workgroup (GemmArgs::pf_*): workgroup `part` of `nparts` touches every nparts-th group of lines of the regions,
-// 8 loads in flight per lane, results discarded.  Plain loads: the line is fetched from HBM through the memory-side cache into this
-// XCD's L2 -- whichever XCD the consumer's workgroups run on finds it in the MALL.
-template <bool NT>
-__device__ __forceinline__ unsigned sat_pf_load(const char* p) {
-    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
-    else return *reinterpret_cast<const volatile unsigned*>(p);
-}
-template <bool NT>
-__device__ __forceinline__ void sat_prefetch_lines(const void* base, unsigned bytes, int part, int nparts, int tid, int nthreads) {
-    const unsigned lines = bytes >> 7;
-    const char* p = reinterpret_cast<const char*>(base);
-    unsigned acc = 0;
-    const unsigned stride = (unsigned)nparts * (unsigned)nthreads;
-    unsigned i = (unsigned)part * (unsigned)nthreads + (unsigned)tid;
-    for (; i + 7u * stride < lines; i += 8u * stride) {
-        unsigned v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = sat_pf_load<NT>(p + ((size_t)(i + u * stride) << 7));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc ^= v[u];
-    }
-    for (; i < lines; i += stride) acc ^= sat_pf_load<NT>(p + ((size_t)i << 7));
-    asm volatile("" ::"v"(acc));          // keep the loads
-}
-
-// what a kernel runs for blockIdx.x >= its own workgroup count (`part` = blockIdx.x - that count)
-template <typename Args>
-__device__ __forceinline__ void sat_prefetch_wg(const Args& g, int part, int tid, int nthreads) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (!g.pf_bytes[r]) continue;
-        if (g.pf_nt) sat_prefetch_lines<true>(g.pf_ptr[r], g.pf_bytes[r], part, g.pf_wgs, tid, nthreads);
-        else sat_prefetch_lines<false>(g.pf_ptr[r], g.pf_bytes[r], part, g.pf_wgs, tid, nthreads);
-    }
 }
 
 // LDS tile layout used by the MFMA kernels: rows of 64 bf16 (128 B = eight 16-B chunks);
@@ -393,27 +327,7 @@ struct GemmArgs {
     // workspace), used by this launch only; nullptr = the remainder round's tiles stay whole.
     float* slab;
     size_t slab_bytes;
-    // ---- next-launch operand prefetch (round 6).  In the model every layer's weights were last touched one sampler step (2.15 GB of
-    // weight traffic) ago: they come from HBM, where a stand-alone loop on one operand set finds them in the 256-MiB memory-side cache
-    // (MALL).  A launch that leaves compute units idle (one prompt: 192-216 workgroups on 256 CUs) therefore carries up to `pf_wgs`
-    // EXTRA workgroups behind its tiles (blockIdx >= the tile / persistent-workgroup count, so hardware dispatch puts them on the
-    // idle CUs) that touch one dword of every 128-byte line of up to two regions -- the weights of the launches that follow -- and
-    // exit: HBM is idle under these compute-bound launches, and the lines are in the MALL when the next launch's LDS-DMA asks for them.
-    // Set by the DiT plan (sat_dit_cfg.prefetch); 0 extra workgroups = off.  Reads only; never changes a result.
-    const void* pf_ptr[2];
-    unsigned pf_bytes[2];
-    int pf_wgs;
-    int pf_nt;                 // 1: non-temporal loads (A/B switch, sat_dit_cfg.prefetch = 2)
 };
-
-// cap on the extra prefetch workgroups of one launch
-#define SAT_PF_MAX_WGS 48
-// extra workgroups the launcher may append behind `main_wgs` resident workgroups (one per CU)
-static inline int sat_pf_extra_wgs(const GemmArgs& a, int main_wgs, int cus) {
-    if (!(a.pf_bytes[0] | a.pf_bytes[1]) || main_wgs >= cus) return 0;
-    const int idle = cus - main_wgs;
-    return idle < SAT_PF_MAX_WGS ? idle : SAT_PF_MAX_WGS;
-}
 
 // bf16 build: checks a.f16 and forwards fp16 work to sat_launch_gemm_f16 (the fp16 build of the same file)
 int sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream);

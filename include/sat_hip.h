@@ -123,16 +123,13 @@ typedef struct sat_dit_cfg {
     int32_t tile_policy;       /* 0 / 80 (default): the measured tile choice; A/B measurement switches: 22 = the 16-wave 256 x 256 tile of rounds
                                   1-2 instead of the 8-phase kernel, 81 = the 8-phase kernel also for fp32-output GEMMs with K < 4096, 82 = no
                                   two-K-group 128 x 128 tile */
-    /* ---- version 6 (read by sat_dit_plan_create_sized only) */
-    int32_t prefetch;          /* next-launch operand prefetch: a block GEMM that leaves compute units idle (one prompt: 192-216 workgroups on 256
-                                  CUs) carries extra workgroups that pull the weights of the launches behind it from HBM into the 256-MiB
-                                  memory-side cache while the matrix pipes work (reads only; results are bit-identical).  0 (default): on;
-                                  1: off; 2: on, with non-temporal loads (A/B measurement switch) */
 } sat_dit_cfg;
-#define SAT_DIT_CFG_BYTES_V5 56          /* the layout sat_dit_plan_create reads: everything up to and including tile_policy */
+#define SAT_DIT_CFG_BYTES_V5 56          /* the layout sat_dit_plan_create reads: 14 int32 fields, up to and including tile_policy */
 
-/* cfg_bytes = sizeof(sat_dit_cfg) of the header the CALLER was built against: the current size or SAT_DIT_CFG_BYTES_V5 (fields behind it take
- * their defaults); anything else is SAT_E_INVALID.  sat_dit_plan_create(cfg, out) == sat_dit_plan_create_sized(cfg, SAT_DIT_CFG_BYTES_V5, out). */
+/* cfg_bytes = sizeof(sat_dit_cfg) of the header the CALLER was built against.  This version knows one layout (SAT_DIT_CFG_BYTES_V5 = the
+ * version-5 layout, unchanged in version 6); any other size is SAT_E_INVALID -- a caller built against another header is told so instead of having
+ * its struct read past its end.  When the struct grows again, the older sizes stay accepted and the new fields take their defaults.
+ * sat_dit_plan_create(cfg, out) == sat_dit_plan_create_sized(cfg, SAT_DIT_CFG_BYTES_V5, out). */
 int sat_dit_plan_create_sized(const sat_dit_cfg* cfg, size_t cfg_bytes, sat_dit_plan** out_plan);
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
 void sat_dit_plan_destroy(sat_dit_plan* plan);
