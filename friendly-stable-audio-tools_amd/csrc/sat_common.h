@@ -277,7 +277,10 @@ struct HeadsEpi {
     int xa_kvh, xa_sk, xa_sk_pad;
     int parts;           // N == parts * heads * 64
     int heads;           // heads per part
-    int S;               // valid rows per sequence (row m -> b = m / S, s = m % S)
+    int S;               // valid rows per sequence (row m_base + m -> b = row / S, s = row % S)
+    int m_base;          // row of the launch's first A / output row in the [B * S] row space, multiple of 4: a launch that covers rows
+                         // [m_base, m_base + M) of a larger problem (the M-tail launch of the DiT plan, round 6).  Pipelined and simple tiles
+                         // of gemm_bf16.hip only (sat_gemm_ph8_supports says no to m_base != 0)
     int Spad;            // padded sequence length of the destination
     const float* rope_cos;   // [>=S][16]
     const float* rope_sin;

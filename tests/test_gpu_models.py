@@ -899,6 +899,55 @@ def test_full_size_trajectory_100_steps(dev, full_dit, gemm_dtype):
     assert e_audio <= audio_gate, f"[{gemm_dtype}] decoded audio: rel-L2 {e_audio:.3e} > {audio_gate:.1e}"
 
 
+# Gate of the claim README / DESIGN section 2 make for the default format -- "<= 1e-3 rel-L2 against the fp32 latents over the 100-step generation
+# the metric is quoted on" -- on THREE (prompt, seed) pairs (round 5 had one pair at 8.9e-4 under a 1.8e-3 gate): the gate IS the
+# claim.  Measured on MI355X (round 6, printed by the test; profiles/r06_traj100_three_pairs.txt): see TRAJ100_3PAIRS_MEASURED below.
+TRAJ100_3PAIRS_GATES = {"fp16": 1e-3, "bf16": 9.5e-3, "fp32x": 4e-6}
+
+
+@pytest.mark.parametrize("gemm_dtype", ["fp16", "bf16", "fp32x"])
+def test_full_size_trajectory_100_steps_three_pairs(dev, full_dit, gemm_dtype):
+    """The 100-step full-size trajectory of `test_full_size_trajectory_100_steps` on three (prompt, seed) pairs -- variant 0 is that test's own
+    fixture, variants 1 and 2 have their own conditioning tensors and their own initial / per-step noise (tests/golden/traj100_full_v{1,2}.npz,
+    make_traj100_golden.py <threads> <variant>: fp32 oracle latents after 50 / 100 steps).  The gate is the MAX over the three of the rel-L2 of the
+    final latents, set at the figure the documentation claims (fp16: 1e-3 = north_star's tolerance)."""
+    import cases
+    import os
+    if os.environ.get("SAT_SKIP_SLOW") == "1":
+        pytest.skip("SAT_SKIP_SLOW=1")
+    from stable_audio_tools.inference.sampling import sample_k
+    from stable_audio_tools.models.diffusion import DiTWrapper
+    tj = cases.TRAJ100
+    wrap = DiTWrapper.__new__(DiTWrapper)
+    torch.nn.Module.__init__(wrap)
+    wrap.model = full_dit
+    errs, msg = {}, []
+    full_dit.set_gemm_dtype(gemm_dtype)
+    try:
+        for v in cases.TRAJ100_VARIANTS:
+            gold = cases.load("traj100_full" if v == 0 else f"traj100_full_v{v}")
+            c, g, noise, step_noise = cases.traj100_inputs(v)
+            snaps = {}
+
+            def cb(info):
+                if info["i"] == 50:
+                    snaps[50] = info["x"].clone()
+
+            it = iter([n.to(dev) for n in step_noise])
+            x = sample_k(wrap, noise.to(dev), steps=tj["steps"], sampler_type="dpmpp-3m-sde", sigma_min=tj["sigma_min"], sigma_max=tj["sigma_max"],
+                         device=str(dev), callback=cb, noise_sampler=lambda s, sn: next(it), cfg_scale=tj["cfg_scale"],
+                         cross_attn_cond=c.to(dev), global_cond=g.to(dev))
+            assert torch.isfinite(x).all()
+            e50, e100 = rel_l2(snaps[50], gold["fp32_step50"]), rel_l2(x, gold["fp32_step100"])
+            errs[v] = e100
+            msg.append(f"pair {v}: latents after 50 / 100 steps vs fp32 oracle {e50:.2e} / {e100:.2e}")
+    finally:
+        full_dit.set_gemm_dtype(SUITE.gemm_dtype)
+    worst = max(errs.values())
+    print(f"\n[100-step full-size trajectory, three (prompt, seed) pairs, {gemm_dtype}]\n  " + "\n  ".join(msg) + f"\n  max over the pairs {worst:.2e} (gate {TRAJ100_3PAIRS_GATES[gemm_dtype]:.1e})")
+    assert worst <= TRAJ100_3PAIRS_GATES[gemm_dtype], f"[{gemm_dtype}] final latents, worst of three pairs: rel-L2 {worst:.3e} > {TRAJ100_3PAIRS_GATES[gemm_dtype]:.1e}"
+
+
 def test_fp32x_mode_vs_reference_golden(dev, full_dit, small_dit):
     """gemm_dtype="fp32x": the fp32 verification mode (csrc/f32_ref.hip: exact fp32 MFMA, fp32 LayerNorm output, fp32 q / k / v / P)
     through the SAME plan, workspace layout, RoPE table, prepend token, null-context skip and CFG batching as the bf16 path.
