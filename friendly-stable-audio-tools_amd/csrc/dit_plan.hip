@@ -112,8 +112,9 @@ struct sat_dit_plan {
     int f16 = 0;                    // cfg.gemm_dtype == 3: every 16-bit operand buffer holds IEEE fp16 and the fp16 build of the kernels runs
     bool cross_fusion = true;       // cfg.cross_attention == 0: to_q + cross-attention core in one launch where it applies
     int tile_bits = 0;              // cfg.tile_policy as GemmArgs::variant bits (sat_tile_policy_bits)
-    // cfg.m_tail == 0 (round 6): the block GEMMs run on M rounded DOWN to whole 256-row tiles, the few rows left over (2 at one prompt, 16 at
-    // eight: M = bf * 1025) run as a second, narrow-tile launch of the same GEMM on the plan's side stream, next to the main launches
+    // cfg.m_tail != 0 (round 6, opt-in: measured slower than one launch per GEMM, profiles/r06_mtail_split.txt): the block GEMMs run on M rounded
+    // DOWN to whole 256-row tiles, the few rows left over (2 at one prompt, 16 at eight: M = bf * 1025) run as a second, narrow-tile launch of the
+    // same GEMM on the plan's side stream, next to the main launches
     bool tail_split = false;
     int tail_max = 64;              // rows: a tail up to a quarter tile is the "near-empty row of tiles" case; 255 = every tail (cfg.m_tail == 2, tests)
     hipStream_t side = nullptr;
@@ -439,6 +440,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         const int mf = (ga.M / 256) * 256;
         if (!split || mf == 0 || mf == ga.M || ga.M - mf > p->tail_max) return sat_launch_gemm(epi, ga, s);
         GemmArgs t = ga;
+        ga.m_choose = ga.M;          // the tiles measured for the whole problem
         ga.M = mf;
         SAT_TRY(sat_launch_gemm(epi, ga, s));
         t.M -= mf;
@@ -452,6 +454,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         t.heads.m_base = mf;
         t.slab = nullptr;
         t.slab_bytes = 0;
+        t.variant = (t.variant & ~0xff) | 16;          // the 128 x 64 tile: the most workgroups per row of tiles (one wave per SIMD, 72 KiB of LDS)
         SAT_TRY(fork());
         SAT_TRY(sat_launch_gemm(epi, t, side));
         side_dirty = true;
@@ -640,7 +643,7 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
                   "dit_plan_create: fp8_families = 0x%x with gemm_dtype %d (a caller built against an older sat_dit_cfg layout?)", cfg->fp8_families, cfg->gemm_dtype);
     SAT_CHECK_ARG(cfg->cross_attention == 0 || cfg->cross_attention == 1, SAT_E_INVALID, "dit_plan_create: cross_attention must be 0 (fused where it applies) or 1 (two kernels)");
     SAT_CHECK_ARG(cfg->m_tail >= 0 && cfg->m_tail <= 2, SAT_E_INVALID,
-                  "dit_plan_create: m_tail must be 0 (up to 64 tail rows as a second launch, default), 1 (one launch per GEMM) or 2 (any tail as a second launch)");
+                  "dit_plan_create: m_tail must be 0 (one launch per GEMM, default), 1 (up to 64 tail rows as a second launch) or 2 (any tail as a second launch)");
     SAT_CHECK_ARG(cfg->tile_policy == 0 || cfg->tile_policy == 22 || cfg->tile_policy == 80 || cfg->tile_policy == 81 || cfg->tile_policy == 82, SAT_E_INVALID,
                   "dit_plan_create: tile_policy must be 0 / 80 (default), 22, 81 or 82");
     const int fam = cfg->fp8_families ? cfg->fp8_families : SAT_FP8_DEFAULT;
@@ -664,8 +667,9 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
     p->tile_bits = sat_tile_policy_bits(cfg->tile_policy);
     // the M-tail split lives where the row maps carry a row offset: 16-bit operand modes, "prepend" conditioning
     // (its side stream and events are created by sat_dit_plan_finalize: creating a plan touches no device)
-    p->tail_split = cfg->m_tail != 1 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln;
+    p->tail_split = cfg->m_tail != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln;
     p->tail_max = cfg->m_tail == 2 ? 255 : 64;
+    p->ln_fold = cfg->ln_fold != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
     return 0;
 }

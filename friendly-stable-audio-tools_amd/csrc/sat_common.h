@@ -330,6 +330,9 @@ struct GemmArgs {
     // workspace), used by this launch only; nullptr = the remainder round's tiles stay whole.
     float* slab;
     size_t slab_bytes;
+    // M the automatic tile choice is made for, if not this launch's own (0): the main launch of an M-tail split (dit_plan.hip, launch2) keeps the
+    // tiles measured for the whole problem -- 384 whole tiles score differently from 432 with a near-empty row, and the scores are calibrated on the latter
+    int m_choose;
 };
 
 // bf16 build: checks a.f16 and forwards fp16 work to sat_launch_gemm_f16 (the fp16 build of the same file)

@@ -79,12 +79,12 @@ class DiffusionTransformer(nn.Module):
         self.layernorm_fusion = True
         self.cross_attention_fusion = True
         self.tile_policy = 0
-        self.m_tail = int(os.environ.get("SAT_M_TAIL", "0"))         # sat_dit_cfg.m_tail: 0 = tail rows as a second launch (default), 1 = one launch per GEMM
+        self.m_tail = int(os.environ.get("SAT_M_TAIL", "0"))         # sat_dit_cfg.m_tail: 0 = one launch per GEMM (default), 1 / 2 = tail rows as a second launch (A/B)
 
     def set_m_tail(self, mode: int):
-        """Build extension, A/B switch (``sat_dit_cfg.m_tail``): 0 = every block GEMM runs on the rows of its whole 256-row tiles and the 2 (16)
-        rows left over of M = bf * 1025 as a second narrow-tile launch on the plan's side stream (default), 1 = one launch per GEMM.  Per model;
-        rebuilds the plan on next use."""
+        """Build extension, A/B switch (``sat_dit_cfg.m_tail``): 0 = one launch per GEMM (default); 1 = every block GEMM runs on the rows of its whole
+        256-row tiles and the 2 (16) rows left over of M = bf * 1025 as a second narrow-tile launch on the plan's side stream (measured slower,
+        profiles/r06_mtail_split.txt); 2 = the same for tails of any length (tests).  Per model; rebuilds the plan on next use."""
         if mode not in (0, 1, 2):
             raise ValueError("m_tail must be 0, 1 or 2 (2: tails of any length, tests)")
         if mode != self.m_tail:

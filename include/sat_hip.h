@@ -124,13 +124,12 @@ typedef struct sat_dit_cfg {
                                   1-2 instead of the 8-phase kernel, 81 = the 8-phase kernel also for fp32-output GEMMs with K < 4096, 82 = no
                                   two-K-group 128 x 128 tile */
     /* ---- version 6 (read by sat_dit_plan_create_sized only; sat_dit_plan_create defaults it to 0) */
-    int32_t m_tail;            /* 0 (default; gemm_dtype 0 / 3, adaln == 0): the block GEMMs run on the rows of their WHOLE 256-row tiles and the
-                                  rows left over (M = bf * (t_len + 1): 2 rows at one prompt, 16 at eight) run as a second, narrow-tile launch of
-                                  the same GEMM on a side stream the plan owns, beside the main launches -- the near-empty extra row of tiles cost
-                                  every GEMM 4-10 % (profiles/r06_mtail_pricing.txt).  Same arithmetic per row, so results are identical up to the
-                                  summation order of the tile that computes a row; the caller's stream is ordered behind the side stream before
-                                  the call returns control of it (fork / join through events; capturable).  Applies to tails of up to 64 rows.
-                                  1: one launch per GEMM (A/B); 2: any tail (1..255 rows) runs as the second launch (tests) */
+    int32_t m_tail;            /* M-tail split (round 6; an A/B switch -- measured SLOWER than the default, profiles/r06_mtail_split.txt).  M = bf * (t_len + 1)
+                                  is 8 (64) whole 256-row tiles plus 2 (16) rows, and the near-empty extra row of tiles costs every GEMM 1-10 %
+                                  (profiles/r06_mtail_pricing.txt).  0 (default): one launch per GEMM.  1 (gemm_dtype 0 / 3, adaln == 0): the block GEMMs run
+                                  on the rows of their WHOLE tiles, the rows left over (up to 64) as a second, narrow-tile launch of the same GEMM on a side
+                                  stream the plan owns; the caller's stream is ordered behind it (fork / join through events; capturable).  Same arithmetic
+                                  per row: results differ only by the summation order of the tile that computes a row.  2: any tail, 1..255 rows (tests) */
 } sat_dit_cfg;
 #define SAT_DIT_CFG_BYTES_V5 56          /* the layout sat_dit_plan_create reads: 14 int32 fields, up to and including tile_policy */
 

@@ -50,7 +50,7 @@ def main():
     from stable_audio_tools.models import _init
     new = _hip.lib()
     entries = {"r05": (load_old(os.path.join(ROOT, "tools", "ab", "libsat_hip_r05.so")), {})}
-    spec = os.environ.get("AB_SET", "one:m_tail=1,two:m_tail=0")
+    spec = os.environ.get("AB_SET", "r05b:old=1,r06:")
     for item in filter(None, spec.split(",")):
         name, _, kv = item.partition(":")
         raw = dict(p.split("=") for p in filter(None, kv.split(";")))

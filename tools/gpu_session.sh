@@ -42,6 +42,13 @@ case $stage in
       rm -rf $R/gpurun_out/${TAG}_pmc_$tag
     done
     head -4 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE_per_kernel.csv | cut -c1-200 ;;
+  clock)
+    # effective clock per kernel: GRBM_GUI_ACTIVE / wall (one counter, one pass, kernel trace only) at PROBE_B=$1 (default 1)
+    cd /tmp; export TMPDIR=/tmp; B=${1:-1}; rm -rf /tmp/clk_$TAG
+    PROBE_B=$B timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/clk_$TAG -- python $R/tools/gpu_probe.py full > $R/gpurun_out/${TAG}_clock_b$B.log 2>&1
+    c=$(find /tmp/clk_$TAG -name "*counter_collection.csv" | head -1); t=$(find /tmp/clk_$TAG -name "*kernel_trace.csv" | head -1)
+    head -2 $c > $R/gpurun_out/${TAG}_clock_b${B}_csv_head.txt
+    python $R/tools/pmc_clock.py $c $t > $R/gpurun_out/${TAG}_clock_b$B.md 2>&1; head -14 $R/gpurun_out/${TAG}_clock_b$B.md | cut -c1-220 ;;
   ab)
     timeout 1200 python tools/ab_r05.py "$@" > gpurun_out/${TAG}_ab_r05.log 2>&1; tail -6 gpurun_out/${TAG}_ab_r05.log ;;
   ab4)
