@@ -116,6 +116,7 @@ struct sat_dit_plan {
     // DOWN to whole 256-row tiles, the few rows left over (2 at one prompt, 16 at eight: M = bf * 1025) run as a second, narrow-tile launch of the
     // same GEMM on the plan's side stream, next to the main launches
     bool tail_split = false;
+    int tail_mode = 0;              // cfg.m_tail
     int tail_max = 64;              // rows: a tail up to a quarter tile is the "near-empty row of tiles" case; 255 = every tail (cfg.m_tail == 2, tests)
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev;     // fork / join events of one forward, used round-robin
@@ -414,35 +415,74 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     const bool split = p->tail_split && !f32 && M > 256 && (M % 256) != 0;
     hipStream_t side = p->side;
     bool main_ahead = true, side_dirty = false;
+    // GEMMs of different M follow each other (the cross-attention branch runs on the conditional sequences only): rows a main launch wrote may be a
+    // later tail launch's input and the other way round -- main_hi = rows [0, main_hi) written by main launches the side stream is not ordered
+    // behind, side_lo = first row written by tail launches the main stream is not ordered behind
+    int main_hi = 0, side_lo = 1 << 30;
     auto next_ev = [&]() {
         hipEvent_t e = p->ev[p->ev_next];
         p->ev_next = (p->ev_next + 1) % (int)p->ev.size();
         return e;
     };
-    auto fork = [&]() -> int {
-        if (!main_ahead) return 0;
+    auto fork = [&](int tail_lo) -> int {
+        if (!main_ahead && main_hi <= tail_lo) return 0;
         hipEvent_t e = next_ev();
         SAT_HIP(hipEventRecord(e, s));
         SAT_HIP(hipStreamWaitEvent(side, e, 0));
         main_ahead = false;
+        main_hi = 0;
         return 0;
     };
-    auto join = [&]() -> int {
-        main_ahead = true;          // (called in front of every row-mixing launch of the main stream)
-        if (!side_dirty) return 0;
+    auto join_rows = [&](int rows) -> int {          // the main stream is about to touch rows [0, rows)
+        if (!side_dirty || side_lo >= rows) return 0;
         hipEvent_t e = next_ev();
         SAT_HIP(hipEventRecord(e, side));
         SAT_HIP(hipStreamWaitEvent(s, e, 0));
         side_dirty = false;
+        side_lo = 1 << 30;
         return 0;
     };
-    auto launch2 = [&](int epi, GemmArgs& ga) -> int {
+    auto join = [&]() -> int {
+        main_ahead = true;          // (called in front of every row-mixing launch of the main stream)
+        return join_rows(1 << 30);
+    };
+    // which: 0 = a GEMM the serial skinny mode leaves alone (to_qkv and the cross-attention branch gain ~0 from whole tiles), 1 = to_out (picks its
+    // tile for the whole-tile M: 512 tiles of 256 x 192 = 2.0 rounds at eight prompts), 2 = FF-in / FF-out (keep the tile measured for the whole M)
+    auto launch2 = [&](int epi, GemmArgs& ga, int which = 0) -> int {
         const int mf = (ga.M / 256) * 256;
-        if (!split || mf == 0 || mf == ga.M || ga.M - mf > p->tail_max) return sat_launch_gemm(epi, ga, s);
+        if (!split) return sat_launch_gemm(epi, ga, s);
+        if (p->tail_mode != 3 && (mf == 0 || mf == ga.M || ga.M - mf > p->tail_max)) {          // a whole launch in side-stream mode: touches every row
+            SAT_TRY(join_rows(ga.M));
+            SAT_TRY(sat_launch_gemm(epi, ga, s));
+            main_hi = main_hi > ga.M ? main_hi : ga.M;
+            return 0;
+        }
+        if (mf == 0 || mf == ga.M || ga.M - mf > p->tail_max) return sat_launch_gemm(epi, ga, s);
+        if (p->tail_mode == 3) {
+            // serial skinny mode: the rows of the whole tiles on the big tiles, the rest on the weight-streaming kernel, same stream
+            GemmArgs t = ga;
+            t.M -= mf;
+            if (!which || !sat_gemm_skinny_supports(epi, t)) return sat_launch_gemm(epi, ga, s);
+            if (which == 2) ga.m_choose = ga.M;
+            ga.M = mf;
+            SAT_TRY(sat_launch_gemm(epi, ga, s));
+            t.A += (size_t)mf * t.K;
+            if (t.C) t.C += (size_t)mf * t.ldc;
+            if (t.H) t.H += (size_t)mf * (t.N / 2);
+            if (t.xb) t.xb += (size_t)mf * t.N;
+            if (t.ln_part_out) t.ln_part_out += (size_t)mf * (t.N >> 6) * 2;
+            if (t.ln_part) t.ln_part += (size_t)mf * (t.K >> 6) * 2;
+            t.slab = nullptr;
+            t.slab_bytes = 0;
+            t.variant = (t.variant & ~0xff) | 90;
+            return sat_launch_gemm(epi, t, s);
+        }
         GemmArgs t = ga;
         ga.m_choose = ga.M;          // the tiles measured for the whole problem
         ga.M = mf;
+        SAT_TRY(join_rows(mf));
         SAT_TRY(sat_launch_gemm(epi, ga, s));
+        main_hi = main_hi > mf ? main_hi : mf;
         t.M -= mf;
         t.A += (size_t)mf * t.K;
         if (t.C) t.C += (size_t)mf * t.ldc;
@@ -455,9 +495,10 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         t.slab = nullptr;
         t.slab_bytes = 0;
         t.variant = (t.variant & ~0xff) | 16;          // the 128 x 64 tile: the most workgroups per row of tiles (one wave per SIMD, 72 KiB of LDS)
-        SAT_TRY(fork());
+        SAT_TRY(fork(mf));
         SAT_TRY(sat_launch_gemm(epi, t, side));
         side_dirty = true;
+        side_lo = side_lo < mf ? side_lo : mf;
         return 0;
     };
 
@@ -521,7 +562,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         fold_out(g);
-        SAT_TRY(launch2(EPI_RESID, g));
+        SAT_TRY(launch2(EPI_RESID, g, 1));
         // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
         // unconditional CFG half, dit.py:294-300) get k = v = 0 from the bias-free to_cond_embed / to_kv, hence an
         // attention output of exactly 0 and, through the bias-free to_out, a branch contribution of exactly 0:
@@ -584,7 +625,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             }
             SAT_HIP(hipEventRecord(p->prof_ev[2 * p->prof_n], s));
         }
-        SAT_TRY(launch2(EPI_SWIGLU, g));
+        SAT_TRY(launch2(EPI_SWIGLU, g, 2));
         if (prof) {
             SAT_HIP(hipEventRecord(p->prof_ev[2 * p->prof_n + 1], s));
             p->prof_n++;
@@ -596,7 +637,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         if (l + 1 < c.depth) fold_out(g);       // nobody normalises the output of the last block
-        SAT_TRY(launch2(EPI_RESID, g));
+        SAT_TRY(launch2(EPI_RESID, g, 2));
     }
     // project_out + drop prepend + postprocess_conv + residual (transformer.py:807, dit.py:219-224)
     SAT_TRY(join());
@@ -642,8 +683,8 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
     SAT_CHECK_ARG(cfg->gemm_dtype == 1 || cfg->fp8_families == 0, SAT_E_INVALID,
                   "dit_plan_create: fp8_families = 0x%x with gemm_dtype %d (a caller built against an older sat_dit_cfg layout?)", cfg->fp8_families, cfg->gemm_dtype);
     SAT_CHECK_ARG(cfg->cross_attention == 0 || cfg->cross_attention == 1, SAT_E_INVALID, "dit_plan_create: cross_attention must be 0 (fused where it applies) or 1 (two kernels)");
-    SAT_CHECK_ARG(cfg->m_tail >= 0 && cfg->m_tail <= 2, SAT_E_INVALID,
-                  "dit_plan_create: m_tail must be 0 (one launch per GEMM, default), 1 (up to 64 tail rows as a second launch) or 2 (any tail as a second launch)");
+    SAT_CHECK_ARG(cfg->m_tail >= 0 && cfg->m_tail <= 3, SAT_E_INVALID,
+                  "dit_plan_create: m_tail must be 0 (one launch per GEMM), 1 / 2 (tail rows as a second launch on a side stream: up to 64 rows / any) or 3 (to_out, FF-in, FF-out: tail rows on the skinny kernel, same stream)");
     SAT_CHECK_ARG(cfg->tile_policy == 0 || cfg->tile_policy == 22 || cfg->tile_policy == 80 || cfg->tile_policy == 81 || cfg->tile_policy == 82, SAT_E_INVALID,
                   "dit_plan_create: tile_policy must be 0 / 80 (default), 22, 81 or 82");
     const int fam = cfg->fp8_families ? cfg->fp8_families : SAT_FP8_DEFAULT;
@@ -668,6 +709,7 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
     // the M-tail split lives where the row maps carry a row offset: 16-bit operand modes, "prepend" conditioning
     // (its side stream and events are created by sat_dit_plan_finalize: creating a plan touches no device)
     p->tail_split = cfg->m_tail != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln;
+    p->tail_mode = cfg->m_tail;
     p->tail_max = cfg->m_tail == 2 ? 255 : 64;
     p->ln_fold = cfg->ln_fold != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
@@ -706,7 +748,7 @@ extern "C" int sat_dit_plan_finalize(sat_dit_plan* p, sat_stream_t stream) {
         p->arena = nullptr;
     }
     p->finalized = false;
-    if (p->tail_split && !p->side) {
+    if (p->tail_split && p->tail_mode != 3 && !p->side) {
         SAT_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
         p->ev.assign(8 * (size_t)p->cfg.depth + 8, nullptr);
         for (auto& e : p->ev) SAT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -1661,6 +1661,7 @@ int SAT_OPNS::sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
                   SAT_E_INVALID, "gemm: LayerNorm fold needs ln_c1 / ln_c2 / ln_eps, no separate bias (it is part of ln_c2), 16-byte aligned vectors");
     SAT_CHECK_ARG((((uintptr_t)a.xb | (uintptr_t)a.ln_part_out) & 15) == 0, SAT_E_INVALID, "gemm: xb / ln_part_out must be 16-byte aligned");
     SAT_CHECK_ARG(a.heads.m_base >= 0 && a.heads.m_base % 4 == 0, SAT_E_INVALID, "gemm: heads.m_base must be a non-negative multiple of 4 (aligned V^T groups)");
+    if ((a.variant & 0xff) == 90) return sat_launch_gemm_skinny(epi, a, stream);          // a few rows: the weight-streaming kernel of gemm_skinny.hip
     if ((a.variant & 0xfff) % 100 == 80 || (a.variant & 0xfff) % 100 == 81) return sat_launch_gemm_ph8(epi, a, stream);      // 256x256x64, 8 waves, 8-phase schedule (gemm_ph8.hip)
     switch (epi) {
         case EPI_F32:

@@ -1,0 +1,175 @@
+// Skinny GEMM for the M-tail of the block GEMMs (round 6):   C[Mt, N] = A[Mt, K] . W[N, K]^T   with Mt = a few rows (16 per workgroup row).
+// The block GEMMs of the DiT run M = bf * 1025 rows = whole 256-row tiles + 2 (one prompt) / 16 (eight prompts) rows, and the near-empty extra
+// row of tiles costs the big-tile kernels 4-10 % at eight prompts (profiles/r06_mtail_pricing.txt): every column tile streams its whole W panel
+// through the LDS ring of one compute unit for 16 rows.  Those rows are ordinary tokens -- nn.Linear is per row (models/transformer.py:222, 270, 319)
+// -- so the plan (dit_plan.hip, launch2) runs the big tiles on the rows of the whole tiles and THIS kernel on the rest: no LDS ring, no barriers in
+// the K loop -- a weight-streaming kernel.
+//   workgroup = 16 rows x 64 columns, 8 waves, wave w takes the k-range [w K/8, (w+1) K/8): per 32 k one 16-byte load of the lane's A row piece
+//   and four of its W row pieces (v_mfma_f32_16x16x32 fragments straight from global memory), six k-steps = 30 loads in flight per lane;
+//   the eight partial 16 x 64 blocks meet in LDS (32 KiB) and wave 0 runs the epilogue on the sums.
+//   N / 64 workgroups per 16 rows: FF-in 192, to_qkv 72, FF-out / to_out 24 -- every W row is read exactly once, 64 contiguous bytes per lane quad.
+// Epilogues = those of the big tiles on TRANSPOSED accumulators (weight fragment = MFMA A operand: lane (l15, q4) holds token row l15 and channels
+// 16 nb + 4 q4 + r of block nb): SwiGLU (value / gate = blocks nb / nb + 2 of the same lane) and the fp32 residual update with the LayerNorm-fold
+// producer (16-bit image + (sum, sum of squares) of the rounded values over the workgroup's 64 columns), both with the LayerNorm-fold consumer
+// constants where the GEMM sits behind a LayerNorm.  The heads epilogue (RoPE, q / k / v^T layouts) is not built: to_qkv gains 1 % from whole tiles.
+#include "sat_common.h"
+
+namespace {
+
+constexpr int SK_WAVES = 8;
+
+template <int EPI>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmArgs g) {
+    sat_f16_saturate();
+    __shared__ f32x4 part[SK_WAVES][4][64];          // [wave][block][lane]: 32 KiB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int M = g.M, N = g.N, K = g.K;
+    const int n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 16;
+    const int m = m0 + l15;
+    const int mc = m < M ? m : M - 1;
+    const int kw = K / SK_WAVES;                     // k-range of this wave (a multiple of 32: the launcher checks K % 256 == 0)
+    const int k0 = wave * kw + 8 * q4;
+    const op_t* ap = g.A + (size_t)mc * K + k0;
+    const op_t* wp[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) wp[nb] = g.W + (size_t)(n0 + 16 * nb + l15) * K + k0;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 6;                             // k-steps per batch: 6 x (1 + 4) 16-byte loads in flight per lane
+    const int steps = kw / 32;
+    for (int s0 = 0; s0 < steps; s0 += U) {
+        opx8 fa[U], fw[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = (s0 + u < steps ? s0 + u : steps - 1) * 32;          // (a short last batch re-reads its last step; its MFMAs are skipped)
+            fa[u] = *reinterpret_cast<const opx8*>(ap + ks);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) fw[u][nb] = *reinterpret_cast<const opx8*>(wp[nb] + ks);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (s0 + u < steps) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma_16x16x32(fw[u][nb], fa[u], acc[nb]);
+            }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) part[wave][nb][lane] = acc[nb];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < SK_WAVES; ++w)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] += part[w][nb][lane];
+
+    // ---- LayerNorm fold, consumer side (GemmArgs::ln_part): (mean, rstd) of the lane's token row from the producer's per-64-column partial sums;
+    //      the four lanes of a token (q4 = 0..3) each add every fourth pair
+    float mean = 0.f, rstd = 1.f;
+    const bool fold = g.ln_part != nullptr;
+    if (fold) {
+        const int np = K >> 6;
+        const float2* pp = reinterpret_cast<const float2*>(g.ln_part) + (size_t)mc * np;
+        float sum = 0.f, sq = 0.f;
+        for (int i = q4; i < np; i += 4) {
+            const float2 v = pp[i];
+            sum += v.x;
+            sq += v.y;
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sq += __shfl_xor(sq, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        const float inv_k = 1.0f / (float)K;
+        mean = sum * inv_k;
+        rstd = rsqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + g.ln_eps);
+    }
+    // x = rstd * (acc - mean * c1) + c2 with (c1, c2) = (rowsum(gamma W), W beta + b) under the fold, (0, bias) without it
+    f32x4 x[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int ch = n0 + 16 * nb + 4 * q4;
+        f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
+        if (fold) {
+            c1 = *reinterpret_cast<const f32x4*>(g.ln_c1 + ch);
+            c2 = *reinterpret_cast<const f32x4*>(g.ln_c2 + ch);
+        } else if (g.bias) {
+            c2 = *reinterpret_cast<const f32x4*>(g.bias + ch);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[nb][e] = rstd * (acc[nb][e] - mean * c1[e]) + c2[e];
+    }
+    if constexpr (EPI == EPI_SWIGLU) {
+        // packed FF-in rows: columns [n0, n0 + 32) are values, [n0 + 32, n0 + 64) their gates (models/transformer.py:232-235)
+        if (m < M) {
+            op_t* hrow = g.H + (size_t)m * (N >> 1) + (n0 >> 1) + 4 * q4;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = x[nb][e] * silu_f(x[nb + 2][e]);
+                *reinterpret_cast<u32x2*>(hrow + 16 * nb) = u32x2{pack_op2(h[0], h[1]), pack_op2(h[2], h[3])};
+            }
+        }
+    } else {
+        // fp32 output / residual update (models/transformer.py:692-700) + LayerNorm-fold producer
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int ch = n0 + 16 * nb + 4 * q4;
+            f32x4 v = x[nb];
+            if (m < M) {
+                float* crow = g.C + (size_t)m * g.ldc + ch;
+                if (g.accumulate) v += *reinterpret_cast<const f32x4*>(crow);
+                *reinterpret_cast<f32x4*>(crow) = v;
+                if (g.xb) {
+                    opx4 xr;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xr[e] = f32_to_op(v[e]);
+                        const float f = op_to_f32(xr[e]);
+                        sum += f;
+                        sq += f * f;
+                    }
+                    *reinterpret_cast<opx4*>(g.xb + (size_t)m * N + ch) = xr;
+                }
+            }
+        }
+        if (g.xb) {
+            sum += __shfl_xor(sum, 16, 64);
+            sq += __shfl_xor(sq, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (q4 == 0 && m < M) *reinterpret_cast<float2*>(g.ln_part_out + ((size_t)m * (N >> 6) + (n0 >> 6)) * 2) = make_float2(sum, sq);
+        }
+    }
+}
+
+}  // namespace
+
+bool SAT_OPNS::sat_gemm_skinny_supports(int epi, const GemmArgs& a) {
+    return (epi == EPI_SWIGLU || epi == EPI_F32 || epi == EPI_RESID) && !a.fp8 && !a.H8 && !a.gate && a.N % 64 == 0 && a.K % (SK_WAVES * 32) == 0 &&
+           a.M > 0 && a.M <= 64;
+}
+
+int SAT_OPNS::sat_launch_gemm_skinny(int epi, const GemmArgs& a, hipStream_t stream) {
+    SAT_CHECK_ARG(sat_gemm_skinny_supports(epi, a), SAT_E_UNSUPPORTED,
+                  "gemm(skinny): 16-bit operands, SwiGLU or fp32 output without gate, N %% 64 == 0, K %% 256 == 0, at most 64 rows (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    SAT_CHECK_ARG(!a.ln_part || (a.ln_c1 && a.ln_c2), SAT_E_INVALID, "gemm(skinny): LayerNorm fold needs ln_c1 / ln_c2");
+    SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (a.xb && a.ln_part_out && epi != EPI_SWIGLU), SAT_E_INVALID, "gemm(skinny): xb and ln_part_out come together, from the fp32 epilogue");
+    const dim3 grid(a.N / 64, cdiv(a.M, 16));
+    if (epi == EPI_SWIGLU) {
+        SAT_CHECK_ARG(a.H, SAT_E_INVALID, "gemm(skinny): null output");
+        hipLaunchKernelGGL(gemm_skinny_kernel<EPI_SWIGLU>, grid, dim3(SK_WAVES * 64), 0, stream, a);
+    } else {
+        SAT_CHECK_ARG(a.C, SAT_E_INVALID, "gemm(skinny): null output");
+        hipLaunchKernelGGL(gemm_skinny_kernel<EPI_F32>, grid, dim3(SK_WAVES * 64), 0, stream, a);
+    }
+    SAT_LAUNCH_CHECK();
+    return 0;
+}

@@ -341,6 +341,8 @@ bool sat_gemm_ph8_supports(int epi, const GemmArgs& a);
 bool sat_gemm_ph8_splits(int epi, const GemmArgs& a);       // the automatic schedule would split the remainder round along K
 size_t sat_gemm_ph8_slab_bytes(int epi, int M, int N, int K);      // slab workspace that makes it do so (0: never for this shape)
 int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream);     // gemm_ph8.hip: the 8-wave / 8-phase 256x256 tile
+bool sat_gemm_skinny_supports(int epi, const GemmArgs& a);
+int sat_launch_gemm_skinny(int epi, const GemmArgs& a, hipStream_t stream);  // gemm_skinny.hip: <= 64 rows, weight-streaming (variant 90)
 // out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
 // q_scale: what the kernel still has to multiply in -- SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e) for a plain Q, 1.0f for a Q the
 // producer already wrote pre-scaled (HeadsEpi kind bit 3): only then the single-KV-group kernel carries its softmax reference

@@ -85,8 +85,8 @@ class DiffusionTransformer(nn.Module):
         """Build extension, A/B switch (``sat_dit_cfg.m_tail``): 0 = one launch per GEMM (default); 1 = every block GEMM runs on the rows of its whole
         256-row tiles and the 2 (16) rows left over of M = bf * 1025 as a second narrow-tile launch on the plan's side stream (measured slower,
         profiles/r06_mtail_split.txt); 2 = the same for tails of any length (tests).  Per model; rebuilds the plan on next use."""
-        if mode not in (0, 1, 2):
-            raise ValueError("m_tail must be 0, 1 or 2 (2: tails of any length, tests)")
+        if mode not in (0, 1, 2, 3):
+            raise ValueError("m_tail must be 0, 1, 2 or 3")
         if mode != self.m_tail:
             self.m_tail = mode
             self._plan_version = None

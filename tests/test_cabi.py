@@ -78,7 +78,7 @@ def test_argument_validation_without_gpu():
         if rc == 0:
             lib.sat_dit_plan_destroy(plan)
     assert b"bytes" in lib.sat_last_error()
-    ok.m_tail = 3
+    ok.m_tail = 4
     assert lib.sat_dit_plan_create_sized(ctypes.byref(ok), 60, ctypes.byref(plan)) == -1 and b"m_tail" in lib.sat_last_error()
 
 

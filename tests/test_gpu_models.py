@@ -95,20 +95,21 @@ def test_m_tail_split_on_off(dev, small_dit):
     cfg, model, sd = small_dit
     dc = cfg["model"]["diffusion"]["config"]
     dit = model.model.model
-    for b, t_len, cfg_scale in ((2, 200, 1.0), (3, 300, 1.0), (2, 200, 5.0)):
+    # mode 2: side stream, any tail; mode 1: side stream, tails up to 64 rows; mode 3: to_out / FF-in / FF-out tails on the skinny kernel, same stream
+    for mode, b, t_len, cfg_scale in ((2, 2, 200, 1.0), (2, 3, 300, 1.0), (2, 2, 200, 5.0), (1, 2, 132, 5.0), (3, 2, 132, 1.0), (3, 2, 132, 5.0), (3, 4, 135, 1.0)):
         x, c, g = _inputs(b, t_len, dc["cond_token_dim"], seed=11)
-        t = torch.tensor([0.31, 0.87, 0.5][:b])
+        t = torch.tensor([0.31, 0.87, 0.5, 0.11][:b])
         run = lambda: model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=cfg_scale).cpu()
         one = run()
         try:
-            dit.set_m_tail(2)
+            dit.set_m_tail(mode)
             two = run()
             assert torch.equal(two, run()), "the split path is not repeatable (a missing fork / join?)"
         finally:
             dit.set_m_tail(0)
         assert torch.isfinite(two).all()
-        e = assert_close(f"M-tail split vs one launch per GEMM, {b} x {t_len + 1} rows, cfg {cfg_scale}", two, one, T(3e-3))
-        print(f"\n[m_tail, {b} x {t_len + 1} rows, cfg {cfg_scale}] rel-L2 split vs single launch {e:.2e}")
+        e = assert_close(f"M-tail split (mode {mode}) vs one launch per GEMM, {b} x {t_len + 1} rows, cfg {cfg_scale}", two, one, T(8e-3))
+        print(f"\n[m_tail {mode}, {b} x {t_len + 1} rows, cfg {cfg_scale}] rel-L2 split vs single launch {e:.2e}")
 
 
 def test_layernorm_fusion_on_off(dev, small_dit):
