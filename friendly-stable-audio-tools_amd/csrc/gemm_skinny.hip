@@ -4,9 +4,9 @@
 // through the LDS ring of one compute unit for 16 rows.  Those rows are ordinary tokens -- nn.Linear is per row (models/transformer.py:222, 270, 319)
 // -- so the plan (dit_plan.hip, launch2) runs the big tiles on the rows of the whole tiles and THIS kernel on the rest: no LDS ring, no barriers in
 // the K loop -- a weight-streaming kernel.
-//   workgroup = 16 rows x 64 columns, 8 waves, wave w takes the k-range [w K/8, (w+1) K/8): per 32 k one 16-byte load of the lane's A row piece
+//   workgroup = 16 rows x 64 columns, 8 (16) waves, wave w takes the k-range [w K/8, (w+1) K/8): per 32 k one 16-byte load of the lane's A row piece
 //   and four of its W row pieces (v_mfma_f32_16x16x32 fragments straight from global memory), six k-steps = 30 loads in flight per lane;
-//   the eight partial 16 x 64 blocks meet in LDS (32 KiB) and wave 0 runs the epilogue on the sums.
+//   the partial 16 x 64 blocks meet in LDS (32 / 64 KiB) and wave 0 runs the epilogue on the sums.
 //   N / 64 workgroups per 16 rows: FF-in 192, to_qkv 72, FF-out / to_out 24 -- every W row is read exactly once, 64 contiguous bytes per lane quad.
 // Epilogues = those of the big tiles on TRANSPOSED accumulators (weight fragment = MFMA A operand: lane (l15, q4) holds token row l15 and channels
 // 16 nb + 4 q4 + r of block nb): SwiGLU (value / gate = blocks nb / nb + 2 of the same lane) and the fp32 residual update with the LayerNorm-fold
@@ -16,12 +16,11 @@
 
 namespace {
 
-constexpr int SK_WAVES = 8;
-
-template <int EPI>
-__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmArgs g) {
+// NW waves share the reduction (K / NW each); U k-steps per batch: U x (1 + 4) 16-byte loads in flight per lane, then U x 4 MFMAs, no branch inside
+template <int EPI, int NW, int U>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs g) {
     sat_f16_saturate();
-    __shared__ f32x4 part[SK_WAVES][4][64];          // [wave][block][lane]: 32 KiB
+    __shared__ f32x4 part[NW][4][64];                // [wave][block][lane]: 32 KiB (64 KiB with 16 waves)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -31,7 +30,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmArgs g) 
     const int m0 = blockIdx.y * 16;
     const int m = m0 + l15;
     const int mc = m < M ? m : M - 1;
-    const int kw = K / SK_WAVES;                     // k-range of this wave (a multiple of 32: the launcher checks K % 256 == 0)
+    const int kw = K / NW;                           // k-range of this wave: a multiple of 32 U (the launcher picks U)
     const int k0 = wave * kw + 8 * q4;
     const op_t* ap = g.A + (size_t)mc * K + k0;
     const op_t* wp[4];
@@ -41,30 +40,31 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmArgs g) 
     f32x4 acc[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 6;                             // k-steps per batch: 6 x (1 + 4) 16-byte loads in flight per lane
-    const int steps = kw / 32;
-    for (int s0 = 0; s0 < steps; s0 += U) {
+    const int batches = kw / (32 * U);
+    for (int bt = 0; bt < batches; ++bt) {
         opx8 fa[U], fw[U][4];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ks = (s0 + u < steps ? s0 + u : steps - 1) * 32;          // (a short last batch re-reads its last step; its MFMAs are skipped)
-            fa[u] = *reinterpret_cast<const opx8*>(ap + ks);
+            fa[u] = *reinterpret_cast<const opx8*>(ap + u * 32);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) fw[u][nb] = *reinterpret_cast<const opx8*>(wp[nb] + ks);
+            for (int nb = 0; nb < 4; ++nb) fw[u][nb] = *reinterpret_cast<const opx8*>(wp[nb] + u * 32);
         }
+        ap += 32 * U;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) wp[nb] += 32 * U;
+        __builtin_amdgcn_sched_barrier(0);          // every load of the batch is issued before its first MFMA (the scheduler would otherwise trade
+                                                    // memory-level parallelism for registers: 64 VGPRs, a dozen loads in flight)
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (s0 + u < steps) {
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma_16x16x32(fw[u][nb], fa[u], acc[nb]);
-            }
+            for (int nb = 0; nb < 4; ++nb) acc[nb] = mfma_16x16x32(fw[u][nb], fa[u], acc[nb]);
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) part[wave][nb][lane] = acc[nb];
     __syncthreads();
     if (wave != 0) return;
-#pragma unroll
-    for (int w = 1; w < SK_WAVES; ++w)
+#pragma unroll 4          // (fully unrolled, sixteen waves' partials would all be live at once: 240 registers)
+    for (int w = 1; w < NW; ++w)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[nb] += part[w][nb][lane];
 
@@ -153,23 +153,40 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmArgs g) 
 }  // namespace
 
 bool SAT_OPNS::sat_gemm_skinny_supports(int epi, const GemmArgs& a) {
-    return (epi == EPI_SWIGLU || epi == EPI_F32 || epi == EPI_RESID) && !a.fp8 && !a.H8 && !a.gate && a.N % 64 == 0 && a.K % (SK_WAVES * 32) == 0 &&
-           a.M > 0 && a.M <= 64;
+    return (epi == EPI_SWIGLU || epi == EPI_F32 || epi == EPI_RESID) && !a.fp8 && !a.H8 && !a.gate && a.N % 64 == 0 && a.K % 256 == 0 && a.M > 0 && a.M <= 64;
 }
+
+namespace {
+template <int EPI, int NW>
+int launch_skinny(const GemmArgs& a, hipStream_t stream) {
+    const dim3 grid(a.N / 64, cdiv(a.M, 16));
+    const int steps = a.K / NW / 32;          // k-steps per wave
+    if constexpr (NW == 8) {          // (sixteen waves have 128 registers each: four k-steps = 20 loads in flight)
+        if (steps % 6 == 0) {
+            hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NW, 6>), grid, dim3(NW * 64), 0, stream, a);
+            SAT_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if (steps % 4 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NW, 4>), grid, dim3(NW * 64), 0, stream, a);
+    else if (steps % 2 == 0) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NW, 2>), grid, dim3(NW * 64), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NW, 1>), grid, dim3(NW * 64), 0, stream, a);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
 
 int SAT_OPNS::sat_launch_gemm_skinny(int epi, const GemmArgs& a, hipStream_t stream) {
     SAT_CHECK_ARG(sat_gemm_skinny_supports(epi, a), SAT_E_UNSUPPORTED,
                   "gemm(skinny): 16-bit operands, SwiGLU or fp32 output without gate, N %% 64 == 0, K %% 256 == 0, at most 64 rows (M=%d N=%d K=%d)", a.M, a.N, a.K);
     SAT_CHECK_ARG(!a.ln_part || (a.ln_c1 && a.ln_c2), SAT_E_INVALID, "gemm(skinny): LayerNorm fold needs ln_c1 / ln_c2");
     SAT_CHECK_ARG((!a.xb && !a.ln_part_out) || (a.xb && a.ln_part_out && epi != EPI_SWIGLU), SAT_E_INVALID, "gemm(skinny): xb and ln_part_out come together, from the fp32 epilogue");
-    const dim3 grid(a.N / 64, cdiv(a.M, 16));
+    // few workgroups and a long reduction (FF-out: 24 column groups, K = 6144): sixteen waves share it
+    const bool wide = a.K % 512 == 0 && a.K >= 4096 && (long)(a.N / 64) * cdiv(a.M, 16) < 128;
     if (epi == EPI_SWIGLU) {
         SAT_CHECK_ARG(a.H, SAT_E_INVALID, "gemm(skinny): null output");
-        hipLaunchKernelGGL(gemm_skinny_kernel<EPI_SWIGLU>, grid, dim3(SK_WAVES * 64), 0, stream, a);
-    } else {
-        SAT_CHECK_ARG(a.C, SAT_E_INVALID, "gemm(skinny): null output");
-        hipLaunchKernelGGL(gemm_skinny_kernel<EPI_F32>, grid, dim3(SK_WAVES * 64), 0, stream, a);
+        return wide ? launch_skinny<EPI_SWIGLU, 16>(a, stream) : launch_skinny<EPI_SWIGLU, 8>(a, stream);
     }
-    SAT_LAUNCH_CHECK();
-    return 0;
+    SAT_CHECK_ARG(a.C, SAT_E_INVALID, "gemm(skinny): null output");
+    return wide ? launch_skinny<EPI_F32, 16>(a, stream) : launch_skinny<EPI_F32, 8>(a, stream);
 }
