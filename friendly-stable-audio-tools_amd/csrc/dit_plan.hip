@@ -112,15 +112,6 @@ struct sat_dit_plan {
     int f16 = 0;                    // cfg.gemm_dtype == 3: every 16-bit operand buffer holds IEEE fp16 and the fp16 build of the kernels runs
     bool cross_fusion = true;       // cfg.cross_attention == 0: to_q + cross-attention core in one launch where it applies
     int tile_bits = 0;              // cfg.tile_policy as GemmArgs::variant bits (sat_tile_policy_bits)
-    // cfg.m_tail != 0 (round 6, opt-in: measured slower than one launch per GEMM, profiles/r06_mtail_split.txt): the block GEMMs run on M rounded
-    // DOWN to whole 256-row tiles, the few rows left over (2 at one prompt, 16 at eight: M = bf * 1025) run as a second, narrow-tile launch of the
-    // same GEMM on the plan's side stream, next to the main launches
-    bool tail_split = false;
-    int tail_mode = 0;              // cfg.m_tail
-    int tail_max = 64;              // rows: a tail up to a quarter tile is the "near-empty row of tiles" case; 255 = every tail (cfg.m_tail == 2, tests)
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> ev;     // fork / join events of one forward, used round-robin
-    int ev_next = 0;
     bool ln_fold = false;           // cfg.ln_fold, bf16 / fp16 operands, "prepend" conditioning: LayerNorms run inside the GEMM epilogues
     int fp8_mode = 2;               // 2: v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, 2x rate); 1: v_mfma_f32_32x32x16_fp8_fp8
     // gemm_dtype == 1: which GEMM families take e4m3 operands (sat_dit_cfg.fp8_families; SAT_FP8_* bits); 0 in every other mode
@@ -404,104 +395,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     // preprocess_conv + residual + project_in (dit.py:197-199, transformer.py:778)
     SAT_TRY(glue_input_proj(x, p->win_eff, w.X, bf, xB, C, T, S, D, xscale, s));
 
-    // ---- M-tail split (sat_dit_cfg.m_tail, round 6; pricing: profiles/r06_mtail_pricing.txt).  M = bf * 1025 is 8 (64) whole 256-row tiles
-    // plus 2 (16) rows, and that ninth (65th) row of near-empty tiles costs every block GEMM 4-10 %: the whole W panel streams through a
-    // compute unit for 2 rows.  So a GEMM runs on the rows of its whole tiles, and the rows left over -- ordinary tokens: everything between
-    // two attention launches is per token -- run as a SECOND launch of the same GEMM (row offset HeadsEpi::m_base, narrow tiles) on the
-    // plan's side stream, beside the main launches.  The two streams meet where rows meet: the side stream is ordered behind the main
-    // stream's last row-mixing launch (attention, a standalone LayerNorm, the input projection) before a tail launch (`fork`), the main
-    // stream behind the tail launches before the next such launch (`join`).  Capturable (fork / join through events); a plan serves one
-    // caller stream at a time.
-    const bool split = p->tail_split && !f32 && M > 256 && (M % 256) != 0;
-    hipStream_t side = p->side;
-    bool main_ahead = true, side_dirty = false;
-    // GEMMs of different M follow each other (the cross-attention branch runs on the conditional sequences only): rows a main launch wrote may be a
-    // later tail launch's input and the other way round -- main_hi = rows [0, main_hi) written by main launches the side stream is not ordered
-    // behind, side_lo = first row written by tail launches the main stream is not ordered behind
-    int main_hi = 0, side_lo = 1 << 30;
-    auto next_ev = [&]() {
-        hipEvent_t e = p->ev[p->ev_next];
-        p->ev_next = (p->ev_next + 1) % (int)p->ev.size();
-        return e;
-    };
-    auto fork = [&](int tail_lo) -> int {
-        if (!main_ahead && main_hi <= tail_lo) return 0;
-        hipEvent_t e = next_ev();
-        SAT_HIP(hipEventRecord(e, s));
-        SAT_HIP(hipStreamWaitEvent(side, e, 0));
-        main_ahead = false;
-        main_hi = 0;
-        return 0;
-    };
-    auto join_rows = [&](int rows) -> int {          // the main stream is about to touch rows [0, rows)
-        if (!side_dirty || side_lo >= rows) return 0;
-        hipEvent_t e = next_ev();
-        SAT_HIP(hipEventRecord(e, side));
-        SAT_HIP(hipStreamWaitEvent(s, e, 0));
-        side_dirty = false;
-        side_lo = 1 << 30;
-        return 0;
-    };
-    auto join = [&]() -> int {
-        main_ahead = true;          // (called in front of every row-mixing launch of the main stream)
-        return join_rows(1 << 30);
-    };
-    // which: 0 = a GEMM the serial skinny mode leaves alone (to_qkv and the cross-attention branch gain ~0 from whole tiles), 1 = to_out (picks its
-    // tile for the whole-tile M: 512 tiles of 256 x 192 = 2.0 rounds at eight prompts), 2 = FF-in / FF-out (keep the tile measured for the whole M)
-    auto launch2 = [&](int epi, GemmArgs& ga, int which = 0) -> int {
-        const int mf = (ga.M / 256) * 256;
-        if (!split) return sat_launch_gemm(epi, ga, s);
-        if (p->tail_mode != 3 && (mf == 0 || mf == ga.M || ga.M - mf > p->tail_max)) {          // a whole launch in side-stream mode: touches every row
-            SAT_TRY(join_rows(ga.M));
-            SAT_TRY(sat_launch_gemm(epi, ga, s));
-            main_hi = main_hi > ga.M ? main_hi : ga.M;
-            return 0;
-        }
-        if (mf == 0 || mf == ga.M || ga.M - mf > p->tail_max) return sat_launch_gemm(epi, ga, s);
-        if (p->tail_mode == 3) {
-            // serial skinny mode: the rows of the whole tiles on the big tiles, the rest on the weight-streaming kernel, same stream
-            GemmArgs t = ga;
-            t.M -= mf;
-            if (!which || !sat_gemm_skinny_supports(epi, t)) return sat_launch_gemm(epi, ga, s);
-            if (which == 2) ga.m_choose = ga.M;
-            ga.M = mf;
-            SAT_TRY(sat_launch_gemm(epi, ga, s));
-            t.A += (size_t)mf * t.K;
-            if (t.C) t.C += (size_t)mf * t.ldc;
-            if (t.H) t.H += (size_t)mf * (t.N / 2);
-            if (t.xb) t.xb += (size_t)mf * t.N;
-            if (t.ln_part_out) t.ln_part_out += (size_t)mf * (t.N >> 6) * 2;
-            if (t.ln_part) t.ln_part += (size_t)mf * (t.K >> 6) * 2;
-            t.slab = nullptr;
-            t.slab_bytes = 0;
-            t.variant = (t.variant & ~0xff) | 90;
-            return sat_launch_gemm(epi, t, s);
-        }
-        GemmArgs t = ga;
-        ga.m_choose = ga.M;          // the tiles measured for the whole problem
-        ga.M = mf;
-        SAT_TRY(join_rows(mf));
-        SAT_TRY(sat_launch_gemm(epi, ga, s));
-        main_hi = main_hi > mf ? main_hi : mf;
-        t.M -= mf;
-        t.A += (size_t)mf * t.K;
-        if (t.C) t.C += (size_t)mf * t.ldc;
-        if (t.H) t.H += (size_t)mf * (t.N / 2);
-        if (t.xb) t.xb += (size_t)mf * t.N;
-        if (t.ln_part_out) t.ln_part_out += (size_t)mf * (t.N >> 6) * 2;
-        if (t.ln_part) t.ln_part += (size_t)mf * (t.K >> 6) * 2;
-        if (t.heads.xa_out) t.heads.xa_out += (size_t)mf * t.heads.heads * 64;
-        t.heads.m_base = mf;
-        t.slab = nullptr;
-        t.slab_bytes = 0;
-        t.variant = (t.variant & ~0xff) | 16;          // the 128 x 64 tile: the most workgroups per row of tiles (one wave per SIMD, 72 KiB of LDS)
-        SAT_TRY(fork(mf));
-        SAT_TRY(sat_launch_gemm(epi, t, side));
-        side_dirty = true;
-        side_lo = side_lo < mf ? side_lo : mf;
-        return 0;
-    };
-
     GemmArgs g{};
     for (int l = 0; l < c.depth && f32; ++l) {
         // fp32 verification mode: the same block (transformer.py:656-702) on f32_ref.hip, fp32 everywhere
@@ -543,7 +436,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         auto fold_out = [&](GemmArgs& ga) {
             if (lf) { ga.xb = w.A; ga.ln_part_out = w.ln_part; }
         };
-        if (p->f8_qkv || !L.fold_qkv) SAT_TRY(join());
         if (p->f8_qkv) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.pre_g, L.pre_b, w.A, w.As, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s));
         else if (!L.fold_qkv) SAT_TRY(sat_launch_layernorm_mod(w.X, L.pre_g, L.pre_b, w.A, M, D, mod, mod ? mod + D : nullptr, S, ssg_ld, s, f16));
         g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
@@ -554,15 +446,14 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.heads.kind[0] = 2 | 8; g.heads.kind[1] = 2 | 4; g.heads.kind[2] = 1 | 4; g.heads.qscale = SAT_ATTN_QSCALE;
         g.heads.parts = 3; g.heads.heads = H; g.heads.S = S; g.heads.Spad = Spad;
         g.heads.rope_cos = p->rope_cos; g.heads.rope_sin = p->rope_sin;
-        SAT_TRY(launch2(EPI_HEADS, g));
-        SAT_TRY(join());
+        SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
         SAT_TRY(sat_launch_attention(w.Q, w.K, w.Vt, w.AO, bf, H, H, S, S, Spad, Spad, s, p->f8_o ? w.AOs : nullptr, 1.0f, f16));
         g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
         g.A = w.AO; g.W = L.w_o; g.M = M; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
         if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         fold_out(g);
-        SAT_TRY(launch2(EPI_RESID, g, 1));
+        SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
         // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
         // unconditional CFG half, dit.py:294-300) get k = v = 0 from the bias-free to_cond_embed / to_kv, hence an
         // attention output of exactly 0 and, through the bias-free to_out, a branch contribution of exactly 0:
@@ -571,7 +462,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             const int bc = (p->ctx_null_from >= 0 && p->ctx_null_from < bf) ? p->ctx_null_from : bf;
             const int Mc = bc * S;
             if (bc > 0) {
-                if (p->f8_cq || !lf) SAT_TRY(join());
                 if (p->f8_cq) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.cross_g, L.cross_b, w.A, w.As, Mc, D, nullptr, nullptr, 1, 0, s));
                 else if (!lf) SAT_TRY(sat_launch_layernorm(w.X, L.cross_g, L.cross_b, w.A, Mc, D, s, f16));
                 g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
@@ -589,8 +479,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                     g.heads.xa_k = p->kc + l * per_layer; g.heads.xa_vt = p->vct + l * per_layer; g.heads.xa_out = w.AO;
                     g.heads.xa_kvh = p->kvh_cross; g.heads.xa_sk = p->ctx_lc; g.heads.xa_sk_pad = p->ctx_lcpad;
                 }
-                SAT_TRY(launch2(EPI_HEADS, g));
-                if (!fuse) SAT_TRY(join());
+                SAT_TRY(sat_launch_gemm(EPI_HEADS, g, s));
                 if (!fuse)
                     SAT_TRY(sat_launch_attention(w.Q, p->kc + l * per_layer, p->vct + l * per_layer, w.AO, bc, H, p->kvh_cross, S,
                                                  p->ctx_lc, Spad, p->ctx_lcpad, s, p->f8_o ? w.AOs : nullptr, 1.0f, f16));
@@ -598,11 +487,10 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 g.A = w.AO; g.W = L.w_co; g.M = Mc; g.N = D; g.K = D; g.C = w.X; g.ldc = D; g.accumulate = 1;
                 if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
                 fold_out(g);
-                SAT_TRY(launch2(EPI_RESID, g));
+                SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
             }
         }
         // ---- feed-forward branch (transformer.py:700)
-        if (p->f8_ff1 || !lf) SAT_TRY(join());
         if (p->f8_ff1) SAT_TRY(sat_launch_layernorm_fp8(w.X, L.ff_g, L.ff_b, w.A, w.As, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr,
                                                        S, ssg_ld, s));
         else if (!lf) SAT_TRY(sat_launch_layernorm_mod(w.X, L.ff_g, L.ff_b, w.A, M, D, mod ? mod + 3 * D : nullptr, mod ? mod + 4 * D : nullptr, S,
@@ -625,11 +513,11 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             }
             SAT_HIP(hipEventRecord(p->prof_ev[2 * p->prof_n], s));
         }
-        SAT_TRY(launch2(EPI_SWIGLU, g, 2));
+        SAT_TRY(sat_launch_gemm(EPI_SWIGLU, g, s));
         if (prof) {
             SAT_HIP(hipEventRecord(p->prof_ev[2 * p->prof_n + 1], s));
             p->prof_n++;
-            p->prof_m = M; p->prof_nn = g.N; p->prof_k = g.K;          // (M: the launch's rows and its tail launch's)
+            p->prof_m = g.M; p->prof_nn = g.N; p->prof_k = g.K;
         }
         g = GemmArgs{}; g.f16 = f16; g.variant = p->tile_bits;
         g.A = w.Hh; g.W = L.w_ff2; g.bias = L.b_ff2; g.M = M; g.N = D; g.K = p->inner; g.C = w.X; g.ldc = D; g.accumulate = 1;
@@ -637,10 +525,9 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (adaln) { g.gate = mod + 5 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         if (l + 1 < c.depth) fold_out(g);       // nobody normalises the output of the last block
-        SAT_TRY(launch2(EPI_RESID, g, 2));
+        SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
     }
     // project_out + drop prepend + postprocess_conv + residual (transformer.py:807, dit.py:219-224)
-    SAT_TRY(join());
     SAT_TRY(glue_output_proj(w.X, p->wout_eff, out, bf, C, T, S, D, s));
     return 0;
 }
@@ -654,11 +541,11 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
 
 extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_bytes, sat_dit_plan** out_plan) {
     SAT_CHECK_ARG(cfg_in && out_plan, SAT_E_INVALID, "dit_plan_create: null argument");
-    static_assert(sizeof(sat_dit_cfg) == SAT_DIT_CFG_BYTES_V5 + 4 && offsetof(sat_dit_cfg, m_tail) == SAT_DIT_CFG_BYTES_V5, "sat_dit_cfg layout");
-    SAT_CHECK_ARG(cfg_bytes == sizeof(sat_dit_cfg) || cfg_bytes == SAT_DIT_CFG_BYTES_V5, SAT_E_INVALID,
-                  "dit_plan_create: sat_dit_cfg of %zu bytes; this library (ABI version %d) knows %zu and %d (the version-5 layout)", cfg_bytes, sat_version(),
-                  sizeof(sat_dit_cfg), SAT_DIT_CFG_BYTES_V5);
-    sat_dit_cfg cfg_local{};              // fields behind the caller's struct keep their defaults (0)
+    static_assert(sizeof(sat_dit_cfg) == SAT_DIT_CFG_BYTES_V5, "sat_dit_cfg layout");
+    // (the one layout this library knows; when the struct grows again, the older sizes are accepted here and the fields behind them defaulted)
+    SAT_CHECK_ARG(cfg_bytes == sizeof(sat_dit_cfg), SAT_E_INVALID, "dit_plan_create: sat_dit_cfg of %zu bytes; this library (ABI version %d) knows %zu",
+                  cfg_bytes, sat_version(), sizeof(sat_dit_cfg));
+    sat_dit_cfg cfg_local{};
     memcpy(&cfg_local, cfg_in, cfg_bytes);
     const sat_dit_cfg* cfg = &cfg_local;
     SAT_CHECK_ARG(cfg->embed_dim > 0 && cfg->num_heads > 0 && cfg->embed_dim == cfg->num_heads * 64, SAT_E_UNSUPPORTED,
@@ -683,8 +570,6 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
     SAT_CHECK_ARG(cfg->gemm_dtype == 1 || cfg->fp8_families == 0, SAT_E_INVALID,
                   "dit_plan_create: fp8_families = 0x%x with gemm_dtype %d (a caller built against an older sat_dit_cfg layout?)", cfg->fp8_families, cfg->gemm_dtype);
     SAT_CHECK_ARG(cfg->cross_attention == 0 || cfg->cross_attention == 1, SAT_E_INVALID, "dit_plan_create: cross_attention must be 0 (fused where it applies) or 1 (two kernels)");
-    SAT_CHECK_ARG(cfg->m_tail >= 0 && cfg->m_tail <= 3, SAT_E_INVALID,
-                  "dit_plan_create: m_tail must be 0 (one launch per GEMM), 1 / 2 (tail rows as a second launch on a side stream: up to 64 rows / any) or 3 (to_out, FF-in, FF-out: tail rows on the skinny kernel, same stream)");
     SAT_CHECK_ARG(cfg->tile_policy == 0 || cfg->tile_policy == 22 || cfg->tile_policy == 80 || cfg->tile_policy == 81 || cfg->tile_policy == 82, SAT_E_INVALID,
                   "dit_plan_create: tile_policy must be 0 / 80 (default), 22, 81 or 82");
     const int fam = cfg->fp8_families ? cfg->fp8_families : SAT_FP8_DEFAULT;
@@ -706,11 +591,6 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
     }
     p->cross_fusion = cfg->cross_attention == 0;
     p->tile_bits = sat_tile_policy_bits(cfg->tile_policy);
-    // the M-tail split lives where the row maps carry a row offset: 16-bit operand modes, "prepend" conditioning
-    // (its side stream and events are created by sat_dit_plan_finalize: creating a plan touches no device)
-    p->tail_split = cfg->m_tail != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln;
-    p->tail_mode = cfg->m_tail;
-    p->tail_max = cfg->m_tail == 2 ? 255 : 64;
     p->ln_fold = cfg->ln_fold != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
     return 0;
@@ -721,9 +601,6 @@ extern "C" void sat_dit_plan_destroy(sat_dit_plan* p) {
     if (p->arena) (void)hipFree(p->arena);
     if (p->ctx_buf) (void)hipFree(p->ctx_buf);
     for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : p->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
 }
 
@@ -748,11 +625,6 @@ extern "C" int sat_dit_plan_finalize(sat_dit_plan* p, sat_stream_t stream) {
         p->arena = nullptr;
     }
     p->finalized = false;
-    if (p->tail_split && p->tail_mode != 3 && !p->side) {
-        SAT_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-        p->ev.assign(8 * (size_t)p->cfg.depth + 8, nullptr);
-        for (auto& e : p->ev) SAT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     Arena dry;
     SAT_TRY(build(p, dry, s));
     SAT_HIP(hipMalloc((void**)&p->arena, dry.off));

@@ -142,7 +142,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                 for (int e = 0; e < 4; ++e) {
                     const int r = rq * 4 + e;
                     int mm = mb + e;
-                    mm = (mm < M ? mm : M - 1) + he.m_base;
+                    mm = mm < M ? mm : M - 1;
                     bb[e] = mm / S;
                     ss[e] = mm - bb[e] * S;
                     v0[e] = acc[i][0][r];
@@ -354,7 +354,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = mw + i * 32 + l31;
-                const int s = ((m < M ? m : M - 1) + he.m_base) % S;
+                const int s = (m < M ? m : M - 1) % S;
                 rcs[i][0] = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 4 * half);
                 rcs[i][1] = *reinterpret_cast<const f32x4*>(he.rope_cos + (size_t)s * 16 + 8 + 4 * half);
                 rsn[i][0] = *reinterpret_cast<const f32x4*>(he.rope_sin + (size_t)s * 16 + 4 * half);
@@ -364,7 +364,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmArgs& g, f32x16 (&acc)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = mw + i * 32 + l31;
-            const int mc = (m < M ? m : M - 1) + he.m_base;
+            const int mc = m < M ? m : M - 1;
             const int b = mc / S;
             const int s = mc - b * S;
             const int ob = (kind & 4) ? ((b * S) & 3) : 0;
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
     };
     if constexpr (XA_OK) {
         xa_on = g.heads.xa_k != nullptr;
-        if (xa_on) xa_stage((m0 + g.heads.m_base) / g.heads.S);
+        if (xa_on) xa_stage(m0 / g.heads.S);
     }
     // fp32 residual epilogue of the small tiles (one 32-row block per wave, registers to spare): fetch the residual values NOW.
     // They are the oldest entries of the vector-memory queue, so every counted vmcnt wait of the K loop still holds.
@@ -1293,12 +1293,11 @@ __global__ __launch_bounds__(KG * WM * WN * 64) void gemm_pipe_kernel(GemmArgs g
             }
             const int S = he.S;
             const int m = m0 + wm * TM + l31;
-            const int mb_ = he.m_base;          // (rows of a larger problem: sequences are counted in ITS row space)
-            const int b_me = ((m < M ? m : M - 1) + mb_) / S;
+            const int b_me = (m < M ? m : M - 1) / S;
             const int last = (m0 + BM - 1 < M ? m0 + BM - 1 : M - 1);
-            const int b_lo = (m0 + mb_) / S, b_hi = (last + mb_) / S;
+            const int b_lo = m0 / S, b_hi = last / S;
             const int wlast = (m0 + wm * TM + 31 < M ? m0 + wm * TM + 31 : M - 1);
-            const int w_lo = (m0 + wm * TM + mb_) / S, w_hi = (wlast + mb_) / S;
+            const int w_lo = (m0 + wm * TM) / S, w_hi = wlast / S;
             for (int bb = b_lo; bb <= b_hi; ++bb) {
                 if (bb > b_lo) {        // the tile's rows straddle two sequences: second pass on the next sequence's keys
                     __builtin_amdgcn_s_barrier();
@@ -1509,10 +1508,9 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
     }
     // fill of the last round of the device's CUs (256 on MI355X) x measured in-kernel rate of the tile, relative to the 256x256 tile
     const long cus = std::max(1, sat_device_cus());
-    const int m_ch = a.m_choose > 0 ? a.m_choose : a.M;
     auto score = [&](int bm, int bn, double rate) {
         if (a.N % bn) return 0.0;
-        long t = (long)cdiv(m_ch, bm) * (a.N / bn);
+        long t = (long)cdiv(a.M, bm) * (a.N / bn);
         return rate * (double)t / (double)(((t + cus - 1) / cus) * cus);
     };
 #ifndef SAT_OPERAND_F16          // e4m3 operands ride in the bf16 build (sat_launch_gemm rejects f16 && fp8): the fp16 build does not instantiate them
@@ -1564,7 +1562,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             double s256 = score(256, 256, 1.0);
             if (sat_wide_tile_of(a.variant) >= 80 && sat_gemm_ph8_supports(EPI, a)) {
                 const double rate = EPI == EPI_SWIGLU ? 1.26 : EPI == EPI_HEADS ? 1.07 : 1.02;
-                const long t = (long)cdiv(m_ch, 256) * (a.N / 256);
+                const long t = (long)cdiv(a.M, 256) * (a.N / 256);
                 const double rounds = sat_gemm_ph8_splits(EPI, a) ? (double)(t / cus) + 0.35 : (double)((t + cus - 1) / cus);
                 s256 = rate * (double)t / (rounds * (double)cus);
             }
@@ -1579,7 +1577,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             if (v == 15 && EPI == EPI_F32 && a.K >= 4096 && !deep_ring_off()) v = 44;
             // one round of 128 x 128 tiles (to_out / FF-out at one prompt: 204 workgroups on 256 CUs): the two-K-group build puts 8 waves of
             // 64 x 64 on every CU instead of 8 waves of 32 x 64 -- FF-out 56.5 us against 60.7, to_out 20.6 against 21.4 (tools/ph8_probe.py narrow)
-            if ((v == 15 || v == 44) && EPI == EPI_F32 && !a.fp8 && a.K % 128 == 0 && a.K >= 256 && (long)cdiv(m_ch, 128) * (a.N / 128) <= cus &&
+            if ((v == 15 || v == 44) && EPI == EPI_F32 && !a.fp8 && a.K % 128 == 0 && a.K >= 256 && (long)cdiv(a.M, 128) * (a.N / 128) <= cus &&
                 !(a.variant & 0x800000) && sat_wide_tile_of(a.variant) != 82)
                 v = 49;
         } else {
@@ -1660,8 +1658,6 @@ int SAT_OPNS::sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
                                  (((uintptr_t)a.ln_part | (uintptr_t)a.ln_c1 | (uintptr_t)a.ln_c2) & 15) == 0),
                   SAT_E_INVALID, "gemm: LayerNorm fold needs ln_c1 / ln_c2 / ln_eps, no separate bias (it is part of ln_c2), 16-byte aligned vectors");
     SAT_CHECK_ARG((((uintptr_t)a.xb | (uintptr_t)a.ln_part_out) & 15) == 0, SAT_E_INVALID, "gemm: xb / ln_part_out must be 16-byte aligned");
-    SAT_CHECK_ARG(a.heads.m_base >= 0 && a.heads.m_base % 4 == 0, SAT_E_INVALID, "gemm: heads.m_base must be a non-negative multiple of 4 (aligned V^T groups)");
-    if ((a.variant & 0xff) == 90) return sat_launch_gemm_skinny(epi, a, stream);          // a few rows: the weight-streaming kernel of gemm_skinny.hip
     if ((a.variant & 0xfff) % 100 == 80 || (a.variant & 0xfff) % 100 == 81) return sat_launch_gemm_ph8(epi, a, stream);      // 256x256x64, 8 waves, 8-phase schedule (gemm_ph8.hip)
     switch (epi) {
         case EPI_F32:

@@ -1308,7 +1308,6 @@ int launch_ph8(const GemmArgs& a0, hipStream_t stream) {
         for (int p = 0; p < a.heads.parts; ++p)
             SAT_CHECK_ARG((a.heads.kind[p] & 3) != 3, SAT_E_UNSUPPORTED, "gemm(8-phase): no rotation on a transposed destination");
         SAT_CHECK_ARG(!a.heads.xa_k, SAT_E_UNSUPPORTED, "gemm(8-phase): the fused cross-attention epilogue lives in the 128 x 64 tile");
-        SAT_CHECK_ARG(a.heads.m_base == 0, SAT_E_UNSUPPORTED, "gemm(8-phase): a row offset (HeadsEpi::m_base) is built into the tiles of gemm_bf16.hip only");
     }
     Ph8Sched sc;
     // bits 16 / 17 of the variant force / forbid the K-split of the remainder round (measurements, tests)
@@ -1343,7 +1342,7 @@ bool SAT_OPNS::sat_gemm_ph8_supports(int epi, const GemmArgs& a) {
     // read-modify-write at HBM speed; persistent workgroups run those epilogues in lockstep, the 16-wave tile's independent workgroups
     // drift apart and overlap them with other tiles' main loops: measured 111 us against 122 at 8 prompts (profiles/r03_ph8_streamk.txt)
     if ((epi == EPI_F32 || epi == EPI_RESID) && a.K < 4096 && sat_wide_tile_of(a.variant) != 81) return false;          // (81: sat_dit_cfg.tile_policy, A/B)
-    if (epi == EPI_HEADS) return (a.heads.heads * 64) % 256 == 0 && a.heads.m_base == 0;          // (an M-tail launch runs the narrow tiles)
+    if (epi == EPI_HEADS) return (a.heads.heads * 64) % 256 == 0;
     return true;
 }
 

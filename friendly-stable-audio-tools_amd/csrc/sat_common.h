@@ -277,10 +277,7 @@ struct HeadsEpi {
     int xa_kvh, xa_sk, xa_sk_pad;
     int parts;           // N == parts * heads * 64
     int heads;           // heads per part
-    int S;               // valid rows per sequence (row m_base + m -> b = row / S, s = row % S)
-    int m_base;          // row of the launch's first A / output row in the [B * S] row space, multiple of 4: a launch that covers rows
-                         // [m_base, m_base + M) of a larger problem (the M-tail launch of the DiT plan, round 6).  Pipelined and simple tiles
-                         // of gemm_bf16.hip only (sat_gemm_ph8_supports says no to m_base != 0)
+    int S;               // valid rows per sequence (row m -> b = m / S, s = m % S)
     int Spad;            // padded sequence length of the destination
     const float* rope_cos;   // [>=S][16]
     const float* rope_sin;
@@ -330,9 +327,6 @@ struct GemmArgs {
     // workspace), used by this launch only; nullptr = the remainder round's tiles stay whole.
     float* slab;
     size_t slab_bytes;
-    // M the automatic tile choice is made for, if not this launch's own (0): the main launch of an M-tail split (dit_plan.hip, launch2) keeps the
-    // tiles measured for the whole problem -- 384 whole tiles score differently from 432 with a near-empty row, and the scores are calibrated on the latter
-    int m_choose;
 };
 
 // bf16 build: checks a.f16 and forwards fp16 work to sat_launch_gemm_f16 (the fp16 build of the same file)
@@ -341,8 +335,6 @@ bool sat_gemm_ph8_supports(int epi, const GemmArgs& a);
 bool sat_gemm_ph8_splits(int epi, const GemmArgs& a);       // the automatic schedule would split the remainder round along K
 size_t sat_gemm_ph8_slab_bytes(int epi, int M, int N, int K);      // slab workspace that makes it do so (0: never for this shape)
 int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream);     // gemm_ph8.hip: the 8-wave / 8-phase 256x256 tile
-bool sat_gemm_skinny_supports(int epi, const GemmArgs& a);
-int sat_launch_gemm_skinny(int epi, const GemmArgs& a, hipStream_t stream);  // gemm_skinny.hip: <= 64 rows, weight-streaming (variant 90)
 // out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
 // q_scale: what the kernel still has to multiply in -- SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e) for a plain Q, 1.0f for a Q the
 // producer already wrote pre-scaled (HeadsEpi kind bit 3): only then the single-KV-group kernel carries its softmax reference

@@ -8,7 +8,6 @@ batched CFG, dit.py:228-364); ``denoise`` is the fused k-diffusion ``VDenoiser``
 the sampler loop uses (one ``sat_dit_denoise_cfg`` call per step).
 """
 import ctypes
-import os
 import typing as tp
 
 import torch
@@ -79,18 +78,6 @@ class DiffusionTransformer(nn.Module):
         self.layernorm_fusion = True
         self.cross_attention_fusion = True
         self.tile_policy = 0
-        self.m_tail = int(os.environ.get("SAT_M_TAIL", "0"))         # sat_dit_cfg.m_tail: 0 = one launch per GEMM (default), 1 / 2 = tail rows as a second launch (A/B)
-
-    def set_m_tail(self, mode: int):
-        """Build extension, A/B switch (``sat_dit_cfg.m_tail``): 0 = one launch per GEMM (default); 1 = every block GEMM runs on the rows of its whole
-        256-row tiles and the 2 (16) rows left over of M = bf * 1025 as a second narrow-tile launch on the plan's side stream (measured slower,
-        profiles/r06_mtail_split.txt); 2 = the same for tails of any length (tests).  Per model; rebuilds the plan on next use."""
-        if mode not in (0, 1, 2, 3):
-            raise ValueError("m_tail must be 0, 1, 2 or 3")
-        if mode != self.m_tail:
-            self.m_tail = mode
-            self._plan_version = None
-        return self
 
     def set_cross_attention_fusion(self, on: bool):
         """Build extension, A/B switch: the to_q projection + cross-attention core as ONE launch where it applies (one prompt; the default) or
@@ -157,7 +144,7 @@ class DiffusionTransformer(nn.Module):
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
                              self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
                              1 if self.global_cond_type == "adaLN" else 0, GEMM_DTYPES[self.gemm_dtype], FP8_FAMILIES.get(self.gemm_dtype, 0),
-                             1 if self.layernorm_fusion else 0, 0 if self.cross_attention_fusion else 1, self.tile_policy, self.m_tail)
+                             1 if self.layernorm_fusion else 0, 0 if self.cross_attention_fusion else 1, self.tile_policy)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create_sized(ctypes.byref(cfg), ctypes.sizeof(cfg), ctypes.byref(plan)))
         keep = []

@@ -123,19 +123,13 @@ typedef struct sat_dit_cfg {
     int32_t tile_policy;       /* 0 / 80 (default): the measured tile choice; A/B measurement switches: 22 = the 16-wave 256 x 256 tile of rounds
                                   1-2 instead of the 8-phase kernel, 81 = the 8-phase kernel also for fp32-output GEMMs with K < 4096, 82 = no
                                   two-K-group 128 x 128 tile */
-    /* ---- version 6 (read by sat_dit_plan_create_sized only; sat_dit_plan_create defaults it to 0) */
-    int32_t m_tail;            /* M-tail split (round 6; an A/B switch -- measured SLOWER than the default, profiles/r06_mtail_split.txt).  M = bf * (t_len + 1)
-                                  is 8 (64) whole 256-row tiles plus 2 (16) rows, and the near-empty extra row of tiles costs every GEMM 1-10 %
-                                  (profiles/r06_mtail_pricing.txt).  0 (default): one launch per GEMM.  1 (gemm_dtype 0 / 3, adaln == 0): the block GEMMs run
-                                  on the rows of their WHOLE tiles, the rows left over (up to 64) as a second, narrow-tile launch of the same GEMM on a side
-                                  stream the plan owns; the caller's stream is ordered behind it (fork / join through events; capturable).  Same arithmetic
-                                  per row: results differ only by the summation order of the tile that computes a row.  2: any tail, 1..255 rows (tests) */
 } sat_dit_cfg;
 #define SAT_DIT_CFG_BYTES_V5 56          /* the layout sat_dit_plan_create reads: 14 int32 fields, up to and including tile_policy */
 
-/* cfg_bytes = sizeof(sat_dit_cfg) of the header the CALLER was built against: the current size, or SAT_DIT_CFG_BYTES_V5 (the version-5 layout; the
- * fields behind it take their defaults).  Any other size is SAT_E_INVALID -- a caller built against another header is told so instead of having its
- * struct read past its end.  sat_dit_plan_create(cfg, out) == sat_dit_plan_create_sized(cfg, SAT_DIT_CFG_BYTES_V5, out). */
+/* cfg_bytes = sizeof(sat_dit_cfg) of the header the CALLER was built against.  This version knows one layout (SAT_DIT_CFG_BYTES_V5: the version-5
+ * layout, unchanged in version 6); any other size is SAT_E_INVALID -- a caller built against another header is told so instead of having its struct
+ * read past its end.  When the struct grows again, the older sizes stay accepted and the new fields take their defaults.
+ * sat_dit_plan_create(cfg, out) == sat_dit_plan_create_sized(cfg, SAT_DIT_CFG_BYTES_V5, out). */
 int sat_dit_plan_create_sized(const sat_dit_cfg* cfg, size_t cfg_bytes, sat_dit_plan** out_plan);
 int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_plan);
 void sat_dit_plan_destroy(sat_dit_plan* plan);

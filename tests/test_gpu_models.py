@@ -86,32 +86,6 @@ def test_cross_attention_fusion_on_off(dev, small_dit):
             assert_close("fused vs separate cross-attention, 3 sequences", fused, separate, T(2e-3))
 
 
-def test_m_tail_split_on_off(dev, small_dit):
-    """sat_dit_cfg.m_tail (round 6, an opt-in A/B switch): every block GEMM on the rows of its whole 256-row tiles + the rows left over as a second
-    launch of the same GEMM (row offset HeadsEpi::m_base, 128 x 64 tiles) on the plan's side stream, against the default one launch per GEMM.
-    Per row the arithmetic is the same; a row may be computed by another tile shape, i.e. in another summation order.  Shapes: 2 x 201 rows =
-    256 + 146 (q / k / v^T rows of two sequences in the tail, one sequence boundary inside it), 3 x 301 = 768 + 135 (cross-attention branch on
-    903 rows: its own tail), with and without the null-context skip of CFG."""
-    cfg, model, sd = small_dit
-    dc = cfg["model"]["diffusion"]["config"]
-    dit = model.model.model
-    # mode 2: side stream, any tail; mode 1: side stream, tails up to 64 rows; mode 3: to_out / FF-in / FF-out tails on the skinny kernel, same stream
-    for mode, b, t_len, cfg_scale in ((2, 2, 200, 1.0), (2, 3, 300, 1.0), (2, 2, 200, 5.0), (1, 2, 132, 5.0), (3, 2, 132, 1.0), (3, 2, 132, 5.0), (3, 4, 135, 1.0)):
-        x, c, g = _inputs(b, t_len, dc["cond_token_dim"], seed=11)
-        t = torch.tensor([0.31, 0.87, 0.5, 0.11][:b])
-        run = lambda: model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=cfg_scale).cpu()
-        one = run()
-        try:
-            dit.set_m_tail(mode)
-            two = run()
-            assert torch.equal(two, run()), "the split path is not repeatable (a missing fork / join?)"
-        finally:
-            dit.set_m_tail(0)
-        assert torch.isfinite(two).all()
-        e = assert_close(f"M-tail split (mode {mode}) vs one launch per GEMM, {b} x {t_len + 1} rows, cfg {cfg_scale}", two, one, T(8e-3))
-        print(f"\n[m_tail {mode}, {b} x {t_len + 1} rows, cfg {cfg_scale}] rel-L2 split vs single launch {e:.2e}")
-
-
 def test_layernorm_fusion_on_off(dev, small_dit):
     """The standalone-LayerNorm plan (sat_dit_cfg.ln_fold = 0) against ITS matched oracle (plain bf16 rounding points), and the two
     plans against each other: they differ only in where the activation is rounded (before / after the normalisation)."""

@@ -2,7 +2,7 @@
 to the library round 5 shipped; git-ignored like every .so, it travels to the GPU box) against this tree's library under named settings of its
 per-plan switches, all timed INTERLEAVED in one process on one box (box-to-box spread of the bench line is +-3 %): one full-size model per
 entry, `dit.denoise` = one CFG-7 denoiser step (2 sequences per prompt), what generate_diffusion_cond calls 100 times.
-Entries: AB_SET="name:key=value;key=value,name:..." with keys m_tail / tile_policy / old=1 (a second instance of the round-5 library:
+Entries: AB_SET="name:key=value;key=value,name:..." with keys tile_policy / old=1 (a second instance of the round-5 library:
 instance-to-instance noise) / lib=path (another build of this tree).  Developer tool; not part of the product or the tests.     usage: python tools/ab_r05.py [batch ...]      (default: 1 8)"""
 import ctypes
 import os
@@ -72,8 +72,6 @@ def main():
             model = S.create_model_from_config(MC.stable_audio_open_1_0())
         model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), 0))
         dit = model.to(dev).eval().model.model
-        if "m_tail" in opts:
-            dit.set_m_tail(opts["m_tail"])
         if "tile_policy" in opts:
             dit.set_tile_policy(opts["tile_policy"])
         dits[name] = dit
