@@ -327,7 +327,9 @@ int SAT_OPNS::sat_launch_attention(const op_t* q, const op_t* k, const op_t* vt,
     static const int force_grp = [] { const char* e = getenv("SAT_ATTN_GROUPS"); return e ? atoi(e) : 0; }();
 #endif
     const long wg1 = (long)cdiv(sq, 256) * h * b;
-    const bool one_group = force_grp ? force_grp == 1 : (wg1 >= 1024 || sk <= 512 || (q_scale == 1.0f && !out_scales && wg1 >= 200));
+    // (the pre-scaled rule holds where it was measured: S = 1025; a lone long sequence -- S = 6145, 600 workgroups -- measured 2 % FASTER split,
+    // profiles/r05_attention_layout_sweep.txt -- keeps round 3's rule: ADVICE r5)
+    const bool one_group = force_grp ? force_grp == 1 : (wg1 >= 1024 || sk <= 512 || (q_scale == 1.0f && !out_scales && wg1 >= 200 && sk <= 2048));
 #ifdef SAT_GEMM_EXPERIMENTS
     if (one_group && !out_scales && getenv("SAT_ATTN_DBG") && atoi(getenv("SAT_ATTN_DBG")) == 9) {
         if (!g_attn_dbg) {

@@ -671,6 +671,9 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
         float a_sc;
     };
     constexpr bool LN_DEFER = LN_CONS && EPI == EPI_SWIGLU;
+    // Half-tiles of a range's DMA prologue: all four of its first K-tile + PRO_T1 of the second.  ONE constant drives the issue loop below and the
+    // counted waits that let exactly these stay in flight (PRO_DMA; ADVICE r5: the two used to spell the expression out separately)
+    constexpr int PRO_T1 = (PH2 && PH2V != 2) ? 2 : 3;
     auto prepare_issue = [&](const Seg& s, [[maybe_unused]] LnPre& st) {
         int tid = tid_;
         asm volatile("" : "+v"(tid));            // (keeps this block's address arithmetic inside the persistent loop, see the epilogue)
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue(j, 0, s.kt0);
 #pragma unroll
-        for (int j = 0; j < ((PH2 && PH2V != 2) ? 2 : 3); ++j) issue(j, 1, s.kt0 + 1);
+        for (int j = 0; j < PRO_T1; ++j) issue(j, 1, s.kt0 + 1);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto prepare_finish = [&](const Seg& s, int lb, [[maybe_unused]] LnPre& st) {
@@ -764,7 +767,8 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
             reinterpret_cast<float*>(smem + ROPE16_OFF)[tid_] = (tid_ < 16 ? g.heads.rope_cos : g.heads.rope_sin)[r16 * 16 + (tid_ & 15)];
         }          // (published by the barriers of the first main loop)
     }
-    constexpr int PRO_DMA = 2 * ((PH2 && PH2V != 2) ? 6 : 7);          // LDS-DMA instructions per wave of a range's prologue (two per half-tile)
+    constexpr int PRO_DMA = 2 * (4 + PRO_T1);          // LDS-DMA instructions per wave of a range's prologue (issue(): two per half-tile)
+    static_assert(PRO_DMA == 12 || PRO_DMA == 14, "prologue = 6 or 7 half-tiles");
     [[maybe_unused]] auto rope_load = [&](f32x4_t& cs, f32x4_t& sn, int row, int q4) {
         const unsigned voff = (unsigned)(row * 16 + 4 * q4) * 4u;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(cs) : "v"(voff), "s"(g.heads.rope_cos) : "memory");
@@ -1050,7 +1054,12 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_ph8_kernel(GemmArgs g, Ph8Sc
     // vector-memory operations a wave issues between a range's DMA prologue and the top of that range, when they are a constant: the MB
     // unconditional stores of the SwiGLU epilogue (16-bit output; the e4m3 build writes a data-dependent mix).  -1: not a constant.
     // (DBG 9, the timeline build: wave 0 issues its timestamp stores on top -- more operations behind the prologue, so the counted wait only gets stricter)
-    constexpr int EPI_STORES = (EPI == EPI_SWIGLU && FP8 == 0 && (DBG == 0 || DBG == 9) && PH2 && PH2V == 1) ? MB : -1;
+    // the 16-bit SwiGLU epilogue issues exactly ONE unconditional buffer store per 16-row block of the wave (the `mb` loop around the store to rsH)
+    // and no other vector-memory operation: that is the number the counted wait at the top of the next range adds to its 6.  A store made
+    // conditional again, or a second one per block, has to change this line (a build with vmcnt(0) there must give bit-identical results)
+    constexpr int SWIGLU_STORES_PER_BLOCK = 1;
+    constexpr int EPI_STORES = (EPI == EPI_SWIGLU && FP8 == 0 && (DBG == 0 || DBG == 9) && PH2 && PH2V == 1) ? MB * SWIGLU_STORES_PER_BLOCK : -1;
+    static_assert(EPI_STORES < 0 || 6 + EPI_STORES <= 63, "vmcnt is a 6-bit counter");
     [[maybe_unused]] bool stores_behind = false;
     LnPre lnpre;
     prepare_issue(cur, lnpre);

@@ -61,3 +61,59 @@ def test_one_prompt_gemm_tiles_keep_their_occupancy(defines, tmp_path):
         assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, f"{name}: {m}"
     assert next(iter(qkv.values()))["vgpr_count"] <= 168
     assert next(iter(kgroup.values()))["vgpr_count"] <= 256
+
+
+def _regs(tok):
+    """VGPR numbers named by one operand token: v12 -> {12}, v[4:7] -> {4..7}"""
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", tok):
+        out |= set(range(int(a), int(b) + 1))
+    out |= {int(a) for a in re.findall(r"\bv(\d+)\b", tok)}
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("defines", [[], ["-DSAT_OPERAND_F16"]], ids=["bf16", "f16"])
+def test_ph8_asm_loads_are_not_read_before_their_wait(defines, tmp_path):
+    """gemm_ph8.hip issues loads from inline assembly with plain "=v" outputs (rope_load: global_load_dwordx4; lds_ld32 / 64 /
+    128: ds_read) and waits for them LATER with its own s_waitcnt (rope_wait / lds_wait) -- the compiler believes the destination registers are
+    valid from the asm statement on, so a copy, live-range split or spill it inserted in that window would read them before the data lands.  The
+    no-scratch test above rules out spills; this one reads the ISA of every 8-phase kernel: between an asm load and the first s_waitcnt on its
+    counter (vmcnt for global loads, lgkmcnt for LDS reads), no instruction may name one of its destination registers.  Verified with the
+    hipcc of ROCm 7.2.0 (the image this repository builds in); it is a property of the allocation, so it is re-checked at every build."""
+    out = os.path.join(str(tmp_path), "k.s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", os.path.join(CSRC, "gemm_ph8.hip"), "-o", out] + defines,
+                   check=True, capture_output=True)
+    lines = open(out).read().split("\n")
+    checked = {"global_load": 0, "ds_read": 0}
+    in_asm = False
+    pending = []          # (counter, destination registers, line number, text) of asm loads still in flight
+    for no, raw in enumerate(lines):
+        line = raw.split(";")[0].strip() if not raw.strip().startswith(";;#") else raw.strip()
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if line.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not line or line.endswith(":") or line.startswith("."):
+            if line.startswith(".Lfunc_end") or line.startswith(".end_amdhsa_kernel"):
+                pending = []
+            continue
+        op = line.split()[0]
+        if op == "s_waitcnt":
+            if "vmcnt" in line:
+                pending = [p_ for p_ in pending if p_[0] != "vmcnt"]
+            if "lgkmcnt" in line:
+                pending = [p_ for p_ in pending if p_[0] != "lgkmcnt"]
+            continue
+        operands = line[len(op):]
+        used = _regs(operands)
+        for counter, dest, at, text in pending:
+            assert not (used & dest), f"line {no + 1}: `{line}` names v{sorted(used & dest)} before the wait of the asm load at line {at + 1}: `{text}`"
+        if in_asm and (op.startswith("global_load") or op.startswith("ds_read")):
+            dest = _regs(operands.split(",")[0])
+            kind = "global_load" if op.startswith("global_load") else "ds_read"
+            checked[kind] += 1
+            pending.append(("vmcnt" if kind == "global_load" else "lgkmcnt", dest, no, line))
+    assert checked["global_load"] >= 8 and checked["ds_read"] >= 30, checked
