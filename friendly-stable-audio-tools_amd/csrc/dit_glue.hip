@@ -654,3 +654,42 @@ extern "C" int sat_snake_beta(const float* x_dev, const float* alpha_dev, const 
     SAT_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- sat_dit_debug: what the 16-bit image of the residual stream would do to these rows (one wave per row)
+namespace {
+__global__ __launch_bounds__(256) void resid_stats_kernel(const float* __restrict__ X, int M, int D, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* x = X + (size_t)row * D;
+    float sum = 0.f, sq = 0.f, mx = 0.f, over = 0.f;
+    for (int i = lane; i < D; i += 64) {
+        const float v = x[i], a = fabsf(v);
+        sum += v;
+        sq += v * v;
+        mx = fmaxf(mx, a);
+        over += a > 65504.0f ? 1.f : 0.f;
+    }
+    sum = wave_sum(sum);
+    sq = wave_sum(sq);
+    over = wave_sum(over);
+    mx = wave_max(mx);
+    if (lane == 0) {
+        const float mean = sum / (float)D;
+        const float var = fmaxf(sq / (float)D - mean * mean, 0.f);
+        const float cm = fabsf(mean) * rsqrtf(var + 1e-30f);
+        const float crest = mx * rsqrtf(sq / (float)D + 1e-30f);
+        // non-negative floats order like their bit patterns
+        atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(mx));
+        atomicMax(reinterpret_cast<unsigned*>(out + 1), __float_as_uint(cm));
+        if (over > 0.f) atomicAdd(out + 2, over);
+        atomicMax(reinterpret_cast<unsigned*>(out + 3), __float_as_uint(crest));
+    }
+}
+}  // namespace
+
+int glue_resid_stats(const float* X, int M, int D, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(resid_stats_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, X, M, D, out);
+    SAT_LAUNCH_CHECK();
+    return 0;
+}
+

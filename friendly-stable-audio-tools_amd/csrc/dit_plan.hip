@@ -133,6 +133,8 @@ struct sat_dit_plan {
     int prof_n = 0;
     std::vector<hipEvent_t> prof_ev;   // pairs
     long long prof_m = 0, prof_nn = 0, prof_k = 0;
+    // optional diagnostics of the residual stream (sat_dit_debug): [depth][3 updates][4] floats, overwritten by every forward while enabled
+    float* dbg = nullptr;
 };
 static const int kProfMaxPairs = 4096;
 
@@ -395,6 +397,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     // preprocess_conv + residual + project_in (dit.py:197-199, transformer.py:778)
     SAT_TRY(glue_input_proj(x, p->win_eff, w.X, bf, xB, C, T, S, D, xscale, s));
 
+    if (p->dbg) SAT_HIP(hipMemsetAsync(p->dbg, 0, (size_t)c.depth * 3 * 4 * sizeof(float), s));
     GemmArgs g{};
     for (int l = 0; l < c.depth && f32; ++l) {
         // fp32 verification mode: the same block (transformer.py:656-702) on f32_ref.hip, fp32 everywhere
@@ -454,6 +457,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         fold_out(g);
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
+        if (p->dbg) SAT_TRY(glue_resid_stats(w.X, M, D, p->dbg + ((size_t)l * 3 + 0) * 4, s));
         // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
         // unconditional CFG half, dit.py:294-300) get k = v = 0 from the bias-free to_cond_embed / to_kv, hence an
         // attention output of exactly 0 and, through the bias-free to_out, a branch contribution of exactly 0:
@@ -488,6 +492,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
                 if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_co; }
                 fold_out(g);
                 SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
+                if (p->dbg) SAT_TRY(glue_resid_stats(w.X, Mc, D, p->dbg + ((size_t)l * 3 + 1) * 4, s));
             }
         }
         // ---- feed-forward branch (transformer.py:700)
@@ -526,6 +531,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         g.slab = w.slab; g.slab_bytes = w.slab_bytes;
         if (l + 1 < c.depth) fold_out(g);       // nobody normalises the output of the last block
         SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
+        if (p->dbg) SAT_TRY(glue_resid_stats(w.X, M, D, p->dbg + ((size_t)l * 3 + 2) * 4, s));
     }
     // project_out + drop prepend + postprocess_conv + residual (transformer.py:807, dit.py:219-224)
     SAT_TRY(glue_output_proj(w.X, p->wout_eff, out, bf, C, T, S, D, s));
@@ -600,6 +606,7 @@ extern "C" void sat_dit_plan_destroy(sat_dit_plan* p) {
     if (!p) return;
     if (p->arena) (void)hipFree(p->arena);
     if (p->ctx_buf) (void)hipFree(p->ctx_buf);
+    if (p->dbg) (void)hipFree(p->dbg);
     for (hipEvent_t e : p->prof_ev) (void)hipEventDestroy(e);
     delete p;
 }
@@ -788,6 +795,30 @@ extern "C" int sat_dit_profile_read(sat_dit_plan* p, double* total_ms, int32_t* 
     if (m) *m = p->prof_m;
     if (n) *n = p->prof_nn;
     if (k) *k = p->prof_k;
+    return 0;
+}
+
+extern "C" int sat_dit_debug(sat_dit_plan* p, int32_t enable) {
+    SAT_CHECK_ARG(p, SAT_E_INVALID, "dit_debug: null plan");
+    if (enable && !p->dbg) {
+        SAT_CHECK_ARG(p->cfg.gemm_dtype != 2, SAT_E_UNSUPPORTED, "dit_debug: the fp32 verification mode keeps no 16-bit image of the residual stream");
+        SAT_HIP(hipMalloc((void**)&p->dbg, (size_t)p->cfg.depth * 3 * 4 * sizeof(float)));
+        SAT_HIP(hipMemset(p->dbg, 0, (size_t)p->cfg.depth * 3 * 4 * sizeof(float)));
+    } else if (!enable && p->dbg) {
+        SAT_HIP(hipDeviceSynchronize());
+        SAT_HIP(hipFree(p->dbg));
+        p->dbg = nullptr;
+    }
+    return 0;
+}
+
+extern "C" int sat_dit_debug_read(sat_dit_plan* p, float* out_host, int32_t capacity_floats, sat_stream_t stream) {
+    SAT_CHECK_ARG(p && out_host, SAT_E_INVALID, "dit_debug_read: null argument");
+    SAT_CHECK_ARG(p->dbg, SAT_E_STATE, "dit_debug_read: diagnostics are not enabled (sat_dit_debug)");
+    const int n = p->cfg.depth * 3 * 4;
+    SAT_CHECK_ARG(capacity_floats >= n, SAT_E_INVALID, "dit_debug_read: room for %d floats, need %d", capacity_floats, n);
+    SAT_HIP(hipMemcpyAsync(out_host, p->dbg, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    SAT_HIP(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "sat_dit_profile": (c_int32, [c_void_p, c_int32]),
     "sat_dit_profile_read": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64),
                                        POINTER(c_int64)]),
+    "sat_dit_debug": (c_int32, [c_void_p, c_int32]),
+    "sat_dit_debug_read": (c_int32, [c_void_p, POINTER(c_float), c_int32, c_void_p]),
     "sat_cfg_combine": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_void_p]),
     "sat_quant_rows_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "sat_layernorm_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),

@@ -79,6 +79,27 @@ class DiffusionTransformer(nn.Module):
         self.cross_attention_fusion = True
         self.tile_policy = 0
 
+    def residual_stream_report(self, enable: bool = True):
+        """Build extension (``sat_dit_debug``), for checkpoints this build was never run on.  ``residual_stream_report(True)`` switches the
+        diagnostics on; every forward / ``denoise`` then leaves, per block and residual update (self-attention to_out, cross-attention to_out,
+        FF-out), the statistics of the fp32 residual rows that update wrote: ``max_abs``, ``common_mode`` = max over rows of |mean| / std (the
+        LayerNorm fold rounds the UN-normalised row to 16 bits: its error grows with this ratio -- ``set_layernorm_fusion(False)`` from ~8 on),
+        ``saturated`` = elements beyond +-65504 (what the fp16 image clamps -- ``set_gemm_dtype("bf16")`` if not 0) and ``crest`` = max |x| / rms.
+        ``residual_stream_report(False)`` returns the table of the LAST forward as a list of dicts and switches the diagnostics off."""
+        import ctypes as _ct
+        lib = _hip.lib()
+        plan = self._ensure_plan()
+        if enable:
+            _hip.check(lib.sat_dit_debug(plan, 1))
+            return None
+        n = self.depth * 3 * 4
+        buf = (_ct.c_float * n)()
+        _hip.check(lib.sat_dit_debug_read(plan, buf, n, _hip.stream()))
+        _hip.check(lib.sat_dit_debug(plan, 0))
+        names = ("self_attn.to_out", "cross_attn.to_out", "ff.out")
+        return [dict(layer=l, update=names[j], max_abs=buf[(l * 3 + j) * 4], common_mode=buf[(l * 3 + j) * 4 + 1],
+                     saturated=int(buf[(l * 3 + j) * 4 + 2]), crest=buf[(l * 3 + j) * 4 + 3]) for l in range(self.depth) for j in range(3)]
+
     def set_cross_attention_fusion(self, on: bool):
         """Build extension, A/B switch: the to_q projection + cross-attention core as ONE launch where it applies (one prompt; the default) or
         always as two kernels (``sat_dit_cfg.cross_attention``).  Per model; rebuilds the plan on next use."""

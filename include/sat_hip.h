@@ -184,6 +184,17 @@ int sat_dit_denoise_cfg(sat_dit_plan* plan, const float* x_dev, float sigma, flo
 int sat_dit_profile(sat_dit_plan* plan, int32_t enable);
 int sat_dit_profile_read(sat_dit_plan* plan, double* total_ms, int32_t* launches, int64_t* m, int64_t* n, int64_t* k);
 
+/* Diagnostics of the residual stream, for checkpoints this build could not be run on (the fp16 default rounds the UN-normalised
+ * residual row to 16 bits for the LayerNorm fold and saturates at +-65504 -- models/transformer.py:692-700; real DiT checkpoints are known for
+ * massive-activation channels, the synthetic weights of the test-suite have none).  While enabled (16-bit operand modes), every forward runs one
+ * small reduction kernel behind each of the three residual updates of every block (self-attention to_out, cross-attention to_out, FF-out) and
+ * keeps, over the rows of that update: [0] max |x|, [1] max over rows of |mean| / std (the common-mode ratio the fold's error grows with:
+ * 3.7e-3 at 0, 2.1e-2 at 8, tests/test_gpu_kernels.py::test_ln_fold_rows_with_common_mode), [2] the number of elements beyond +-65504,
+ * [3] max over rows of max |x| / rms.  sat_dit_debug_read copies the [depth][3][4] floats of the LAST forward to the host (synchronises the
+ * stream).  Enabling allocates, disabling frees: not for the timed path.  What to do with it: see README "Checking a real checkpoint". */
+int sat_dit_debug(sat_dit_plan* plan, int32_t enable);
+int sat_dit_debug_read(sat_dit_plan* plan, float* out_host, int32_t capacity_floats, sat_stream_t stream);
+
 /* Batched-CFG combine alone (models/dit.py:336-345): model_out_dev [2*b, c, t] (cond half, then
  * uncond half) -> out_dev [b, c, t] = uncond + (cond - uncond) * cfg_scale, with the optional
  * std rescale when scale_phi != 0. */

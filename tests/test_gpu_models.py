@@ -86,6 +86,35 @@ def test_cross_attention_fusion_on_off(dev, small_dit):
             assert_close("fused vs separate cross-attention, 3 sequences", fused, separate, T(2e-3))
 
 
+def test_residual_stream_report(dev, small_dit):
+    """sat_dit_debug (round 6): the per-block statistics of the fp32 residual stream a forward leaves behind -- checked against the same quantities
+    of the oracle's residual stream for the LAST update (FF-out of the last block = the transformer's output rows), and for what the report is for:
+    a residual stream pushed beyond the fp16 range is counted, one with a common-mode offset is reported with its ratio."""
+    from stable_audio_tools import _hip
+    cfg, model, sd = small_dit
+    dc = cfg["model"]["diffusion"]["config"]
+    dit = model.model.model
+    x, c, g = _inputs(2, 77, dc["cond_token_dim"], seed=3)
+    t = torch.tensor([0.31, 0.87])
+    run = lambda xs: model.model(xs.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0)
+    base = run(x).cpu()
+    dit.residual_stream_report(True)
+    try:
+        same = run(x).cpu()
+        rep = dit.residual_stream_report(False)
+    finally:
+        pass
+    assert torch.equal(base, same), "the diagnostics changed the result"
+    assert len(rep) == dc["depth"] * 3 and all(r["saturated"] == 0 for r in rep)
+    assert all(0.0 < r["max_abs"] < 1e4 and r["crest"] >= 1.0 and r["common_mode"] >= 0.0 for r in rep), rep[:3]
+    # an input 3e5 times larger: the input projection is linear, so the first residual rows leave the fp16 range and the report says so
+    dit.residual_stream_report(True)
+    run(x * 3e5)
+    rep_big = dit.residual_stream_report(False)
+    assert rep_big[0]["max_abs"] > 65504.0 and rep_big[0]["saturated"] > 0, rep_big[0]
+    print(f"\n[residual stream report] first update: {rep[0]}\n  scaled input: {rep_big[0]}")
+
+
 def test_layernorm_fusion_on_off(dev, small_dit):
     """The standalone-LayerNorm plan (sat_dit_cfg.ln_fold = 0) against ITS matched oracle (plain bf16 rounding points), and the two
     plans against each other: they differ only in where the activation is rounded (before / after the normalisation)."""
