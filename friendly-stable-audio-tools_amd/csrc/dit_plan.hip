@@ -112,7 +112,6 @@ struct sat_dit_plan {
     int f16 = 0;                    // cfg.gemm_dtype == 3: every 16-bit operand buffer holds IEEE fp16 and the fp16 build of the kernels runs
     bool cross_fusion = true;       // cfg.cross_attention == 0: to_q + cross-attention core in one launch where it applies
     int tile_bits = 0;              // cfg.tile_policy as GemmArgs::variant bits (sat_tile_policy_bits)
-    int m_tail = 0;                 // cfg.m_tail: the M-tail of to_out / FF-in on the skinny kernel (launch_tail in run_forward)
     bool ln_fold = false;           // cfg.ln_fold, bf16 / fp16 operands, "prepend" conditioning: LayerNorms run inside the GEMM epilogues
     int fp8_mode = 2;               // 2: v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales, 2x rate); 1: v_mfma_f32_32x32x16_fp8_fp8
     // gemm_dtype == 1: which GEMM families take e4m3 operands (sat_dit_cfg.fp8_families; SAT_FP8_* bits); 0 in every other mode
@@ -399,31 +398,6 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
     SAT_TRY(glue_input_proj(x, p->win_eff, w.X, bf, xB, C, T, S, D, xscale, s));
 
     if (p->dbg) SAT_HIP(hipMemsetAsync(p->dbg, 0, (size_t)c.depth * 3 * 4 * sizeof(float), s));
-    // ---- M-tail (sat_dit_cfg.m_tail; profiles/r06_mtail_pricing.txt, r06_mtail_split.txt).  M = bf * 1025 is 64 whole 256-row tiles plus 16 rows at eight
-    // prompts, and the near-empty 65th row of tiles costs the persistent 8-phase FF-in 27 us (every column tile streams its W panel for 16 rows: 48 extra
-    // half-cost tiles behind 12 whole rounds) and keeps to_out off the tile that fits (256 x 192: 512 tiles = 2.0 rounds).  nn.Linear is per row, so those
-    // two GEMMs run on the rows of their whole tiles and the leftover rows on the weight-streaming kernel of gemm_skinny.hip, same stream, right behind.
-    // which: 1 = to_out (tile chosen for the whole-tile M), 2 = FF-in (keeps the tile measured for the whole M)
-    const bool tail_on = p->m_tail == 1 && !f32 && !adaln && (c.gemm_dtype == 0 || c.gemm_dtype == 3);
-    auto launch_tail = [&](int epi, GemmArgs& ga, int which) -> int {
-        const int mf = (ga.M / 256) * 256;
-        GemmArgs t = ga;
-        t.M -= mf;
-        if (!tail_on || mf < 4096 || t.M == 0 || t.M > 64 || !sat_gemm_skinny_supports(epi, t)) return sat_launch_gemm(epi, ga, s);
-        if (which == 2) ga.m_choose = ga.M;
-        ga.M = mf;
-        SAT_TRY(sat_launch_gemm(epi, ga, s));
-        t.A += (size_t)mf * t.K;
-        if (t.C) t.C += (size_t)mf * t.ldc;
-        if (t.H) t.H += (size_t)mf * (t.N / 2);
-        if (t.xb) t.xb += (size_t)mf * t.N;
-        if (t.ln_part_out) t.ln_part_out += (size_t)mf * (t.N >> 6) * 2;
-        if (t.ln_part) t.ln_part += (size_t)mf * (t.K >> 6) * 2;
-        t.slab = nullptr;
-        t.slab_bytes = 0;
-        t.variant = (t.variant & ~0xff) | 90;
-        return sat_launch_gemm(epi, t, s);
-    };
     GemmArgs g{};
     for (int l = 0; l < c.depth && f32; ++l) {
         // fp32 verification mode: the same block (transformer.py:656-702) on f32_ref.hip, fp32 everywhere
@@ -482,7 +456,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
         if (p->f8_o) { g.fp8 = 3; g.a_bscale = (const unsigned*)w.AOs; g.w_scale = L.s_o; }
         if (adaln) { g.gate = mod + 2 * D; g.gate_rows = S; g.gate_ld = ssg_ld; }
         fold_out(g);
-        SAT_TRY(launch_tail(EPI_RESID, g, 1));
+        SAT_TRY(sat_launch_gemm(EPI_RESID, g, s));
         if (p->dbg) SAT_TRY(glue_resid_stats(w.X, M, D, p->dbg + ((size_t)l * 3 + 0) * 4, s));
         // ---- cross-attention branch (transformer.py:694-695).  Sequences whose context is all-zero (the
         // unconditional CFG half, dit.py:294-300) get k = v = 0 from the bias-free to_cond_embed / to_kv, hence an
@@ -544,9 +518,7 @@ int run_forward(sat_dit_plan* p, const float* x, int xB, float xscale, const flo
             }
             SAT_HIP(hipEventRecord(p->prof_ev[2 * p->prof_n], s));
         }
-        const int ffin_m = g.M;
-        SAT_TRY(launch_tail(EPI_SWIGLU, g, 2));
-        g.M = ffin_m;          // (the profile hook reports the whole GEMM)
+        SAT_TRY(sat_launch_gemm(EPI_SWIGLU, g, s));
         if (prof) {
             SAT_HIP(hipEventRecord(p->prof_ev[2 * p->prof_n + 1], s));
             p->prof_n++;
@@ -575,11 +547,11 @@ extern "C" int sat_dit_plan_create(const sat_dit_cfg* cfg, sat_dit_plan** out_pl
 
 extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_bytes, sat_dit_plan** out_plan) {
     SAT_CHECK_ARG(cfg_in && out_plan, SAT_E_INVALID, "dit_plan_create: null argument");
-    static_assert(sizeof(sat_dit_cfg) == SAT_DIT_CFG_BYTES_V5 + 4 && offsetof(sat_dit_cfg, m_tail) == SAT_DIT_CFG_BYTES_V5, "sat_dit_cfg layout");
-    SAT_CHECK_ARG(cfg_bytes == sizeof(sat_dit_cfg) || cfg_bytes == SAT_DIT_CFG_BYTES_V5, SAT_E_INVALID,
-                  "dit_plan_create: sat_dit_cfg of %zu bytes; this library (ABI version %d) knows %zu and %d (the version-5 layout)", cfg_bytes, sat_version(),
-                  sizeof(sat_dit_cfg), SAT_DIT_CFG_BYTES_V5);
-    sat_dit_cfg cfg_local{};              // fields behind the caller's struct keep their defaults (0)
+    static_assert(sizeof(sat_dit_cfg) == SAT_DIT_CFG_BYTES_V5, "sat_dit_cfg layout");
+    // (the one layout this library knows; when the struct grows again, the older sizes are accepted here and the fields behind them defaulted)
+    SAT_CHECK_ARG(cfg_bytes == sizeof(sat_dit_cfg), SAT_E_INVALID, "dit_plan_create: sat_dit_cfg of %zu bytes; this library (ABI version %d) knows %zu",
+                  cfg_bytes, sat_version(), sizeof(sat_dit_cfg));
+    sat_dit_cfg cfg_local{};
     memcpy(&cfg_local, cfg_in, cfg_bytes);
     const sat_dit_cfg* cfg = &cfg_local;
     SAT_CHECK_ARG(cfg->embed_dim > 0 && cfg->num_heads > 0 && cfg->embed_dim == cfg->num_heads * 64, SAT_E_UNSUPPORTED,
@@ -604,7 +576,6 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
     SAT_CHECK_ARG(cfg->gemm_dtype == 1 || cfg->fp8_families == 0, SAT_E_INVALID,
                   "dit_plan_create: fp8_families = 0x%x with gemm_dtype %d (a caller built against an older sat_dit_cfg layout?)", cfg->fp8_families, cfg->gemm_dtype);
     SAT_CHECK_ARG(cfg->cross_attention == 0 || cfg->cross_attention == 1, SAT_E_INVALID, "dit_plan_create: cross_attention must be 0 (fused where it applies) or 1 (two kernels)");
-    SAT_CHECK_ARG(cfg->m_tail == 0 || cfg->m_tail == 1, SAT_E_INVALID, "dit_plan_create: m_tail must be 0 or 1");
     SAT_CHECK_ARG(cfg->tile_policy == 0 || cfg->tile_policy == 22 || cfg->tile_policy == 80 || cfg->tile_policy == 81 || cfg->tile_policy == 82, SAT_E_INVALID,
                   "dit_plan_create: tile_policy must be 0 / 80 (default), 22, 81 or 82");
     const int fam = cfg->fp8_families ? cfg->fp8_families : SAT_FP8_DEFAULT;
@@ -626,7 +597,6 @@ extern "C" int sat_dit_plan_create_sized(const sat_dit_cfg* cfg_in, size_t cfg_b
     }
     p->cross_fusion = cfg->cross_attention == 0;
     p->tile_bits = sat_tile_policy_bits(cfg->tile_policy);
-    p->m_tail = cfg->m_tail;
     p->ln_fold = cfg->ln_fold != 0 && (cfg->gemm_dtype == 0 || cfg->gemm_dtype == 3) && !cfg->adaln && cfg->embed_dim >= 256;
     *out_plan = p;
     return 0;

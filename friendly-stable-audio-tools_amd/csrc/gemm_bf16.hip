@@ -1508,10 +1508,9 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
     }
     // fill of the last round of the device's CUs (256 on MI355X) x measured in-kernel rate of the tile, relative to the 256x256 tile
     const long cus = std::max(1, sat_device_cus());
-    const int m_ch = a.m_choose > 0 ? a.m_choose : a.M;
     auto score = [&](int bm, int bn, double rate) {
         if (a.N % bn) return 0.0;
-        long t = (long)cdiv(m_ch, bm) * (a.N / bn);
+        long t = (long)cdiv(a.M, bm) * (a.N / bn);
         return rate * (double)t / (double)(((t + cus - 1) / cus) * cus);
     };
 #ifndef SAT_OPERAND_F16          // e4m3 operands ride in the bf16 build (sat_launch_gemm rejects f16 && fp8): the fp16 build does not instantiate them
@@ -1563,7 +1562,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             double s256 = score(256, 256, 1.0);
             if (sat_wide_tile_of(a.variant) >= 80 && sat_gemm_ph8_supports(EPI, a)) {
                 const double rate = EPI == EPI_SWIGLU ? 1.26 : EPI == EPI_HEADS ? 1.07 : 1.02;
-                const long t = (long)cdiv(m_ch, 256) * (a.N / 256);
+                const long t = (long)cdiv(a.M, 256) * (a.N / 256);
                 const double rounds = sat_gemm_ph8_splits(EPI, a) ? (double)(t / cus) + 0.35 : (double)((t + cus - 1) / cus);
                 s256 = rate * (double)t / (rounds * (double)cus);
             }
@@ -1578,7 +1577,7 @@ int launch_epi(const GemmArgs& a, hipStream_t stream) {
             if (v == 15 && EPI == EPI_F32 && a.K >= 4096 && !deep_ring_off()) v = 44;
             // one round of 128 x 128 tiles (to_out / FF-out at one prompt: 204 workgroups on 256 CUs): the two-K-group build puts 8 waves of
             // 64 x 64 on every CU instead of 8 waves of 32 x 64 -- FF-out 56.5 us against 60.7, to_out 20.6 against 21.4 (tools/ph8_probe.py narrow)
-            if ((v == 15 || v == 44) && EPI == EPI_F32 && !a.fp8 && a.K % 128 == 0 && a.K >= 256 && (long)cdiv(m_ch, 128) * (a.N / 128) <= cus &&
+            if ((v == 15 || v == 44) && EPI == EPI_F32 && !a.fp8 && a.K % 128 == 0 && a.K >= 256 && (long)cdiv(a.M, 128) * (a.N / 128) <= cus &&
                 !(a.variant & 0x800000) && sat_wide_tile_of(a.variant) != 82)
                 v = 49;
         } else {
@@ -1659,7 +1658,6 @@ int SAT_OPNS::sat_launch_gemm(int epi, const GemmArgs& a, hipStream_t stream) {
                                  (((uintptr_t)a.ln_part | (uintptr_t)a.ln_c1 | (uintptr_t)a.ln_c2) & 15) == 0),
                   SAT_E_INVALID, "gemm: LayerNorm fold needs ln_c1 / ln_c2 / ln_eps, no separate bias (it is part of ln_c2), 16-byte aligned vectors");
     SAT_CHECK_ARG((((uintptr_t)a.xb | (uintptr_t)a.ln_part_out) & 15) == 0, SAT_E_INVALID, "gemm: xb / ln_part_out must be 16-byte aligned");
-    if ((a.variant & 0xff) == 90) return sat_launch_gemm_skinny(epi, a, stream);          // a few rows: the weight-streaming kernel of gemm_skinny.hip
     if ((a.variant & 0xfff) % 100 == 80 || (a.variant & 0xfff) % 100 == 81) return sat_launch_gemm_ph8(epi, a, stream);      // 256x256x64, 8 waves, 8-phase schedule (gemm_ph8.hip)
     switch (epi) {
         case EPI_F32:

@@ -327,9 +327,6 @@ struct GemmArgs {
     // workspace), used by this launch only; nullptr = the remainder round's tiles stay whole.
     float* slab;
     size_t slab_bytes;
-    // M the automatic tile choice is made for, if not this launch's own (0): the whole-tile launch of an M-tail split (dit_plan.hip) keeps the tile
-    // measured for the whole problem where that is the better one (FF-in: 3072 whole tiles score differently from 3120 with a near-empty row)
-    int m_choose;
 };
 
 // bf16 build: checks a.f16 and forwards fp16 work to sat_launch_gemm_f16 (the fp16 build of the same file)
@@ -338,8 +335,6 @@ bool sat_gemm_ph8_supports(int epi, const GemmArgs& a);
 bool sat_gemm_ph8_splits(int epi, const GemmArgs& a);       // the automatic schedule would split the remainder round along K
 size_t sat_gemm_ph8_slab_bytes(int epi, int M, int N, int K);      // slab workspace that makes it do so (0: never for this shape)
 int sat_launch_gemm_ph8(int epi, const GemmArgs& a, hipStream_t stream);     // gemm_ph8.hip: the 8-wave / 8-phase 256x256 tile
-bool sat_gemm_skinny_supports(int epi, const GemmArgs& a);
-int sat_launch_gemm_skinny(int epi, const GemmArgs& a, hipStream_t stream);  // gemm_skinny.hip: <= 64 rows, weight-streaming (variant 90)
 // out_scales != nullptr: MXFP8 output (e4m3 bytes at `out`, E8M0 per 32 channels at out_scales [b*sq][h*2]) instead of bf16
 // q_scale: what the kernel still has to multiply in -- SAT_ATTN_QSCALE = 1/sqrt(64) * log2(e) for a plain Q, 1.0f for a Q the
 // producer already wrote pre-scaled (HeadsEpi kind bit 3): only then the single-KV-group kernel carries its softmax reference

@@ -25,7 +25,7 @@ class SatDitCfg(Structure):
     _fields_ = [("io_channels", c_int32), ("embed_dim", c_int32), ("depth", c_int32), ("num_heads", c_int32),
                 ("cond_token_dim", c_int32), ("cond_embed_dim", c_int32), ("global_cond_dim", c_int32),
                 ("max_seq_len", c_int32), ("adaln", c_int32), ("gemm_dtype", c_int32), ("fp8_families", c_int32), ("ln_fold", c_int32),
-                ("cross_attention", c_int32), ("tile_policy", c_int32), ("m_tail", c_int32)]
+                ("cross_attention", c_int32), ("tile_policy", c_int32)]
 
 
 class SatT5Cfg(Structure):

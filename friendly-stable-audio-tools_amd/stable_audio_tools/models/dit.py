@@ -8,7 +8,6 @@ batched CFG, dit.py:228-364); ``denoise`` is the fused k-diffusion ``VDenoiser``
 the sampler loop uses (one ``sat_dit_denoise_cfg`` call per step).
 """
 import ctypes
-import os
 import typing as tp
 
 import torch
@@ -79,7 +78,6 @@ class DiffusionTransformer(nn.Module):
         self.layernorm_fusion = True
         self.cross_attention_fusion = True
         self.tile_policy = 0
-        self.m_tail = int(os.environ.get("SAT_M_TAIL", "0"))         # sat_dit_cfg.m_tail
 
     def residual_stream_report(self, enable: bool = True):
         """Build extension (``sat_dit_debug``), for checkpoints this build was never run on.  ``residual_stream_report(True)`` switches the
@@ -101,16 +99,6 @@ class DiffusionTransformer(nn.Module):
         names = ("self_attn.to_out", "cross_attn.to_out", "ff.out")
         return [dict(layer=l, update=names[j], max_abs=buf[(l * 3 + j) * 4], common_mode=buf[(l * 3 + j) * 4 + 1],
                      saturated=int(buf[(l * 3 + j) * 4 + 2]), crest=buf[(l * 3 + j) * 4 + 3]) for l in range(self.depth) for j in range(3)]
-
-    def set_m_tail(self, mode: int):
-        """Build extension, experiment switch (``sat_dit_cfg.m_tail``): 1 = to_out and FF-in on the rows of their whole 256-row tiles, the leftover rows on
-        the skinny kernel; 0 = one launch per GEMM.  Per model; rebuilds the plan on next use."""
-        if mode not in (0, 1):
-            raise ValueError("m_tail must be 0 or 1")
-        if mode != self.m_tail:
-            self.m_tail = mode
-            self._plan_version = None
-        return self
 
     def set_cross_attention_fusion(self, on: bool):
         """Build extension, A/B switch: the to_q projection + cross-attention core as ONE launch where it applies (one prompt; the default) or
@@ -177,7 +165,7 @@ class DiffusionTransformer(nn.Module):
         cfg = _hip.SatDitCfg(self.io_channels, self.embed_dim, self.depth, self.num_heads, self.cond_token_dim,
                              self.cond_embed_dim, self.global_cond_dim, self.max_seq_len,
                              1 if self.global_cond_type == "adaLN" else 0, GEMM_DTYPES[self.gemm_dtype], FP8_FAMILIES.get(self.gemm_dtype, 0),
-                             1 if self.layernorm_fusion else 0, 0 if self.cross_attention_fusion else 1, self.tile_policy, self.m_tail)
+                             1 if self.layernorm_fusion else 0, 0 if self.cross_attention_fusion else 1, self.tile_policy)
         plan = ctypes.c_void_p()
         _hip.check(lib.sat_dit_plan_create_sized(ctypes.byref(cfg), ctypes.sizeof(cfg), ctypes.byref(plan)))
         keep = []

@@ -123,10 +123,6 @@ typedef struct sat_dit_cfg {
     int32_t tile_policy;       /* 0 / 80 (default): the measured tile choice; A/B measurement switches: 22 = the 16-wave 256 x 256 tile of rounds
                                   1-2 instead of the 8-phase kernel, 81 = the 8-phase kernel also for fp32-output GEMMs with K < 4096, 82 = no
                                   two-K-group 128 x 128 tile */
-    /* ---- version 6 (read by sat_dit_plan_create_sized only; sat_dit_plan_create defaults it to 0) */
-    int32_t m_tail;            /* EXPERIMENT SWITCH (round 6).  1 (gemm_dtype 0 / 3, adaln == 0, from 4096 rows on): to_out and FF-in run on the rows of their
-                                  WHOLE 256-row tiles and the up to 64 rows left over (M = bf * 1025: 16 at eight prompts) on the weight-streaming
-                                  kernel of csrc/gemm_skinny.hip, same stream.  0: one launch per GEMM */
 } sat_dit_cfg;
 #define SAT_DIT_CFG_BYTES_V5 56          /* the layout sat_dit_plan_create reads: 14 int32 fields, up to and including tile_policy */
 

@@ -399,69 +399,6 @@ def test_ln_fold_swiglu(dev, prod, cons, m, fmt):
     assert_close("ln-fold swiglu vs fp32 LayerNorm + Linear", out, val * F.silu(gate), fmt.tol(1e-2))
 
 
-@pytest.mark.parametrize("fmt", FORMATS, ids=repr)
-@pytest.mark.parametrize("m", [2, 16, 37, 64])
-def test_gemm_skinny(dev, m, fmt):
-    """The weight-streaming kernels for a few rows (csrc/gemm_skinny.hip, variant 90: the M-tail launch of sat_dit_cfg.m_tail) through the same unit
-    entries and against the same references as the big tiles: fp32 output with bias + residual at both reduction lengths of the block (K = 1536,
-    6144: the LDS-staged variant; + 0x100: the direct variant) and at one and two chunks (K = 512, 1024), SwiGLU with bias, and the LayerNorm fold on
-    both sides (producer: 16-bit image + partial sums; consumer: SwiGLU; K = 256 / 768: direct variant, K = 1536: LDS-staged)."""
-    _hip, lib = _lib()
-    for n, k, v in ((1536, 1536, 90), (256, 6144, 90), (1536, 1536, 90 | 0x100), (128, 512, 90), (192, 1024, 90), (256, 6144, 90 | 0x100)):
-        a = _rand((m, k), 5).to(fmt.dtype)
-        w = (_rand((n, k), 6) * 0.05 + torch.linspace(-0.02, 0.03, n)[:, None]).to(fmt.dtype)
-        bias, c0 = _rand((n,), 7), _rand((m, n), 8)
-        want = a.float() @ w.float().T + bias + c0
-        ad, wd, bd, cd = a.to(dev), w.to(dev), bias.to(dev), c0.to(dev)
-        _hip.check(fmt.fn(lib, "sat_gemm_bf16_f32")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(cd), m, n, k, 1, v, _hip.stream()))
-        assert_close(f"skinny gemm v{v} {m}x{n}x{k}", cd, want, 1e-3 if not fmt.f16 else 1e-5)
-    # more than 64 rows: refused, not run
-    big = torch.zeros((65, 256), dtype=fmt.dtype, device=dev)
-    rc = fmt.fn(lib, "sat_gemm_bf16_f32")(_hip.ptr(big), _hip.ptr(big), None, _hip.ptr(torch.zeros((65, 256), device=dev)), 65, 256, 256, 0, 90, _hip.stream())
-    assert rc == -2, f"skinny kernel with 65 rows returned {rc}, expected SAT_E_UNSUPPORTED"
-    # SwiGLU with bias
-    k, inner = 256, 768
-    a = _rand((m, k), 9).to(fmt.dtype)
-    w = _rand((2 * inner, k), 10) * 0.08
-    bias = _rand((2 * inner,), 11) * 0.1
-    val, gate = F.linear(a.float(), fmt.round(w), bias).chunk(2, dim=-1)
-    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
-    wp = torch.empty((2 * inner, k), dtype=fmt.dtype, device=dev)
-    bp = torch.empty((2 * inner,), dtype=torch.float32, device=dev)
-    out = torch.full((m, inner), float("nan"), dtype=fmt.dtype, device=dev)
-    _hip.check(fmt.fn(lib, "sat_gemm_swiglu_bf16")(_hip.ptr(ad), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(wp), _hip.ptr(bp), _hip.ptr(out), m, 2 * inner, k, 90,
-                                                   _hip.stream()))
-    assert_close("skinny swiglu", out, val * F.silu(gate), fmt.tol(4e-3))
-    # LayerNorm fold: producer and consumer both on the skinny kernel
-    d = 768
-    cd, xb, part = _ln_fold_producer(dev, m, d, 256, 90, fmt=fmt)
-    w = _rand((2 * inner, d), 50) * 0.08
-    gamma, beta, bias = 0.8 + 0.2 * _rand((d,), 51), 0.1 * _rand((d,), 52), 0.1 * _rand((2 * inner,), 53)
-    wd, gd, bd, bbd = w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev)
-    wp = torch.empty((2 * inner, d), dtype=fmt.dtype, device=dev)
-    c12 = torch.empty((4 * inner,), dtype=torch.float32, device=dev)
-    out = torch.full((m, inner), float("nan"), dtype=fmt.dtype, device=dev)
-    _hip.check(fmt.fn(lib, "sat_gemm_swiglu_ln_bf16")(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(bbd), _hip.ptr(wp),
-                                                      _hip.ptr(c12), _hip.ptr(out), m, 2 * inner, d, 90, _hip.stream()))
-    val, gate = _ln_fold_reference(xb, w, gamma, beta, bias, fmt).chunk(2, dim=-1)
-    assert_close("skinny ln-fold swiglu vs same arithmetic", out, val * F.silu(gate), fmt.tol(4e-3))
-
-    # the same pair at K = 1536 (FF-in's own reduction length): the LDS-staged variant on the consumer side
-    d = 1536
-    cd, xb, part = _ln_fold_producer(dev, m, d, 512, 90, fmt=fmt)
-    inner2 = 256
-    w = _rand((2 * inner2, d), 60) * 0.05
-    gamma, beta, bias = 0.8 + 0.2 * _rand((d,), 61), 0.1 * _rand((d,), 62), 0.1 * _rand((2 * inner2,), 63)
-    wd, gd, bd, bbd = w.to(dev), gamma.to(dev), beta.to(dev), bias.to(dev)
-    wp = torch.empty((2 * inner2, d), dtype=fmt.dtype, device=dev)
-    c12 = torch.empty((4 * inner2,), dtype=torch.float32, device=dev)
-    out = torch.full((m, inner2), float("nan"), dtype=fmt.dtype, device=dev)
-    _hip.check(fmt.fn(lib, "sat_gemm_swiglu_ln_bf16")(_hip.ptr(xb), _hip.ptr(part), _hip.ptr(wd), _hip.ptr(gd), _hip.ptr(bd), _hip.ptr(bbd), _hip.ptr(wp),
-                                                      _hip.ptr(c12), _hip.ptr(out), m, 2 * inner2, d, 90, _hip.stream()))
-    val, gate = _ln_fold_reference(xb, w, gamma, beta, bias, fmt).chunk(2, dim=-1)
-    assert_close("skinny (LDS-staged) ln-fold swiglu vs same arithmetic", out, val * F.silu(gate), fmt.tol(4e-3))
-
-
 @pytest.mark.parametrize("row_mean,outlier", [(0.0, 0.0), (8.0, 0.0), (30.0, 0.0), (0.0, 60.0)])
 def test_ln_fold_rows_with_common_mode(dev, row_mean, outlier):
     """the fold feeds un-normalised bf16(x) to the MFMA and subtracts mean * c1 afterwards, so its rounding error scales with

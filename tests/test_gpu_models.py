@@ -115,27 +115,6 @@ def test_residual_stream_report(dev, small_dit):
     print(f"\n[residual stream report] first update: {rep[0]}\n  scaled input: {rep_big[0]}")
 
 
-def test_m_tail_on_off(dev, small_dit):
-    """sat_dit_cfg.m_tail (round 6): to_out and FF-in on the rows of their whole 256-row tiles + the rows left over on the skinny kernel, against one
-    launch per GEMM.  Per row the arithmetic is the same; the leftover rows are computed in another summation order.  4 x 1030 rows = 4096 + 24."""
-    cfg, model, sd = small_dit
-    dc = cfg["model"]["diffusion"]["config"]
-    dit = model.model.model
-    x, c, g = _inputs(4, 1029, dc["cond_token_dim"], seed=11)
-    t = torch.tensor([0.31, 0.87, 0.5, 0.11])
-    run = lambda: model.model(x.to(dev), t.to(dev), cross_attn_cond=c.to(dev), global_cond=g.to(dev), cfg_scale=1.0).cpu()
-    one = run()
-    try:
-        dit.set_m_tail(1)
-        two = run()
-        assert torch.equal(two, run()), "the split path is not repeatable"
-    finally:
-        dit.set_m_tail(0)
-    assert torch.isfinite(two).all() and not torch.equal(one, two), "the tail launch did not run"
-    e = assert_close("M-tail on the skinny kernel vs one launch per GEMM, 4 x 1030 rows", two, one, T(8e-3))
-    print(f"\n[m_tail, 4 x 1030 rows] rel-L2 split vs single launch {e:.2e}")
-
-
 def test_layernorm_fusion_on_off(dev, small_dit):
     """The standalone-LayerNorm plan (sat_dit_cfg.ln_fold = 0) against ITS matched oracle (plain bf16 rounding points), and the two
     plans against each other: they differ only in where the activation is rounded (before / after the normalisation)."""

@@ -72,8 +72,6 @@ def main():
             model = S.create_model_from_config(MC.stable_audio_open_1_0())
         model.load_state_dict(synthetic.synth_state_dict(model.state_dict(), 0))
         dit = model.to(dev).eval().model.model
-        if "m_tail" in opts:
-            dit.set_m_tail(opts["m_tail"])
         if "tile_policy" in opts:
             dit.set_tile_policy(opts["tile_policy"])
         dits[name] = dit
